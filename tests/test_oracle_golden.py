@@ -1,0 +1,72 @@
+"""Pins the oracle (oracle/ar.py) against golden vectors produced by the imported reference
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ar as O
+from tests.shapes import tiny_shape, tiny_shape_b
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+CASES = [("greedy_rep1.0", dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.0), None),
+         ("greedy_rep1.1", dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1), None),
+         ("sampled_seed7", dict(temperature=0.7, top_p=0.8, repetition_penalty=1.1), 7),
+         ("sampled_seed11", dict(temperature=1.0, top_p=0.95, repetition_penalty=1.5), 11)]
+
+
+@pytest.mark.parametrize("name,shape_fn,dtype,n_new", [
+    ("ar_tiny_f32", tiny_shape, torch.float32, 16),
+    ("ar_tiny_bf16", tiny_shape, torch.bfloat16, 16),
+    ("ar_tinyb_f32", tiny_shape_b, torch.float32, 12),
+    ("ar_tinyb_bf16", tiny_shape_b, torch.bfloat16, 12),
+])
+def test_ar_oracle_matches_reference(name, shape_fn, dtype, n_new):
+    torch.set_num_threads(4)
+    gold = np.load(os.path.join(G, name + ".npz"))
+    shape = shape_fn()
+    orc = O.AROracle(shape, O.random_weights(shape, seed=0), dtype)
+    prompt = torch.from_numpy(gold["prompt"])
+    for cname, kw, seed in CASES:
+        orc.reset()
+        if seed is not None:
+            torch.manual_seed(seed)
+        seq = orc.generate(prompt.clone(), n_new, **kw)
+        assert np.array_equal(seq.numpy(), gold[f"{cname}.seq"]), cname
+        orc.reset()
+        if seed is not None:
+            torch.manual_seed(seed)
+        cols = orc.generate_stream(prompt.clone(), n_new, **kw)
+        assert np.array_equal(torch.cat(cols, dim=1).numpy(), gold[f"{cname}.stream"]), cname
+    # frame-0 logits/hidden: bit-equal (same ops, same order)
+    orc.reset()
+    with torch.inference_mode():
+        logits, hidden = orc.slow_forward(prompt.view(1, shape.num_codebooks + 1, -1), torch.arange(prompt.size(1)))
+    assert np.array_equal(logits.float().numpy().reshape(-1), gold["frame0.logits"])
+    assert np.array_equal(hidden.float().numpy().reshape(-1), gold["frame0.hidden"])
+
+
+def test_sampling_oracle_matches_reference():
+    gold = np.load(os.path.join(G, "sampling.npz"))
+    for tag, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        for V in (1024, 2320):
+            logits = torch.from_numpy(gold[f"{tag}.V{V}.logits"]).to(dtype)
+            prev = torch.from_numpy(gold[f"{tag}.V{V}.prev"])
+            for tp in (0.8, 0.2, 1.0, 1e-6):
+                for rep in (1.0, 1.1, 1.5):
+                    l = logits.clone()
+                    probs = O.logits_to_probs(l, torch.tensor(0.7), torch.tensor(tp), torch.tensor(rep), prev)
+                    key = f"{tag}.V{V}.tp{tp}.rep{rep}"
+                    assert np.array_equal(probs.float().numpy(), gold[key + ".probs"]), key
+                    assert np.array_equal(l.float().numpy(), gold[key + ".penalised"]), key
+
+
+def test_batch_drops_last_column_stream_keeps_it():
+    """inference.py:839 vs 721/271: batch mode returns n-1 usable frames, streaming n."""
+    gold = np.load(os.path.join(G, "ar_tiny_f32.npz"))
+    T = gold["prompt"].shape[1]
+    seq, stream = gold["greedy_rep1.1.seq"], gold["greedy_rep1.1.stream"]
+    assert seq.shape[1] - T == stream.shape[1]
+    assert np.array_equal(seq[1:, T:], stream)
