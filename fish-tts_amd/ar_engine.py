@@ -1,0 +1,219 @@
+"""Host driver of the HIP dual-AR path: the Python side of the S2 seam —
+init_model / generate / generate_streaming of fish_tts/models/inference.py:281-414,645-738 — on top
+of the C ABI (include/fishtts_hip.h).  torch is used only to hold weight tensors."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterator, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .config import DualARModelArgs
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _rope_table(n_pos: int, n_elem: int, base: float) -> torch.Tensor:
+    """cos/sin pairs rounded to bf16, as the reference builds them (llama.py:594-603), returned as f32."""
+    expo = torch.arange(0, n_elem, 2)[: n_elem // 2].float() / n_elem
+    inv_freq = 1.0 / (base ** expo)
+    ang = torch.outer(torch.arange(n_pos), inv_freq)
+    z = torch.polar(torch.ones_like(ang), ang)
+    return torch.stack([z.real, z.imag], dim=-1).to(torch.bfloat16).float().contiguous()
+
+
+def normalise_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Key layout handling of llama.py:484-498 and the wq/wk/wv -> wqkv fuse of llama.py:222-227."""
+    if "state_dict" in sd:
+        sd = sd["state_dict"]
+    if next(iter(sd.keys())).startswith("model."):
+        sd = {k.replace("model.", ""): v for k, v in sd.items()}
+    sd = {k: v for k, v in sd.items() if "audio_" not in k}
+    out = dict(sd)
+    for k in list(sd.keys()):
+        if k.endswith("attention.wq.weight"):
+            pre = k[: -len("wq.weight")]
+            out[pre + "wqkv.weight"] = torch.cat([out.pop(pre + "wq.weight"), out.pop(pre + "wk.weight"),
+                                                  out.pop(pre + "wv.weight")])
+    return out
+
+
+class ARHipEngine:
+    """One GPU context holding the dual-AR weights, KV caches and the captured frame graph."""
+
+    def __init__(self, args: DualARModelArgs, semantic_begin_id: int, semantic_end_id: int, im_end_id: int,
+                 precision: str = "bf16", device: int = 0, max_batch: int = 1, max_new_tokens: int = 2048,
+                 codec_cfg: Optional[L.ft_codec_config] = None):
+        if precision not in ("bf16", "fp32"):
+            raise NotImplementedError(f"precision {precision!r}: the MI355X path implements 'bf16' and 'fp32'")
+        self.args = args
+        self.precision = precision
+        self.lib = L.load()
+        c = L.ft_ar_config()
+        c.dtype = L.FT_BF16 if precision == "bf16" else L.FT_F32
+        for name in ("vocab_size", "n_layer", "n_head", "dim", "intermediate_size", "n_local_heads", "head_dim",
+                     "max_seq_len", "codebook_size", "num_codebooks", "n_fast_layer", "fast_dim", "fast_n_head",
+                     "fast_n_local_heads", "fast_head_dim", "fast_intermediate_size"):
+            setattr(c, name, int(getattr(args, name)))
+        for name in ("tie_word_embeddings", "attention_qkv_bias", "attention_o_bias", "attention_qk_norm",
+                     "scale_codebook_embeddings", "fast_attention_qkv_bias", "fast_attention_qk_norm",
+                     "fast_attention_o_bias"):
+            setattr(c, name, 1 if getattr(args, name) else 0)
+        c.rope_base = float(args.rope_base)
+        c.norm_eps = float(args.norm_eps)
+        c.semantic_begin_id, c.semantic_end_id, c.im_end_id = int(semantic_begin_id), int(semantic_end_id), int(im_end_id)
+        c.max_batch, c.max_new_tokens = int(max_batch), int(max_new_tokens)
+        self.cfg = c
+        self.R = args.num_codebooks + 1
+        self.max_batch = max_batch
+        self.max_new_tokens = max_new_tokens
+        self.im_end_id = im_end_id
+        self._h = C.c_void_p()
+        st = self.lib.ft_create(C.byref(c), C.byref(codec_cfg) if codec_cfg is not None else None, device,
+                                C.byref(self._h))
+        if st != L.FT_OK:
+            raise HipError(f"ft_create failed ({st}): {self.lib.ft_last_error(None).decode()}")
+        self._loaded = False
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.ft_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st: int, what: str):
+        if st == L.FT_OK:
+            return
+        msg = self.lib.ft_last_error(self._h).decode()
+        if st == L.FT_ERR_TOO_LONG:
+            raise ValueError(msg)  # inference.py:296-299
+        raise HipError(f"{what} failed ({st}): {msg}")
+
+    # ------------------------------------------------------------------ weights
+    def load_tensor(self, name: str, t: torch.Tensor):
+        t = t.detach()
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            t = t.float()
+        t = t.contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        dt = L.FT_F32 if t.dtype == torch.float32 else L.FT_BF16
+        self._check(self.lib.ft_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), dt, shape, t.dim()),
+                    f"ft_load_weight({name})")
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], finalize: bool = True):
+        a = self.args
+        sd = normalise_state_dict(sd)
+        for k, v in sd.items():
+            if k.endswith(("freqs_cis", "causal_mask")) or "kv_cache" in k:
+                continue
+            self.load_tensor(k, v)
+        self.load_tensor("rope.slow", _rope_table(a.max_seq_len, a.head_dim, a.rope_base))
+        self.load_tensor("rope.fast", _rope_table(a.num_codebooks, a.fast_head_dim, a.rope_base))
+        if finalize:
+            self.finalize()
+
+    def finalize(self):
+        self._check(self.lib.ft_finalize_weights(self._h), "ft_finalize_weights")
+        self._loaded = True
+
+    # ------------------------------------------------------------------ primitives
+    @staticmethod
+    def _sampling(temperature, top_p, repetition_penalty, seed=0, ban_eos=False) -> L.ft_sampling:
+        s = L.ft_sampling()
+        s.temperature, s.top_p, s.repetition_penalty = float(temperature), float(top_p), float(repetition_penalty)
+        s.seed, s.ban_eos = int(seed) & (2 ** 64 - 1), 1 if ban_eos else 0
+        return s
+
+    def prefill(self, prompt: np.ndarray, sampling: L.ft_sampling, slot: int = 0) -> np.ndarray:
+        prompt = np.ascontiguousarray(prompt, dtype=np.int32)
+        assert prompt.ndim == 2 and prompt.shape[0] == self.R, prompt.shape
+        out = np.zeros(self.R, dtype=np.int32)
+        self._check(self.lib.ft_ar_prefill(self._h, slot, prompt.ctypes.data_as(C.c_void_p), prompt.shape[1],
+                                           C.byref(sampling), out.ctypes.data_as(C.c_void_p)), "ft_ar_prefill")
+        return out
+
+    def decode(self, n_frames: int, samplings: Sequence[L.ft_sampling], poll: int = 8):
+        ns = len(samplings)
+        arr = (L.ft_sampling * ns)(*samplings)
+        frames = np.zeros((ns, max(n_frames, 1), self.R), dtype=np.int32)
+        n = np.zeros(ns, dtype=np.int32)
+        self._check(self.lib.ft_ar_decode(self._h, ns, n_frames, arr, poll, frames.ctypes.data_as(C.c_void_p),
+                                          n.ctypes.data_as(C.c_void_p)), "ft_ar_decode")
+        return frames, n
+
+    def set_noise(self, q: Optional[np.ndarray]):
+        if q is None:
+            self._check(self.lib.ft_ar_set_noise(self._h, None, 0, 0), "ft_ar_set_noise")
+            return
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        self._check(self.lib.ft_ar_set_noise(self._h, q.ctypes.data_as(C.c_void_p), q.shape[0], q.shape[1]),
+                    "ft_ar_set_noise")
+
+    def debug_state(self, slot: int = 0):
+        logits = np.zeros(self.args.vocab_size, dtype=np.float32)
+        hidden = np.zeros(self.args.fast_dim, dtype=np.float32)
+        self._check(self.lib.ft_ar_get_debug(self._h, slot, logits.ctypes.data_as(C.c_void_p),
+                                             hidden.ctypes.data_as(C.c_void_p)), "ft_ar_get_debug")
+        return logits, hidden
+
+    def sync(self):
+        self._check(self.lib.ft_sync(self._h), "ft_sync")
+
+    def profile_gemv(self, frames: int, sampling: L.ft_sampling):
+        ms, n, b = C.c_double(), C.c_int64(), C.c_int64()
+        self._check(self.lib.ft_ar_profile_gemv(self._h, frames, C.byref(sampling), C.byref(ms), C.byref(n),
+                                                C.byref(b)), "ft_ar_profile_gemv")
+        return ms.value, n.value, b.value
+
+    # ------------------------------------------------------------------ generate (inference.py:281-384)
+    def _clamp_new(self, T: int, max_new_tokens: int) -> int:
+        m = self.args.max_seq_len
+        if T >= m:
+            raise ValueError(f"Input sequence length {T} exceeds max_seq_len {m}")
+        if max_new_tokens:
+            if T + max_new_tokens > m:
+                max_new_tokens = m - T
+        else:
+            max_new_tokens = m - T
+        return min(max_new_tokens, self.max_new_tokens)
+
+    def generate(self, prompt: np.ndarray, max_new_tokens: int, temperature: float = 0.7, top_p: float = 0.7,
+                 repetition_penalty: float = 1.5, seed: int = 0, ban_eos: bool = False, poll: int = 8) -> np.ndarray:
+        """(R, T) int32 prompt -> (R, T + n) int32, n <= max_new_tokens, stopping after <|im_end|>."""
+        prompt = np.ascontiguousarray(prompt, dtype=np.int32)
+        T = prompt.shape[1]
+        n_new = self._clamp_new(T, max_new_tokens)
+        sp = self._sampling(temperature, top_p, repetition_penalty, seed, ban_eos)
+        first = self.prefill(prompt, sp, 0)
+        frames, n = self.decode(n_new - 1, [sp], poll)
+        return np.concatenate([prompt, first[:, None], frames[0, : n[0]].T], axis=1)
+
+    def generate_streaming(self, prompt: np.ndarray, max_new_tokens: int, temperature: float = 0.7,
+                           top_p: float = 0.7, repetition_penalty: float = 1.5, seed: int = 0,
+                           ban_eos: bool = False, chunk: int = 8) -> Iterator[np.ndarray]:
+        """Yields (num_codebooks, k) code blocks as they are produced, <|im_end|> frame included
+        (inference.py:645-738, 218-276); `chunk` frames per graph burst."""
+        prompt = np.ascontiguousarray(prompt, dtype=np.int32)
+        n_new = self._clamp_new(prompt.shape[1], max_new_tokens)
+        sp = self._sampling(temperature, top_p, repetition_penalty, seed, ban_eos)
+        first = self.prefill(prompt, sp, 0)
+        yield first[1:, None]
+        left = n_new - 1
+        while left > 0:
+            k = min(chunk, left)
+            frames, n = self.decode(k, [sp], poll=k)
+            if n[0] > 0:
+                yield frames[0, : n[0], 1:].T
+            left -= k
+            if n[0] < k or (n[0] > 0 and frames[0, n[0] - 1, 0] == self.im_end_id):
+                break

@@ -1,0 +1,804 @@
+// Decode-step kernels of the dual-AR transformer for gfx950 (M = 1..few lock-step rows).
+//
+// Storage convention: activations live in HBM as f32.  In the bf16 model precision every
+// value stored is bf16-representable: it is rounded (rb<ROUND>) at exactly the points where
+// the reference's eager bf16 path rounds, so greedy indices can match.
+// Weights and KV cache are bf16 (or f32 in the f32 precision).
+//
+// Build with -ffp-contract=off: fused multiply-adds appear only where fmaf() is written
+// (dot products); element-wise formulas keep the reference's separate roundings.
+#pragma once
+#include "common.h"
+
+namespace ft {
+
+enum { PRO_NONE = 0, PRO_RMSNORM = 1 };
+enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2 };
+
+// ------------------------------------------------------------------------------------------
+// Weight-streaming GEMV: out[m][n] = epi( sum_k W[n][k] * pro(x[m])[k] + bias[n] )
+//   reference: nn.Linear calls of llama.py:240 (wqkv), 283 (wo), 190 (w1/w3/w2),
+//   449-451 (vocab head), 578 (fast_output), 590 (fast_project_in); RMSNorm prologue =
+//   llama.py:172-177; SwiGLU epilogue = llama.py:190; residual epilogue = llama.py:329-330.
+// One wave owns R consecutive rows; lanes stride K in 16-byte pieces (1 KiB per wave
+// instruction, fully coalesced); all row loads are issued before anything is consumed.
+// ------------------------------------------------------------------------------------------
+struct GemvP {
+    const void* W;
+    const void* bias;
+    const float* x;
+    int ldx;
+    const void* gain;
+    float eps;
+    float* out;
+    int ldo;
+    const float* resid;
+    int ldr;
+    int N, K;
+    int pro, epi;
+};
+
+template <typename WT, int NT, int R, bool ROUND, typename XLoad>
+__device__ __forceinline__ void gemv_rows(const GemvP& p, const int m, const int row0, const int lane,
+                                          XLoad xload) {
+    constexpr int VEC = Vec<WT>::N;
+    constexpr int TILE = 64 * VEC;
+    const WT* W = reinterpret_cast<const WT*>(p.W);
+    const int K = p.K, N = p.N;
+
+    U4 raw[R][NT];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = row0 + r;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int k = t * TILE + lane * VEC;
+            if (row < N && k < K)
+                raw[r][t] = *reinterpret_cast<const U4*>(W + (size_t)row * K + k);
+            else
+                raw[r][t] = U4{0u, 0u, 0u, 0u};
+        }
+    }
+
+    float xv[NT][VEC];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int k = t * TILE + lane * VEC;
+        if (k < K) xload(k, xv[t]);
+        else Vec<WT>::zero(xv[t]);
+    }
+
+    if (p.pro == PRO_RMSNORM) {
+        const WT* gain = reinterpret_cast<const WT*>(p.gain);
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) ss = fmaf(xv[t][j], xv[t][j], ss);
+        ss = wave_sum(ss);
+        const float inv = rsqrt_exact(ss / (float)K + p.eps);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int k = t * TILE + lane * VEC;
+            if (k < K) {
+                float gv[VEC];
+                Vec<WT>::load(gain + k, gv);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) xv[t][j] = rb<ROUND>(rb<ROUND>(xv[t][j] * inv) * gv[j]);
+            }
+        }
+    }
+
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float wv[VEC];
+            Vec<WT>::unpack(raw[r][t], wv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a = fmaf(wv[j], xv[t][j], a);
+        }
+        acc[r] = wave_sum(a);
+    }
+
+    const WT* bias = reinterpret_cast<const WT*>(p.bias);
+    if (p.epi == EPI_SWIGLU) {
+        // rows (2i, 2i+1) = (w1_i, w3_i), interleaved at load time
+#pragma unroll
+        for (int r = 0; r + 1 < R; r += 2) {
+            const int row = row0 + r;
+            if (lane == (r >> 1) && row + 1 < N) {
+                const float a = rb<ROUND>(acc[r]);
+                const float b = rb<ROUND>(acc[r + 1]);
+                const float s = rb<ROUND>(a / (1.0f + expf(-a)));
+                p.out[(size_t)m * p.ldo + (row >> 1)] = rb<ROUND>(s * b);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            if (lane == r && row < N) {
+                float v = acc[r];
+                if (bias) v += ld_elem(bias, row);
+                v = rb<ROUND>(v);
+                if (p.epi == EPI_RESID) v = rb<ROUND>(p.resid[(size_t)m * p.ldr + row] + v);
+                p.out[(size_t)m * p.ldo + row] = v;
+            }
+        }
+    }
+}
+
+template <typename WT, int NT, int R, bool ROUND>
+__global__ __launch_bounds__(256) void gemv_kernel(GemvP p) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= p.N) return;
+    const int m = blockIdx.y;
+    const float* x = p.x + (size_t)m * p.ldx;
+    constexpr int VEC = Vec<WT>::N;
+    gemv_rows<WT, NT, R, ROUND>(p, m, row0, lane, [&](int k, float(&v)[VEC]) {
+#pragma unroll
+        for (int j = 0; j < VEC; j += 4) {
+            const float4 f = *reinterpret_cast<const float4*>(x + k + j);
+            v[j] = f.x; v[j + 1] = f.y; v[j + 2] = f.z; v[j + 3] = f.w;
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// Embedding of one input column (llama.py:409-429): token row + masked sum of the codebook
+// rows, optional 1/sqrt(ncb+1) at VQ positions.  toks[r*tstride + col], r = 0..ncb.
+// ------------------------------------------------------------------------------------------
+struct EmbedP {
+    const void* emb;
+    const void* cb_emb;
+    const int* toks;
+    long tok_row_stride;  // between codebook rows
+    long tok_m_stride;    // between batch rows
+    int col;
+    float* x;
+    int ldx, D, ncb, cbsize, vocab, sem_begin, sem_end, scale;
+    float inv_div;  // (float)sqrt(ncb+1), used as a divisor
+};
+
+template <typename WT, bool ROUND>
+__global__ __launch_bounds__(256) void embed_kernel(EmbedP p) {
+    const int m = blockIdx.y;
+    const int* tk = p.toks + (size_t)m * p.tok_m_stride + p.col;
+    const WT* emb = reinterpret_cast<const WT*>(p.emb);
+    const WT* cbe = reinterpret_cast<const WT*>(p.cb_emb);
+    int t0 = tk[0];
+    const bool is_vq = t0 >= p.sem_begin && t0 <= p.sem_end;
+    t0 = min(max(t0, 0), p.vocab - 1);
+    for (int d = blockIdx.x * 256 + threadIdx.x; d < p.D; d += gridDim.x * 256) {
+        float vq = 0.f;
+        if (is_vq) {
+            for (int i = 0; i < p.ncb; ++i) {
+                int c = tk[(size_t)(i + 1) * p.tok_row_stride];
+                c = min(max(c, 0), p.cbsize - 1);
+                vq += ld_elem(cbe, (size_t)(c + i * p.cbsize) * p.D + d);
+            }
+            vq = rb<ROUND>(vq);
+        }
+        float x = rb<ROUND>(ld_elem(emb, (size_t)t0 * p.D + d) + vq);
+        if (p.scale && is_vq) x = rb<ROUND>(x / p.inv_div);
+        p.x[(size_t)m * p.ldx + d] = x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Slow-layer decode attention (S = 1): q/k nn.RMSNorm (llama.py:207-209,246-248), interleaved
+// RoPE with the bf16 table (llama.py:594-618), KV-cache append (llama.py:142-149), GQA softmax
+// attention over [0, pos] (the reference masks all max_seq_len slots, llama.py:258-274,437 —
+// identical result).  grid = (Hkv, nsplit, M): one block per kv head and KV split; groups of
+// hd/8 lanes own one cached position each (16-byte K/V pieces), online softmax per group,
+// merged through LDS.  nsplit > 1 writes (O, m, l) partials for attn_combine_kernel.
+// ------------------------------------------------------------------------------------------
+struct AttnP {
+    const float* qkv;
+    int ldq;
+    const void* qn;
+    const void* kn;
+    const float* rope;  // [n_pos][hd/2][2]
+    void* kc;
+    void* vc;
+    size_t cache_m_stride;  // elements per batch row
+    const int* pos;
+    int pos_off;
+    int H, Hkv, hd, n_slots, nsplit;
+    float eps, scale;
+    float* y;
+    int ldy;
+    float* part_o;   // [M][H][nsplit][hd]
+    float* part_ml;  // [M][H][nsplit][2]
+};
+
+template <typename WT, int G, bool ROUND>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int kvh = blockIdx.x, split = blockIdx.y, m = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hd = p.hd, hp = hd >> 1;
+    const int pos = p.pos[m] + p.pos_off;
+    const int LPP = hd >> 3;       // lanes per cached position
+    const int PPW = 64 / LPP;      // positions per wave step
+    const int NSLOT = 4 * PPW;
+    float* q_s = smem;                   // [G][hd]
+    float* k_new = q_s + G * hd;         // [hd]
+    float* v_new = k_new + hd;           // [hd]
+    float* ml_s = v_new + hd;            // [NSLOT][G][2]
+    float* acc_s = ml_s + NSLOT * G * 2; // [NSLOT][G][hd]
+    const float* qkv = p.qkv + (size_t)m * p.ldq;
+    const WT* qn = reinterpret_cast<const WT*>(p.qn);
+    const WT* kn = reinterpret_cast<const WT*>(p.kn);
+
+    // phase 1: q heads of this group, new k, new v
+    for (int item = wave; item < G + 2; item += 4) {
+        const float* src;
+        const WT* gain = nullptr;
+        float* dst;
+        if (item < G) { src = qkv + (size_t)(kvh * G + item) * hd; gain = qn; dst = q_s + item * hd; }
+        else if (item == G) { src = qkv + (size_t)(p.H + kvh) * hd; gain = kn; dst = k_new; }
+        else { src = qkv + (size_t)(p.H + p.Hkv + kvh) * hd; dst = v_new; }
+        if (item == G + 1) {
+            for (int e = lane; e < hd; e += 64) dst[e] = src[e];
+        } else {
+            float x0 = 0.f, x1 = 0.f;
+            if (lane < hp) { x0 = src[2 * lane]; x1 = src[2 * lane + 1]; }
+            if (gain) {
+                const float ss = wave_sum(x0 * x0 + x1 * x1);
+                const float inv = rsqrt_exact(ss / (float)hd + p.eps);
+                if (lane < hp) {
+                    x0 = rb<ROUND>((x0 * inv) * ld_elem(gain, 2 * lane));
+                    x1 = rb<ROUND>((x1 * inv) * ld_elem(gain, 2 * lane + 1));
+                }
+            }
+            if (lane < hp) {
+                const float c = p.rope[((size_t)pos * hp + lane) * 2];
+                const float s = p.rope[((size_t)pos * hp + lane) * 2 + 1];
+                dst[2 * lane] = rb<ROUND>(x0 * c - x1 * s);
+                dst[2 * lane + 1] = rb<ROUND>(x1 * c + x0 * s);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int chunk = (pos + p.nsplit) / p.nsplit;  // ceil((pos+1)/nsplit)
+    const int lo = split * chunk;
+    const int hi = min(lo + chunk, pos + 1);
+    WT* kc = reinterpret_cast<WT*>(p.kc) + (size_t)m * p.cache_m_stride + (size_t)kvh * p.n_slots * hd;
+    WT* vc = reinterpret_cast<WT*>(p.vc) + (size_t)m * p.cache_m_stride + (size_t)kvh * p.n_slots * hd;
+    if (pos >= lo && pos < hi) {
+        for (int e = tid; e < hd; e += 256) {
+            st_elem(kc, (size_t)pos * hd + e, k_new[e]);
+            st_elem(vc, (size_t)pos * hd + e, v_new[e]);
+        }
+    }
+
+    // phase 2: this block's share of the cached positions
+    const int grp = lane / LPP, gl = lane % LPP;
+    const int slot = wave * PPW + grp;
+    float qr[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qr[g][e] = q_s[g * hd + gl * 8 + e];
+    float mrun[G], lrun[G], acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        mrun[g] = -INFINITY; lrun[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+    }
+    for (int base = lo + wave * PPW; base < hi; base += NSLOT) {
+        const int j = base + grp;
+        const bool valid = j < hi;
+        float kv[8], vv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kv[e] = 0.f; vv[e] = 0.f; }
+        if (valid) {
+            if (j == pos) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { kv[e] = k_new[gl * 8 + e]; vv[e] = v_new[gl * 8 + e]; }
+            } else {
+                if constexpr (sizeof(WT) == 2) {
+                    Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(kc) + (size_t)j * hd + gl * 8, kv);
+                    Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(vc) + (size_t)j * hd + gl * 8, vv);
+                } else {
+                    const float* kf = reinterpret_cast<const float*>(kc) + (size_t)j * hd + gl * 8;
+                    const float* vf = reinterpret_cast<const float*>(vc) + (size_t)j * hd + gl * 8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { kv[e] = kf[e]; vv[e] = vf[e]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d = fmaf(qr[g][e], kv[e], d);
+            for (int o = LPP >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            if (valid) {
+                const float s = d * p.scale;
+                const float mn = fmaxf(mrun[g], s);
+                const float corr = expf(mrun[g] - mn);
+                const float pj = expf(s - mn);
+                lrun[g] = lrun[g] * corr + pj;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[g][e] = acc[g][e] * corr + pj * vv[e];
+                mrun[g] = mn;
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (gl == 0) { ml_s[(slot * G + g) * 2] = mrun[g]; ml_s[(slot * G + g) * 2 + 1] = lrun[g]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc_s[(size_t)(slot * G + g) * hd + gl * 8 + e] = acc[g][e];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * hd; idx += 256) {
+        const int g = idx / hd, e = idx % hd;
+        float M = -INFINITY;
+        for (int s = 0; s < NSLOT; ++s) M = fmaxf(M, ml_s[(s * G + g) * 2]);
+        float L = 0.f, O = 0.f;
+        if (M > -INFINITY) {
+            for (int s = 0; s < NSLOT; ++s) {
+                const float w = expf(ml_s[(s * G + g) * 2] - M);
+                L += ml_s[(s * G + g) * 2 + 1] * w;
+                O += acc_s[(size_t)(s * G + g) * hd + e] * w;
+            }
+        }
+        const int head = kvh * G + g;
+        if (p.nsplit == 1) {
+            p.y[(size_t)m * p.ldy + head * hd + e] = rb<ROUND>(O / L);
+        } else {
+            const size_t pi = ((size_t)m * p.H + head) * p.nsplit + split;
+            p.part_o[pi * hd + e] = O;
+            if (e == 0) { p.part_ml[pi * 2] = M; p.part_ml[pi * 2 + 1] = L; }
+        }
+    }
+}
+
+template <bool ROUND>
+__global__ __launch_bounds__(128) void attn_combine_kernel(AttnP p) {
+    const int head = blockIdx.x, m = blockIdx.y;
+    const size_t base = ((size_t)m * p.H + head) * p.nsplit;
+    float M = -INFINITY;
+    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, p.part_ml[(base + s) * 2]);
+    for (int e = threadIdx.x; e < p.hd; e += 128) {
+        float L = 0.f, O = 0.f;
+        for (int s = 0; s < p.nsplit; ++s) {
+            const float ms = p.part_ml[(base + s) * 2];
+            if (ms > -INFINITY) {
+                const float w = expf(ms - M);
+                L += p.part_ml[(base + s) * 2 + 1] * w;
+                O += p.part_o[(base + s) * p.hd + e] * w;
+            }
+        }
+        p.y[(size_t)m * p.ldy + head * p.hd + e] = rb<ROUND>(O / L);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fast-layer attention fused into the Wo GEMV (+ residual).  The fast transformer attends
+// over <= num_codebooks positions (llama.py:544-580); its attention is the explicit
+// matmul/softmax path of llama.py:285-309 whose three intermediate roundings are mirrored
+// here.  Every block rebuilds the (tiny) attention output in LDS, then streams its Wo rows.
+// ------------------------------------------------------------------------------------------
+struct FastAttnP {
+    const float* qkv;
+    int ldq;
+    const void* qn;
+    const void* kn;
+    const float* rope;  // [ncb][hd/2][2]
+    void* kc;
+    void* vc;           // [M][Hkv][ncb][hd]
+    size_t cache_m_stride;
+    int c;              // codebook position of this step (0..ncb-1)
+    int H, Hkv, hd, ncb;
+    float eps, scale;
+};
+
+constexpr int FAST_MAXCB = 16;
+
+template <typename WT, bool ROUND>
+__device__ __forceinline__ void fast_attention_to_lds(const FastAttnP& a, const int m, float* smem,
+                                                      float* y_s) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hd = a.hd, hp = hd >> 1, H = a.H, Hkv = a.Hkv, G = H / Hkv, c = a.c;
+    float* q_s = smem;              // [H][hd]
+    float* k_new = q_s + H * hd;    // [Hkv][hd]
+    float* v_new = k_new + Hkv * hd;
+    const float* qkv = a.qkv + (size_t)m * a.ldq;
+    const WT* qn = reinterpret_cast<const WT*>(a.qn);
+    const WT* kn = reinterpret_cast<const WT*>(a.kn);
+    for (int item = wave; item < H + Hkv; item += 4) {
+        const float* src = qkv + (size_t)item * hd;
+        const WT* gain = item < H ? qn : kn;
+        float* dst = item < H ? q_s + item * hd : k_new + (item - H) * hd;
+        float x0 = 0.f, x1 = 0.f;
+        if (lane < hp) { x0 = src[2 * lane]; x1 = src[2 * lane + 1]; }
+        if (gain) {
+            const float ss = wave_sum(x0 * x0 + x1 * x1);
+            const float inv = rsqrt_exact(ss / (float)hd + a.eps);
+            if (lane < hp) {
+                x0 = rb<ROUND>((x0 * inv) * ld_elem(gain, 2 * lane));
+                x1 = rb<ROUND>((x1 * inv) * ld_elem(gain, 2 * lane + 1));
+            }
+        }
+        if (lane < hp) {
+            const float cs = a.rope[((size_t)c * hp + lane) * 2];
+            const float sn = a.rope[((size_t)c * hp + lane) * 2 + 1];
+            dst[2 * lane] = rb<ROUND>(x0 * cs - x1 * sn);
+            dst[2 * lane + 1] = rb<ROUND>(x1 * cs + x0 * sn);
+        }
+    }
+    for (int e = tid; e < Hkv * hd; e += 256) v_new[e] = qkv[(size_t)(H + Hkv) * hd + e];
+    __syncthreads();
+    WT* kc = reinterpret_cast<WT*>(a.kc) + (size_t)m * a.cache_m_stride;
+    WT* vc = reinterpret_cast<WT*>(a.vc) + (size_t)m * a.cache_m_stride;
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < Hkv * hd; e += 256) {
+            const int kvh = e / hd, d = e % hd;
+            st_elem(kc, ((size_t)kvh * a.ncb + c) * hd + d, k_new[e]);
+            st_elem(vc, ((size_t)kvh * a.ncb + c) * hd + d, v_new[e]);
+        }
+    }
+    // 16 lanes per head, EPT = hd/16 dims per lane
+    const int EPT = hd >> 4;
+    const int sub = tid & 15;
+    for (int h0 = 0; h0 < H; h0 += 16) {
+        const int h = h0 + (tid >> 4);
+        const bool hv = h < H;
+        const int kvh = hv ? h / G : 0;
+        // cached positions j < c come from HBM, the current position c from LDS; the two sources are
+        // kept in separate statements (a merged LDS/global pointer select miscompiles on ROCm 7.2)
+        float s[FAST_MAXCB];
+        float dcur = 0.f;
+        if (hv) {
+            for (int e = 0; e < EPT; ++e) {
+                const int dd = sub * EPT + e;
+                dcur = fmaf(q_s[h * hd + dd], k_new[kvh * hd + dd], dcur);
+            }
+        }
+        dcur += __shfl_xor(dcur, 8, 64); dcur += __shfl_xor(dcur, 4, 64);
+        dcur += __shfl_xor(dcur, 2, 64); dcur += __shfl_xor(dcur, 1, 64);
+#pragma unroll
+        for (int j = 0; j < FAST_MAXCB; ++j) {
+            float d = 0.f;
+            if (hv && j < c) {
+                for (int e = 0; e < EPT; ++e) {
+                    const int dd = sub * EPT + e;
+                    d = fmaf(q_s[h * hd + dd], ld_elem(kc, ((size_t)kvh * a.ncb + j) * hd + dd), d);
+                }
+            }
+            d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64);
+            d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
+            d = (j == c) ? dcur : d;
+            s[j] = (j <= c) ? rb<ROUND>(rb<ROUND>(d) * a.scale) : -INFINITY;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < FAST_MAXCB; ++j) mx = fmaxf(mx, s[j]);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < FAST_MAXCB; ++j) { s[j] = (j <= c) ? expf(s[j] - mx) : 0.f; sum += s[j]; }
+#pragma unroll
+        for (int j = 0; j < FAST_MAXCB; ++j) s[j] = rb<ROUND>(s[j] / sum);
+        if (hv) {
+            float pc = 0.f;  // weight of the current position
+#pragma unroll
+            for (int j = 0; j < FAST_MAXCB; ++j) pc = (j == c) ? s[j] : pc;
+            for (int e = 0; e < EPT; ++e) {
+                const int dd = sub * EPT + e;
+                float o = 0.f;
+#pragma unroll
+                for (int j = 0; j < FAST_MAXCB; ++j)
+                    if (j < c) o = fmaf(s[j], ld_elem(vc, ((size_t)kvh * a.ncb + j) * hd + dd), o);
+                o = fmaf(pc, v_new[kvh * hd + dd], o);
+                y_s[h * hd + dd] = rb<ROUND>(o);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <typename WT, int NT, int R, bool ROUND>
+__global__ __launch_bounds__(256) void fast_attn_wo_kernel(GemvP p, FastAttnP a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int m = blockIdx.y;
+    float* y_s = smem;                       // [H*hd] (16-byte aligned: first in LDS)
+    float* scratch = smem + a.H * a.hd;      // q, k_new, v_new
+    fast_attention_to_lds<WT, ROUND>(a, m, scratch, y_s);
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= p.N) return;
+    constexpr int VEC = Vec<WT>::N;
+    gemv_rows<WT, NT, R, ROUND>(p, m, row0, lane, [&](int k, float(&v)[VEC]) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = y_s[k + j];
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// Sampling head (inference.py:24-80) for one row of logits, one 1024-thread block per row.
+// Mirrors: repetition penalty on the window ids (gather all, then scatter), top-p on the
+// descending order with the *inclusive* cumulative sum (rank 0 always kept), temperature,
+// softmax, argmax(p / q) with q ~ Exp(1).  In the bf16 precision the intermediate roundings
+// of the reference (softmax output, cumulative sum, top_p itself, logits/T, p/q) are applied.
+// No sort: the cut is located by a bitwise search on the order-preserving integer image of
+// the logits (mass of {key >= k} is monotone in k); ties inside the cut class are resolved
+// by index (the reference's sort is unstable, so the survivor of an exact tie is unspecified).
+// ------------------------------------------------------------------------------------------
+struct RowCtl {
+    float temperature, top_p, rep;
+    int ban_eos;
+    unsigned long long seed;
+};
+
+struct SampP {
+    float* logits;
+    int ldl, V;
+    const RowCtl* ctl;
+    int* tokn;        // [M][ncb+1] frame under construction
+    int* seq;         // [M][ncb+1][cap]
+    int cap;
+    int* nf;          // [M] frames generated so far
+    int cb;           // 0: semantic token from the slow head; >= 1: fast codebook cb
+    int ncb, sem_begin, im_end, cbsize;
+    const void* fast_emb;
+    float* femb;
+    int Df;
+    const float* noise;
+    long noise_row_len, noise_off;
+    long noise_rows;
+    int last;         // finalize the frame after this draw
+    int* tok;         // [M][ncb+1] input column of the next slow step
+    int* pos;
+    int* done;
+};
+
+__device__ __forceinline__ uint32_t order_key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ uint32_t philox_word(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+struct ArgMax { float v; int i; };
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+// block-wide deterministic reductions over 1024 threads (16 waves)
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    return t;
+}
+__device__ __forceinline__ ArgMax block_argmax(ArgMax a, float* redv, int* redi) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax b;
+        b.v = __shfl_xor(a.v, o, 64);
+        b.i = __shfl_xor(a.i, o, 64);
+        a = better(a, b);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { redv[wave] = a.v; redi[wave] = a.i; }
+    __syncthreads();
+    ArgMax t{redv[0], redi[0]};
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = better(t, ArgMax{redv[w], redi[w]});
+    return t;
+}
+
+template <typename WT, bool ROUND>
+__global__ __launch_bounds__(1024) void sample_kernel(SampP p) {
+    __shared__ float red[16];
+    __shared__ int redi[16];
+    __shared__ float pen_val[32];
+    __shared__ int pen_id[32];
+    const int m = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
+    float* L = p.logits + (size_t)m * p.ldl;
+    const int V = p.V;
+    const RowCtl ctl = p.ctl[m];
+    const int nfv = p.nf[m];
+    const int R = p.ncb + 1;
+    int* seq = p.seq + (size_t)m * R * p.cap;
+
+    // -- repetition penalty (inference.py:39-45, window rule 187-191, id choice 109-111/141-145)
+    if (nfv > 0) {
+        const int i = nfv - 1;
+        const int ws = i < 16 ? 0 : i - 16;
+        const int npen = p.cb == 0 ? R : 16;
+        if (tid < npen) {
+            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1]
+                                     : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
+            pen_id[tid] = id;
+            if (id >= 0 && id < V) {
+                const float s = L[id];
+                pen_val[tid] = s < 0.f ? rb<ROUND>(s * ctl.rep) : rb<ROUND>(s / ctl.rep);
+            }
+        }
+        __syncthreads();
+        if (tid < npen) {
+            const int id = pen_id[tid];
+            if (id >= 0 && id < V) L[id] = pen_val[tid];
+        }
+    }
+    if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end < V) L[p.im_end] = -INFINITY;
+    __syncthreads();
+
+    // -- max / argmax and the softmax normaliser of the sorted logits (inference.py:48-51)
+    ArgMax am{-INFINITY, 0x7fffffff};
+    for (int i = tid; i < V; i += T) am = better(am, ArgMax{L[i], i});
+    am = block_argmax(am, red, redi);
+    const float Lmax = am.v;
+    float z = 0.f;
+    for (int i = tid; i < V; i += T) z += expf(L[i] - Lmax);
+    const float Z = block_sum(z, red);
+
+    const float tp = rb<ROUND>(ctl.top_p);
+    auto removed = [&](float cum) { return rb<ROUND>(cum) > tp; };
+    auto prob = [&](float l) { return rb<ROUND>(expf(l - Lmax) / Z); };
+
+    // kstar: largest key k with removed(mass{key >= k}); none (0) => everything kept
+    uint32_t kstar = 0;
+    long istar = -1;  // elements of class kstar with index <= istar are kept
+    bool all_kept = false, only_top = false;
+    if (removed(prob(Lmax))) {
+        only_top = true;  // rank 0 is always kept, every later rank is cut
+    } else {
+        float tot = 0.f;
+        for (int i = tid; i < V; i += T) tot += prob(L[i]);
+        tot = block_sum(tot, red);
+        if (!removed(tot)) {
+            all_kept = true;
+        } else {
+            const int lowbit = ROUND ? 16 : 0;
+            for (int bit = 31; bit >= lowbit; --bit) {
+                const uint32_t cand = kstar | (1u << bit);
+                float ms = 0.f;
+                for (int i = tid; i < V; i += T) {
+                    const float l = L[i];
+                    if (order_key(l) >= cand) ms += prob(l);
+                }
+                ms = block_sum(ms, red);
+                if (removed(ms)) kstar = cand;
+            }
+            // class kstar: member count, mass strictly above; a member's mass follows from its
+            // (unique) logit value, recovered by inverting the order-preserving key
+            const uint32_t cmask = ROUND ? 0xffff0000u : 0xffffffffu;
+            float above = 0.f, cnt = 0.f;
+            for (int i = tid; i < V; i += T) {
+                const float l = L[i];
+                const uint32_t k = order_key(l) & cmask;
+                if (k > kstar) above += prob(l);
+                else if (k == kstar) cnt += 1.f;
+            }
+            above = block_sum(above, red);
+            const int icnt = (int)block_sum(cnt, red);
+            const uint32_t ubits = (kstar & 0x80000000u) ? (kstar & 0x7fffffffu) : ~(kstar | ~cmask);
+            const float pk = prob(__uint_as_float(ubits));
+            // members kept = largest n with the inclusive cumulative mass still <= top_p
+            int nk = 0;
+            {
+                int lo_n = 0, hi_n = icnt;
+                while (lo_n < hi_n) {
+                    const int mid = (lo_n + hi_n + 1) >> 1;
+                    if (removed(fmaf((float)mid, pk, above))) hi_n = mid - 1; else lo_n = mid;
+                }
+                nk = lo_n;
+            }
+            if (nk >= icnt) istar = V;
+            else if (nk == 0) istar = -1;
+            else {
+                // smallest index bound with exactly nk class members at or below it
+                long lo_i = 0, hi_i = V - 1;
+                while (lo_i < hi_i) {
+                    const long mid = (lo_i + hi_i) >> 1;
+                    float cc = 0.f;
+                    for (int i = tid; i < V; i += T)
+                        if (i <= mid && (order_key(L[i]) & cmask) == kstar) cc += 1.f;
+                    cc = block_sum(cc, red);
+                    if ((int)cc >= nk) hi_i = mid; else lo_i = mid + 1;
+                }
+                istar = lo_i;
+            }
+        }
+    }
+
+    // -- temperature, softmax over the kept set, exponential race (inference.py:57-61, 24-27)
+    int winner = am.i;
+    if (!only_top) {
+        const uint32_t cmask = ROUND ? 0xffff0000u : 0xffffffffu;
+        const float Tc = fmaxf(ctl.temperature, 1e-5f);
+        auto kept = [&](int i, float l) {
+            if (all_kept) return true;
+            const uint32_t k = order_key(l) & cmask;
+            return k > kstar || (k == kstar && (long)i <= istar);
+        };
+        const float Mt = rb<ROUND>(Lmax / Tc);
+        float z2 = 0.f;
+        for (int i = tid; i < V; i += T) {
+            const float l = L[i];
+            if (kept(i, l)) z2 += expf(rb<ROUND>(l / Tc) - Mt);
+        }
+        const float Z2 = block_sum(z2, red);
+        const float* qrow = nullptr;
+        if (p.noise && nfv < p.noise_rows) qrow = p.noise + (size_t)nfv * p.noise_row_len + p.noise_off;
+        ArgMax best{-1.f, 0x7fffffff};
+        for (int i = tid; i < V; i += T) {
+            const float l = L[i];
+            float pr = 0.f;
+            if (kept(i, l)) pr = rb<ROUND>(expf(rb<ROUND>(l / Tc) - Mt) / Z2);
+            float q;
+            if (qrow) q = qrow[i];
+            else {
+                const uint32_t w = philox_word((uint32_t)i, (uint32_t)p.cb, (uint32_t)nfv, (uint32_t)m,
+                                               (uint32_t)ctl.seed, (uint32_t)(ctl.seed >> 32));
+                const float u = ((float)(w >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+                q = -logf(u);
+                q = fmaxf(q, 1e-30f);
+            }
+            q = rb<ROUND>(q);
+            best = better(best, ArgMax{rb<ROUND>(pr / q), i});
+        }
+        best = block_argmax(best, red, redi);
+        winner = best.i;
+    }
+
+    // -- frame bookkeeping (inference.py:123-126, 148-155, 206-210)
+    int* tokn = p.tokn + (size_t)m * R;
+    int code = winner;
+    if (p.cb == 0) {
+        if (tid == 0) tokn[0] = winner;
+        code = winner - p.sem_begin;
+        code = code < 0 ? 0 : code;
+        code = code >= p.cbsize ? p.cbsize - 1 : code;  // reference would raise IndexError here
+        if (tid == 0) tokn[1] = code;
+    } else if (tid == 0) {
+        tokn[p.cb + 1] = code;
+    }
+    const WT* fe = reinterpret_cast<const WT*>(p.fast_emb);
+    for (int d = tid; d < p.Df; d += T) p.femb[(size_t)m * p.Df + d] = ld_elem(fe, (size_t)code * p.Df + d);
+    if (p.last) {
+        __syncthreads();
+        if (tid < R) {
+            const int v = tokn[tid];
+            p.tok[(size_t)m * R + tid] = v;
+            if (nfv < p.cap) seq[(size_t)tid * p.cap + nfv] = v;
+        }
+        if (tid == 0) {
+            p.pos[m] += 1;
+            p.nf[m] = nfv + 1;
+            if (tokn[0] == p.im_end) p.done[m] = 1;
+        }
+    }
+}
+
+}  // namespace ft

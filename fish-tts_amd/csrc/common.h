@@ -1,0 +1,90 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ft {
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+struct alignas(16) U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+
+// round-to-nearest-even f32 -> bf16 precision, result kept in an f32 register (NaN stays NaN)
+__device__ __forceinline__ float round_bf16(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return x;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return __uint_as_float(u & 0xffff0000u);
+}
+__device__ __forceinline__ bf16_t f32_to_bf16_bits(float x) {
+    uint32_t u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+template <bool ROUND> __device__ __forceinline__ float rb(float x) { return ROUND ? round_bf16(x) : x; }
+
+// element load/store for the two storage types the engine supports (bf16 bits, f32)
+__device__ __forceinline__ float ld_elem(const bf16_t* p, size_t i) { return bf16_bits_to_f32(p[i]); }
+__device__ __forceinline__ float ld_elem(const float* p, size_t i) { return p[i]; }
+__device__ __forceinline__ void st_elem(bf16_t* p, size_t i, float v) { p[i] = f32_to_bf16_bits(v); }
+__device__ __forceinline__ void st_elem(float* p, size_t i, float v) { p[i] = v; }
+
+// 16-byte vector of weights -> VEC f32 values (VEC = 8 for bf16, 4 for f32)
+template <typename T> struct Vec;
+template <> struct Vec<bf16_t> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        const U4 r = *reinterpret_cast<const U4*>(p);
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+        v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+        v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+    }
+    __device__ static __forceinline__ void unpack(const U4& r, float (&v)[8]) {
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+        v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+        v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+    }
+    __device__ static __forceinline__ void zero(float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+};
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
+        const float4 r = *reinterpret_cast<const float4*>(p);
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    }
+    __device__ static __forceinline__ void unpack(const U4& r, float (&v)[4]) {
+        v[0] = __uint_as_float(r.x); v[1] = __uint_as_float(r.y);
+        v[2] = __uint_as_float(r.z); v[3] = __uint_as_float(r.w);
+    }
+    __device__ static __forceinline__ void zero(float (&v)[4]) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+};
+
+// butterfly reductions: every lane ends with the full result, same order on every run
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+template <int W> __device__ __forceinline__ float group_sum(float v) {  // W lanes, W power of two <= 64
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// exact-ish f32 helpers (no fast-math): IEEE sqrt/div as torch's CPU kernels use
+__device__ __forceinline__ float rsqrt_exact(float v) { return 1.0f / sqrtf(v); }
+
+}  // namespace ft

@@ -1,0 +1,88 @@
+// Host-side state of libfishtts_hip.so (one ctx per GPU).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fishtts_hip.h"
+#include "ar_kernels.h"
+
+struct FtTensor {
+    void* p = nullptr;
+    std::vector<int64_t> shape;
+    int dtype = FT_BF16;  // storage type in HBM (FT_F32 | FT_BF16)
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+struct FtLayer {
+    void *attn_norm = nullptr, *wqkv = nullptr, *bqkv = nullptr, *qn = nullptr, *kn = nullptr, *wo = nullptr,
+         *bo = nullptr, *ffn_norm = nullptr, *w13 = nullptr, *w2 = nullptr;
+    void *kc = nullptr, *vc = nullptr;
+};
+
+struct CodecState;  // codec.hip
+
+struct ft_ctx {
+    ft_ar_config c{};
+    bool has_ar = false;
+    ft_codec_config cc{};
+    bool has_codec = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool finalized = false;
+
+    std::map<std::string, FtTensor> expected;  // name -> expected shape (p filled once loaded)
+    size_t esz = 2;
+
+    // resolved AR weights
+    void *emb = nullptr, *cb_emb = nullptr, *norm = nullptr, *head = nullptr, *fproj_w = nullptr,
+         *fproj_b = nullptr, *fast_emb = nullptr, *fast_norm = nullptr, *fast_out = nullptr;
+    float *rope = nullptr, *frope = nullptr;
+    std::vector<FtLayer> layers, flayers;
+
+    // activations [max_batch][...]
+    float *x = nullptr, *qkv = nullptr, *y = nullptr, *g = nullptr, *logits = nullptr, *hid = nullptr,
+          *femb = nullptr, *xf = nullptr, *qkvf = nullptr, *gf = nullptr, *flog = nullptr, *part_o = nullptr,
+          *part_ml = nullptr;
+    int n_slots = 0, nsplit = 1, cap = 0, fastV = 0;
+    size_t cache_m_stride = 0, fcache_m_stride = 0;
+
+    // per-slot state
+    int *d_pos = nullptr, *d_tok = nullptr, *d_tokn = nullptr, *d_seq = nullptr, *d_nf = nullptr,
+        *d_done = nullptr, *d_prompt = nullptr;
+    ft::RowCtl* d_ctl = nullptr;
+    int *h_pin = nullptr;  // pinned scratch (2*max_batch + 4 ints)
+    float* noise = nullptr;
+    long noise_rows = 0, noise_row_len = 0;
+
+    std::map<int, hipGraphExec_t> graphs;
+
+    // measurement hook
+    bool prof = false;
+    std::vector<hipEvent_t> prof_ev;
+    int64_t prof_bytes = 0, prof_launches = 0;
+
+    CodecState* codec = nullptr;
+};
+
+ft_status ft_fail(ft_ctx* ctx, ft_status code, const std::string& msg);
+#define FT_HIP(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return ft_fail(ctx, FT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+// codec.hip
+ft_status codec_create(ft_ctx* ctx);
+void codec_destroy(ft_ctx* ctx);
+void codec_expected(ft_ctx* ctx);
+void ft_expect(ft_ctx* ctx, const std::string& name, std::vector<int64_t> shape, int dtype);
+ft_status codec_finalize(ft_ctx* ctx);

@@ -1,0 +1,820 @@
+// libfishtts_hip.so: context, weight ingestion, the AR prefill/decode drivers (hipGraph-captured
+// frame step) and the C ABI declared in include/fishtts_hip.h.
+#include "engine.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+using namespace ft;
+
+static std::string g_create_err;
+
+ft_status ft_fail(ft_ctx* ctx, ft_status code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_create_err = msg;
+    return code;
+}
+
+// ------------------------------------------------------------------------------------------ utils
+template <typename S, typename D>
+__global__ void convert_kernel(const S* s, D* d, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        st_elem(d, (size_t)i, ld_elem(s, (size_t)i));
+}
+template <typename T>
+__global__ void interleave_rows_kernel(const T* a, const T* b, T* o, int64_t rows, int64_t K) {
+    const int64_t n = rows * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / K, k = i % K;
+        o[(2 * r) * K + k] = a[i];
+        o[(2 * r + 1) * K + k] = b[i];
+    }
+}
+
+template <typename T>
+static ft_status dmalloc(ft_ctx* ctx, T** p, size_t n) {
+    void* q = nullptr;
+    const size_t bytes = n * sizeof(T) ? n * sizeof(T) : 16;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return ft_fail(ctx, FT_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    hipMemset(q, 0, bytes);
+    *p = (T*)q;
+    return FT_OK;
+}
+#define FT_TRY(x) do { ft_status s_ = (x); if (s_ != FT_OK) return s_; } while (0)
+
+// ------------------------------------------------------------------------------------------ names
+void ft_expect(ft_ctx* ctx, const std::string& name, std::vector<int64_t> shape, int dtype) {
+    FtTensor t;
+    t.shape = std::move(shape);
+    t.dtype = dtype;
+    ctx->expected[name] = t;
+}
+
+static void ar_expected(ft_ctx* ctx) {
+    const ft_ar_config& c = ctx->c;
+    const int dt = c.dtype;
+    ft_expect(ctx, "embeddings.weight", {c.vocab_size, c.dim}, dt);
+    ft_expect(ctx, "codebook_embeddings.weight", {(int64_t)c.codebook_size * c.num_codebooks, c.dim}, dt);
+    auto block = [&](const std::string& p, int dim, int nh, int nkv, int hd, int ffn, int qkvb, int ob, int qkn) {
+        const int64_t tot = (int64_t)(nh + 2 * nkv) * hd;
+        ft_expect(ctx, p + ".attention.wqkv.weight", {tot, dim}, dt);
+        if (qkvb) ft_expect(ctx, p + ".attention.wqkv.bias", {tot}, dt);
+        ft_expect(ctx, p + ".attention.wo.weight", {dim, (int64_t)nh * hd}, dt);
+        if (ob) ft_expect(ctx, p + ".attention.wo.bias", {dim}, dt);
+        if (qkn) {
+            ft_expect(ctx, p + ".attention.q_norm.weight", {hd}, dt);
+            ft_expect(ctx, p + ".attention.k_norm.weight", {hd}, dt);
+        }
+        ft_expect(ctx, p + ".feed_forward.w1.weight", {ffn, dim}, dt);
+        ft_expect(ctx, p + ".feed_forward.w3.weight", {ffn, dim}, dt);
+        ft_expect(ctx, p + ".feed_forward.w2.weight", {dim, ffn}, dt);
+        ft_expect(ctx, p + ".ffn_norm.weight", {dim}, dt);
+        ft_expect(ctx, p + ".attention_norm.weight", {dim}, dt);
+    };
+    for (int i = 0; i < c.n_layer; ++i)
+        block("layers." + std::to_string(i), c.dim, c.n_head, c.n_local_heads, c.head_dim, c.intermediate_size,
+              c.attention_qkv_bias, c.attention_o_bias, c.attention_qk_norm);
+    ft_expect(ctx, "norm.weight", {c.dim}, dt);
+    if (!c.tie_word_embeddings) ft_expect(ctx, "output.weight", {c.vocab_size, c.dim}, dt);
+    if (c.fast_dim != c.dim) {
+        ft_expect(ctx, "fast_project_in.weight", {c.fast_dim, c.dim}, dt);
+        ft_expect(ctx, "fast_project_in.bias", {c.fast_dim}, dt);
+    }
+    ft_expect(ctx, "fast_embeddings.weight", {c.codebook_size, c.fast_dim}, dt);
+    for (int i = 0; i < c.n_fast_layer; ++i)
+        block("fast_layers." + std::to_string(i), c.fast_dim, c.fast_n_head, c.fast_n_local_heads, c.fast_head_dim,
+              c.fast_intermediate_size, c.fast_attention_qkv_bias, c.fast_attention_o_bias,
+              c.fast_attention_qk_norm);
+    ft_expect(ctx, "fast_norm.weight", {c.fast_dim}, dt);
+    ft_expect(ctx, "fast_output.weight", {c.codebook_size, c.fast_dim}, dt);
+    // RoPE tables exactly as the reference stores them (llama.py:594-603): bf16-rounded cos/sin,
+    // supplied by the host so the table is bit-identical; kept as f32 in HBM.
+    ft_expect(ctx, "rope.slow", {c.max_seq_len, c.head_dim / 2, 2}, FT_F32);
+    ft_expect(ctx, "rope.fast", {c.num_codebooks, c.fast_head_dim / 2, 2}, FT_F32);
+}
+
+// ------------------------------------------------------------------------------------------ create
+static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static ft_status ar_validate(ft_ctx* ctx) {
+    const ft_ar_config& c = ctx->c;
+    auto bad = [&](const char* m) { return ft_fail(ctx, FT_ERR_UNSUPPORTED, m); };
+    if (c.dtype != FT_BF16 && c.dtype != FT_F32) return bad("dtype must be FT_BF16 or FT_F32");
+    if (c.dim % 8 || c.fast_dim % 8 || c.intermediate_size % 8 || c.fast_intermediate_size % 8)
+        return bad("dim / intermediate sizes must be multiples of 8");
+    if (!pow2(c.head_dim) || c.head_dim < 8 || c.head_dim > 128) return bad("head_dim must be a power of two in [8,128]");
+    if (!pow2(c.fast_head_dim) || c.fast_head_dim < 16 || c.fast_head_dim > 128)
+        return bad("fast_head_dim must be a power of two in [16,128]");
+    if (c.n_head % c.n_local_heads || c.fast_n_head % c.fast_n_local_heads) return bad("n_head % n_local_heads != 0");
+    const int G = c.n_head / c.n_local_heads;
+    if (G != 1 && G != 2 && G != 4 && G != 8) return bad("n_head / n_local_heads must be 1, 2, 4 or 8");
+    if (c.num_codebooks < 1 || c.num_codebooks > FAST_MAXCB) return bad("num_codebooks must be in [1,16]");
+    if (c.max_batch < 1 || c.max_batch > 256) return bad("max_batch must be in [1,256]");
+    if (c.max_new_tokens < 1) return bad("max_new_tokens must be >= 1");
+    if (c.vocab_size <= c.semantic_end_id || c.semantic_begin_id > c.semantic_end_id) return bad("bad semantic id range");
+    return FT_OK;
+}
+
+static ft_status ar_alloc(ft_ctx* ctx) {
+    const ft_ar_config& c = ctx->c;
+    const size_t M = c.max_batch;
+    ctx->esz = c.dtype == FT_BF16 ? 2 : 4;
+    ctx->n_slots = c.max_seq_len + ((8 - c.max_seq_len % 8) % 8);  // llama.py:387
+    const char* ns = getenv("FT_ATTN_NSPLIT");
+    ctx->nsplit = ns ? atoi(ns) : (ctx->n_slots > 512 ? 8 : 1);
+    if (ctx->nsplit < 1) ctx->nsplit = 1;
+    ctx->cap = c.max_new_tokens + 24;
+    ctx->fastV = c.codebook_size < 1024 ? c.codebook_size : 1024;  // inference.py:134
+    const size_t qkvN = (size_t)(c.n_head + 2 * c.n_local_heads) * c.head_dim;
+    const size_t fqkvN = (size_t)(c.fast_n_head + 2 * c.fast_n_local_heads) * c.fast_head_dim;
+    FT_TRY(dmalloc(ctx, &ctx->x, M * c.dim));
+    FT_TRY(dmalloc(ctx, &ctx->qkv, M * qkvN));
+    FT_TRY(dmalloc(ctx, &ctx->y, M * c.n_head * c.head_dim));
+    FT_TRY(dmalloc(ctx, &ctx->g, M * c.intermediate_size));
+    FT_TRY(dmalloc(ctx, &ctx->logits, M * c.vocab_size));
+    if (c.fast_dim != c.dim) FT_TRY(dmalloc(ctx, &ctx->hid, M * c.fast_dim));
+    else ctx->hid = ctx->x;
+    FT_TRY(dmalloc(ctx, &ctx->femb, M * c.fast_dim));
+    FT_TRY(dmalloc(ctx, &ctx->xf, M * c.fast_dim));
+    FT_TRY(dmalloc(ctx, &ctx->qkvf, M * fqkvN));
+    FT_TRY(dmalloc(ctx, &ctx->gf, M * c.fast_intermediate_size));
+    FT_TRY(dmalloc(ctx, &ctx->flog, M * ctx->fastV));
+    FT_TRY(dmalloc(ctx, &ctx->part_o, M * c.n_head * ctx->nsplit * c.head_dim));
+    FT_TRY(dmalloc(ctx, &ctx->part_ml, M * c.n_head * ctx->nsplit * 2));
+    ctx->cache_m_stride = (size_t)c.n_local_heads * ctx->n_slots * c.head_dim;
+    ctx->fcache_m_stride = (size_t)c.fast_n_local_heads * c.num_codebooks * c.fast_head_dim;
+    ctx->layers.resize(c.n_layer);
+    ctx->flayers.resize(c.n_fast_layer);
+    for (auto& l : ctx->layers) {
+        FT_TRY(dmalloc(ctx, (char**)&l.kc, M * ctx->cache_m_stride * ctx->esz));
+        FT_TRY(dmalloc(ctx, (char**)&l.vc, M * ctx->cache_m_stride * ctx->esz));
+    }
+    for (auto& l : ctx->flayers) {
+        FT_TRY(dmalloc(ctx, (char**)&l.kc, M * ctx->fcache_m_stride * ctx->esz));
+        FT_TRY(dmalloc(ctx, (char**)&l.vc, M * ctx->fcache_m_stride * ctx->esz));
+    }
+    const size_t R = c.num_codebooks + 1;
+    FT_TRY(dmalloc(ctx, &ctx->d_pos, M));
+    FT_TRY(dmalloc(ctx, &ctx->d_tok, M * R));
+    FT_TRY(dmalloc(ctx, &ctx->d_tokn, M * R));
+    FT_TRY(dmalloc(ctx, &ctx->d_seq, M * R * ctx->cap));
+    FT_TRY(dmalloc(ctx, &ctx->d_nf, M));
+    FT_TRY(dmalloc(ctx, &ctx->d_done, M));
+    FT_TRY(dmalloc(ctx, &ctx->d_prompt, R * (size_t)c.max_seq_len));
+    FT_TRY(dmalloc(ctx, &ctx->d_ctl, M));
+    FT_HIP(ctx, hipHostMalloc((void**)&ctx->h_pin, (2 * M + 8) * sizeof(int), hipHostMallocDefault));
+    return FT_OK;
+}
+
+extern "C" ft_status ft_create(const ft_ar_config* ar, const ft_codec_config* codec, int32_t device, ft_ctx** out) {
+    if (!out || (!ar && !codec)) return ft_fail(nullptr, FT_ERR_ARG, "ft_create: need a config and an out pointer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return ft_fail(nullptr, FT_ERR_HIP, "ft_create: no HIP device visible (the MI355X path has no CPU fallback)");
+    if (device < 0 || device >= ndev) return ft_fail(nullptr, FT_ERR_ARG, "ft_create: bad device index");
+    ft_ctx* ctx = new ft_ctx();
+    ctx->device = device;
+    ft_status st = FT_OK;
+    do {
+        if (hipSetDevice(device) != hipSuccess) { st = ft_fail(ctx, FT_ERR_HIP, "hipSetDevice failed"); break; }
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            st = ft_fail(ctx, FT_ERR_HIP, "hipStreamCreate failed"); break;
+        }
+        if (ar) {
+            ctx->c = *ar;
+            ctx->has_ar = true;
+            if ((st = ar_validate(ctx)) != FT_OK) break;
+            if ((st = ar_alloc(ctx)) != FT_OK) break;
+            ar_expected(ctx);
+        }
+        if (codec) {
+            ctx->cc = *codec;
+            ctx->has_codec = true;
+            if ((st = codec_create(ctx)) != FT_OK) break;
+            codec_expected(ctx);
+        }
+    } while (0);
+    if (st != FT_OK) {
+        g_create_err = ctx->err;
+        ft_destroy(ctx);
+        return st;
+    }
+    *out = ctx;
+    return FT_OK;
+}
+
+extern "C" void ft_destroy(ft_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->graphs) hipGraphExecDestroy(kv.second);
+    for (auto& kv : ctx->expected) if (kv.second.p) hipFree(kv.second.p);
+    for (auto& l : ctx->layers) { hipFree(l.kc); hipFree(l.vc); if (l.w13) hipFree(l.w13); }
+    for (auto& l : ctx->flayers) { hipFree(l.kc); hipFree(l.vc); if (l.w13) hipFree(l.w13); }
+    float* bufs[] = {ctx->x, ctx->qkv, ctx->y, ctx->g, ctx->logits, ctx->femb, ctx->xf, ctx->qkvf, ctx->gf,
+                     ctx->flog, ctx->part_o, ctx->part_ml, ctx->noise};
+    for (float* b : bufs) if (b) hipFree(b);
+    if (ctx->hid && ctx->hid != ctx->x) hipFree(ctx->hid);
+    int* ibufs[] = {ctx->d_pos, ctx->d_tok, ctx->d_tokn, ctx->d_seq, ctx->d_nf, ctx->d_done, ctx->d_prompt};
+    for (int* b : ibufs) if (b) hipFree(b);
+    if (ctx->d_ctl) hipFree(ctx->d_ctl);
+    if (ctx->h_pin) hipHostFree(ctx->h_pin);
+    for (auto e : ctx->prof_ev) hipEventDestroy(e);
+    codec_destroy(ctx);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char* ft_last_error(const ft_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" ft_status ft_sync(ft_ctx* ctx) {
+    if (!ctx) return FT_ERR_ARG;
+    FT_HIP(ctx, hipSetDevice(ctx->device));
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ weights
+extern "C" ft_status ft_load_weight(ft_ctx* ctx, const char* name, const void* src, int32_t src_dtype,
+                                    const int64_t* shape, int32_t ndim) {
+    if (!ctx || !name || !src || !shape) return ft_fail(ctx, FT_ERR_ARG, "ft_load_weight: null argument");
+    if (ctx->finalized) return ft_fail(ctx, FT_ERR_STATE, "ft_load_weight: weights already finalized");
+    auto it = ctx->expected.find(name);
+    if (it == ctx->expected.end()) return ft_fail(ctx, FT_ERR_ARG, std::string("unknown weight name: ") + name);
+    FtTensor& t = it->second;
+    if ((int)t.shape.size() != ndim) return ft_fail(ctx, FT_ERR_ARG, std::string("rank mismatch for ") + name);
+    for (int i = 0; i < ndim; ++i)
+        if (t.shape[i] != shape[i]) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "shape mismatch for %s: dim %d is %lld, expected %lld", name, i,
+                     (long long)shape[i], (long long)t.shape[i]);
+            return ft_fail(ctx, FT_ERR_ARG, buf);
+        }
+    if (src_dtype != FT_F32 && src_dtype != FT_BF16) return ft_fail(ctx, FT_ERR_ARG, "src_dtype must be FT_F32 or FT_BF16");
+    FT_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n = t.numel();
+    const size_t ssz = src_dtype == FT_F32 ? 4 : 2, dsz = t.dtype == FT_F32 ? 4 : 2;
+    if (!t.p) FT_HIP(ctx, hipMalloc(&t.p, (size_t)n * dsz + 64));
+    if (src_dtype == t.dtype) {
+        FT_HIP(ctx, hipMemcpy(t.p, src, (size_t)n * dsz, hipMemcpyDefault));
+        return FT_OK;
+    }
+    void* stage = nullptr;
+    FT_HIP(ctx, hipMalloc(&stage, (size_t)n * ssz));
+    hipError_t e = hipMemcpy(stage, src, (size_t)n * ssz, hipMemcpyDefault);
+    if (e == hipSuccess) {
+        const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        if (src_dtype == FT_F32)
+            convert_kernel<float, bf16_t><<<blocks, 256, 0, ctx->stream>>>((const float*)stage, (bf16_t*)t.p, n);
+        else
+            convert_kernel<bf16_t, float><<<blocks, 256, 0, ctx->stream>>>((const bf16_t*)stage, (float*)t.p, n);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    hipFree(stage);
+    if (e != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("ft_load_weight copy: ") + hipGetErrorString(e));
+    return FT_OK;
+}
+
+static void* wp(ft_ctx* ctx, const std::string& n) {
+    auto it = ctx->expected.find(n);
+    return it == ctx->expected.end() ? nullptr : it->second.p;
+}
+
+static ft_status ar_finalize(ft_ctx* ctx) {
+    const ft_ar_config& c = ctx->c;
+    ctx->emb = wp(ctx, "embeddings.weight");
+    ctx->cb_emb = wp(ctx, "codebook_embeddings.weight");
+    ctx->norm = wp(ctx, "norm.weight");
+    ctx->head = c.tie_word_embeddings ? ctx->emb : wp(ctx, "output.weight");
+    ctx->fproj_w = wp(ctx, "fast_project_in.weight");
+    ctx->fproj_b = wp(ctx, "fast_project_in.bias");
+    ctx->fast_emb = wp(ctx, "fast_embeddings.weight");
+    ctx->fast_norm = wp(ctx, "fast_norm.weight");
+    ctx->fast_out = wp(ctx, "fast_output.weight");
+    ctx->rope = (float*)wp(ctx, "rope.slow");
+    ctx->frope = (float*)wp(ctx, "rope.fast");
+    auto fill = [&](std::vector<FtLayer>& ls, const char* pre, int ffn, int dim) -> ft_status {
+        for (size_t i = 0; i < ls.size(); ++i) {
+            const std::string p = std::string(pre) + std::to_string(i);
+            FtLayer& l = ls[i];
+            l.attn_norm = wp(ctx, p + ".attention_norm.weight");
+            l.wqkv = wp(ctx, p + ".attention.wqkv.weight");
+            l.bqkv = wp(ctx, p + ".attention.wqkv.bias");
+            l.qn = wp(ctx, p + ".attention.q_norm.weight");
+            l.kn = wp(ctx, p + ".attention.k_norm.weight");
+            l.wo = wp(ctx, p + ".attention.wo.weight");
+            l.bo = wp(ctx, p + ".attention.wo.bias");
+            l.ffn_norm = wp(ctx, p + ".ffn_norm.weight");
+            l.w2 = wp(ctx, p + ".feed_forward.w2.weight");
+            // w1/w3 rows interleaved so one wave owns a (gate, up) pair (SwiGLU epilogue)
+            FtTensor& w1 = ctx->expected[p + ".feed_forward.w1.weight"];
+            FtTensor& w3 = ctx->expected[p + ".feed_forward.w3.weight"];
+            FT_HIP(ctx, hipMalloc(&l.w13, (size_t)2 * ffn * dim * ctx->esz));
+            const int64_t n = (int64_t)ffn * dim;
+            const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+            if (ctx->esz == 2)
+                interleave_rows_kernel<bf16_t><<<blocks, 256, 0, ctx->stream>>>((bf16_t*)w1.p, (bf16_t*)w3.p, (bf16_t*)l.w13, ffn, dim);
+            else
+                interleave_rows_kernel<float><<<blocks, 256, 0, ctx->stream>>>((float*)w1.p, (float*)w3.p, (float*)l.w13, ffn, dim);
+            FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(w1.p); w1.p = nullptr;
+            hipFree(w3.p); w3.p = nullptr;
+        }
+        return FT_OK;
+    };
+    FT_TRY(fill(ctx->layers, "layers.", c.intermediate_size, c.dim));
+    FT_TRY(fill(ctx->flayers, "fast_layers.", c.fast_intermediate_size, c.fast_dim));
+    return FT_OK;
+}
+
+extern "C" ft_status ft_finalize_weights(ft_ctx* ctx) {
+    if (!ctx) return FT_ERR_ARG;
+    if (ctx->finalized) return FT_OK;
+    FT_HIP(ctx, hipSetDevice(ctx->device));
+    for (auto& kv : ctx->expected)
+        if (!kv.second.p) return ft_fail(ctx, FT_ERR_MISSING_WEIGHT, "missing weight: " + kv.first);
+    if (ctx->has_ar) FT_TRY(ar_finalize(ctx));
+    if (ctx->has_codec) FT_TRY(codec_finalize(ctx));
+    ctx->finalized = true;
+    return FT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ launches
+struct Launch {
+    ft_ctx* ctx;
+    hipStream_t s;
+    int m0, M;       // batch rows [m0, m0+M)
+    int pos_off;     // added to the device position (token-by-token prefill)
+    hipError_t err = hipSuccess;
+    void chk() { hipError_t e = hipGetLastError(); if (e != hipSuccess && err == hipSuccess) err = e; }
+};
+
+template <typename WT, bool ROUND, int R>
+static void gemv_nt(Launch& L, const GemvP& p, int nt) {
+    const dim3 grid((p.N + 4 * R - 1) / (4 * R), L.M), block(256);
+#define FT_NT(n) case n: gemv_kernel<WT, n, R, ROUND><<<grid, block, 0, L.s>>>(p); break;
+    switch (nt) { FT_NT(1) FT_NT(2) FT_NT(3) FT_NT(4) FT_NT(6) FT_NT(8) FT_NT(12) default: L.err = hipErrorInvalidValue; }
+#undef FT_NT
+}
+
+static int pick_nt(int K, int vec) {
+    const int need = (K + 64 * vec - 1) / (64 * vec);
+    const int opts[] = {1, 2, 3, 4, 6, 8, 12};
+    for (int o : opts) if (o >= need) return o;
+    return -1;
+}
+
+template <typename WT, bool ROUND>
+static void gemv(Launch& L, GemvP p, int R) {
+    const int nt = pick_nt(p.K, Vec<WT>::N);
+    if (nt < 0) { L.err = hipErrorInvalidValue; return; }
+    ft_ctx* ctx = L.ctx;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->prof) {
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, L.s);
+    }
+    if (p.epi == EPI_SWIGLU && R < 2) R = 2;
+    if (R == 1) gemv_nt<WT, ROUND, 1>(L, p, nt);
+    else if (R == 2) gemv_nt<WT, ROUND, 2>(L, p, nt);
+    else gemv_nt<WT, ROUND, 4>(L, p, nt);
+    if (ctx->prof) {
+        hipEventRecord(e1, L.s);
+        ctx->prof_ev.push_back(e0); ctx->prof_ev.push_back(e1);
+        ctx->prof_bytes += (int64_t)p.N * p.K * sizeof(WT);
+        ctx->prof_launches += 1;
+    }
+    L.chk();
+}
+
+static int rows_per_wave(int N, int M) {
+    // enough waves to cover the chip (256 CUs x 4 SIMDs) a few times over; big matrices amortise
+    const long waves1 = (long)N * M;
+    if (waves1 >= 65536) return 4;
+    if (waves1 >= 4096) return 2;
+    return 1;
+}
+
+template <typename WT, bool ROUND, int R>
+static void fast_attn_wo_nt(Launch& L, const GemvP& p, const FastAttnP& a, int nt, size_t lds) {
+    const dim3 grid((p.N + 4 * R - 1) / (4 * R), L.M), block(256);
+#define FT_NT(n) case n: fast_attn_wo_kernel<WT, n, R, ROUND><<<grid, block, lds, L.s>>>(p, a); break;
+    switch (nt) { FT_NT(1) FT_NT(2) FT_NT(3) FT_NT(4) FT_NT(6) FT_NT(8) FT_NT(12) default: L.err = hipErrorInvalidValue; }
+#undef FT_NT
+}
+
+template <typename WT, bool ROUND>
+static void attn_decode(Launch& L, const AttnP& p) {
+    ft_ctx* ctx = L.ctx;
+    const int G = p.H / p.Hkv;
+    const int nslot = 2048 / p.hd;
+    const size_t lds = ((size_t)G * p.hd + 2 * p.hd + (size_t)nslot * G * 2 + (size_t)nslot * G * p.hd) * sizeof(float);
+    const dim3 grid(p.Hkv, p.nsplit, L.M), block(256);
+    switch (G) {
+        case 1: attn_decode_kernel<WT, 1, ROUND><<<grid, block, lds, L.s>>>(p); break;
+        case 2: attn_decode_kernel<WT, 2, ROUND><<<grid, block, lds, L.s>>>(p); break;
+        case 4: attn_decode_kernel<WT, 4, ROUND><<<grid, block, lds, L.s>>>(p); break;
+        case 8: {
+            static bool attr_done = false;
+            if (!attr_done) {
+                hipFuncSetAttribute((const void*)attn_decode_kernel<WT, 8, ROUND>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_done = true;
+            }
+            attn_decode_kernel<WT, 8, ROUND><<<grid, block, lds, L.s>>>(p);
+            break;
+        }
+        default: L.err = hipErrorInvalidValue;
+    }
+    L.chk();
+    if (p.nsplit > 1) {
+        attn_combine_kernel<ROUND><<<dim3(p.H, L.M), 128, 0, L.s>>>(p);
+        L.chk();
+    }
+    (void)ctx;
+}
+
+// One slow-transformer pass over the current input column of rows [m0, m0+M) (llama.py:400-453).
+template <typename WT, bool ROUND>
+static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long tok_m_stride, int col, bool with_head) {
+    ft_ctx* ctx = L.ctx;
+    const ft_ar_config& c = ctx->c;
+    const int m0 = L.m0;
+    const size_t qkvN = (size_t)(c.n_head + 2 * c.n_local_heads) * c.head_dim;
+    float* x = ctx->x + (size_t)m0 * c.dim;
+    float* qkv = ctx->qkv + (size_t)m0 * qkvN;
+    float* y = ctx->y + (size_t)m0 * c.n_head * c.head_dim;
+    float* g = ctx->g + (size_t)m0 * c.intermediate_size;
+
+    EmbedP e{};
+    e.emb = ctx->emb; e.cb_emb = ctx->cb_emb; e.toks = toks; e.tok_row_stride = tok_row_stride;
+    e.tok_m_stride = tok_m_stride; e.col = col; e.x = x; e.ldx = c.dim; e.D = c.dim; e.ncb = c.num_codebooks;
+    e.cbsize = c.codebook_size; e.vocab = c.vocab_size; e.sem_begin = c.semantic_begin_id;
+    e.sem_end = c.semantic_end_id; e.scale = c.scale_codebook_embeddings;
+    e.inv_div = (float)sqrt((double)(c.num_codebooks + 1));
+    embed_kernel<WT, ROUND><<<dim3((c.dim + 255) / 256, L.M), 256, 0, L.s>>>(e);
+    L.chk();
+
+    for (int li = 0; li < c.n_layer; ++li) {
+        const FtLayer& l = ctx->layers[li];
+        GemvP p{};
+        p.W = l.wqkv; p.bias = l.bqkv; p.x = x; p.ldx = c.dim; p.gain = l.attn_norm; p.eps = c.norm_eps;
+        p.out = qkv; p.ldo = (int)qkvN; p.N = (int)qkvN; p.K = c.dim; p.pro = PRO_RMSNORM; p.epi = EPI_STORE;
+        gemv<WT, ROUND>(L, p, rows_per_wave(p.N, L.M));
+
+        AttnP a{};
+        a.qkv = qkv; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->rope;
+        a.kc = (char*)l.kc + (size_t)m0 * ctx->cache_m_stride * ctx->esz;
+        a.vc = (char*)l.vc + (size_t)m0 * ctx->cache_m_stride * ctx->esz;
+        a.cache_m_stride = ctx->cache_m_stride; a.pos = ctx->d_pos + m0; a.pos_off = L.pos_off;
+        a.H = c.n_head; a.Hkv = c.n_local_heads; a.hd = c.head_dim; a.n_slots = ctx->n_slots;
+        a.nsplit = ctx->nsplit; a.eps = c.norm_eps; a.scale = 1.0f / sqrtf((float)c.head_dim);
+        a.y = y; a.ldy = c.n_head * c.head_dim;
+        a.part_o = ctx->part_o + (size_t)m0 * c.n_head * ctx->nsplit * c.head_dim;
+        a.part_ml = ctx->part_ml + (size_t)m0 * c.n_head * ctx->nsplit * 2;
+        attn_decode<WT, ROUND>(L, a);
+
+        GemvP o{};
+        o.W = l.wo; o.bias = l.bo; o.x = y; o.ldx = c.n_head * c.head_dim; o.out = x; o.ldo = c.dim;
+        o.resid = x; o.ldr = c.dim; o.N = c.dim; o.K = c.n_head * c.head_dim; o.pro = PRO_NONE; o.epi = EPI_RESID;
+        gemv<WT, ROUND>(L, o, rows_per_wave(o.N, L.M));
+
+        GemvP f{};
+        f.W = l.w13; f.x = x; f.ldx = c.dim; f.gain = l.ffn_norm; f.eps = c.norm_eps; f.out = g;
+        f.ldo = c.intermediate_size; f.N = 2 * c.intermediate_size; f.K = c.dim; f.pro = PRO_RMSNORM; f.epi = EPI_SWIGLU;
+        gemv<WT, ROUND>(L, f, rows_per_wave(f.N, L.M));
+
+        GemvP d{};
+        d.W = l.w2; d.x = g; d.ldx = c.intermediate_size; d.out = x; d.ldo = c.dim; d.resid = x; d.ldr = c.dim;
+        d.N = c.dim; d.K = c.intermediate_size; d.pro = PRO_NONE; d.epi = EPI_RESID;
+        gemv<WT, ROUND>(L, d, rows_per_wave(d.N, L.M));
+    }
+    if (!with_head) return;
+    GemvP h{};
+    h.W = ctx->head; h.x = x; h.ldx = c.dim; h.gain = ctx->norm; h.eps = c.norm_eps;
+    h.out = ctx->logits + (size_t)m0 * c.vocab_size; h.ldo = c.vocab_size; h.N = c.vocab_size; h.K = c.dim;
+    h.pro = PRO_RMSNORM; h.epi = EPI_STORE;
+    gemv<WT, ROUND>(L, h, rows_per_wave(h.N, L.M));
+    if (c.fast_dim != c.dim) {  // fast_project_in on the pre-norm hidden state (llama.py:453,590)
+        GemvP q{};
+        q.W = ctx->fproj_w; q.bias = ctx->fproj_b; q.x = x; q.ldx = c.dim;
+        q.out = ctx->hid + (size_t)m0 * c.fast_dim; q.ldo = c.fast_dim; q.N = c.fast_dim; q.K = c.dim;
+        q.pro = PRO_NONE; q.epi = EPI_STORE;
+        gemv<WT, ROUND>(L, q, rows_per_wave(q.N, L.M));
+    }
+}
+
+template <typename WT, bool ROUND>
+static void enqueue_sample(Launch& L, int cb, bool last) {
+    ft_ctx* ctx = L.ctx;
+    const ft_ar_config& c = ctx->c;
+    const int m0 = L.m0, R = c.num_codebooks + 1;
+    SampP s{};
+    if (cb == 0) { s.logits = ctx->logits + (size_t)m0 * c.vocab_size; s.ldl = c.vocab_size; s.V = c.vocab_size; }
+    else { s.logits = ctx->flog + (size_t)m0 * ctx->fastV; s.ldl = ctx->fastV; s.V = ctx->fastV; }
+    s.ctl = ctx->d_ctl + m0; s.tokn = ctx->d_tokn + (size_t)m0 * R; s.seq = ctx->d_seq + (size_t)m0 * R * ctx->cap;
+    s.cap = ctx->cap; s.nf = ctx->d_nf + m0; s.cb = cb; s.ncb = c.num_codebooks; s.sem_begin = c.semantic_begin_id;
+    s.im_end = c.im_end_id; s.cbsize = c.codebook_size; s.fast_emb = ctx->fast_emb;
+    s.femb = ctx->femb + (size_t)m0 * c.fast_dim; s.Df = c.fast_dim; s.noise = ctx->noise;
+    s.noise_row_len = ctx->noise_row_len; s.noise_rows = ctx->noise_rows;
+    s.noise_off = cb == 0 ? 0 : (long)c.vocab_size + (long)(cb - 1) * ctx->fastV;
+    s.last = last ? 1 : 0; s.tok = ctx->d_tok + (size_t)m0 * R; s.pos = ctx->d_pos + m0; s.done = ctx->d_done + m0;
+    sample_kernel<WT, ROUND><<<L.M, 1024, 0, L.s>>>(s);
+    L.chk();
+}
+
+// The fast transformer over codebook positions 0..ncb-1 with its sampling (inference.py:115-149).
+template <typename WT, bool ROUND>
+static void enqueue_fast(Launch& L) {
+    ft_ctx* ctx = L.ctx;
+    const ft_ar_config& c = ctx->c;
+    const int m0 = L.m0;
+    const int Df = c.fast_dim, Hf = c.fast_n_head, Hkvf = c.fast_n_local_heads, hdf = c.fast_head_dim;
+    const size_t qkvN = (size_t)(Hf + 2 * Hkvf) * hdf;
+    float* xf = ctx->xf + (size_t)m0 * Df;
+    float* qkvf = ctx->qkvf + (size_t)m0 * qkvN;
+    float* gf = ctx->gf + (size_t)m0 * c.fast_intermediate_size;
+    const size_t lds = (size_t)(2 * Hf + 2 * Hkvf) * hdf * sizeof(float);
+    for (int cb = 0; cb < c.num_codebooks; ++cb) {
+        const float* xin = cb == 0 ? ctx->hid + (size_t)m0 * Df : ctx->femb + (size_t)m0 * Df;
+        for (int li = 0; li < c.n_fast_layer; ++li) {
+            const FtLayer& l = ctx->flayers[li];
+            const float* xl = li == 0 ? xin : xf;
+            GemvP p{};
+            p.W = l.wqkv; p.bias = l.bqkv; p.x = xl; p.ldx = Df; p.gain = l.attn_norm; p.eps = c.norm_eps;
+            p.out = qkvf; p.ldo = (int)qkvN; p.N = (int)qkvN; p.K = Df; p.pro = PRO_RMSNORM; p.epi = EPI_STORE;
+            gemv<WT, ROUND>(L, p, rows_per_wave(p.N, L.M));
+
+            GemvP o{};
+            o.W = l.wo; o.bias = l.bo; o.out = xf; o.ldo = Df; o.resid = xl; o.ldr = Df; o.N = Df; o.K = Hf * hdf;
+            o.pro = PRO_NONE; o.epi = EPI_RESID;
+            FastAttnP a{};
+            a.qkv = qkvf; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->frope;
+            a.kc = (char*)l.kc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
+            a.vc = (char*)l.vc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
+            a.cache_m_stride = ctx->fcache_m_stride; a.c = cb; a.H = Hf; a.Hkv = Hkvf; a.hd = hdf;
+            a.ncb = c.num_codebooks; a.eps = c.norm_eps; a.scale = (float)(1.0 / sqrt((double)hdf));
+            {
+                const int nt = pick_nt(o.K, Vec<WT>::N);
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (ctx->prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, L.s); }
+                if (rows_per_wave(o.N, L.M) >= 2) fast_attn_wo_nt<WT, ROUND, 2>(L, o, a, nt, lds);
+                else fast_attn_wo_nt<WT, ROUND, 1>(L, o, a, nt, lds);
+                if (ctx->prof) {
+                    hipEventRecord(e1, L.s);
+                    ctx->prof_ev.push_back(e0); ctx->prof_ev.push_back(e1);
+                    ctx->prof_bytes += (int64_t)o.N * o.K * sizeof(WT);
+                    ctx->prof_launches += 1;
+                }
+                L.chk();
+            }
+
+            GemvP f{};
+            f.W = l.w13; f.x = xf; f.ldx = Df; f.gain = l.ffn_norm; f.eps = c.norm_eps; f.out = gf;
+            f.ldo = c.fast_intermediate_size; f.N = 2 * c.fast_intermediate_size; f.K = Df; f.pro = PRO_RMSNORM;
+            f.epi = EPI_SWIGLU;
+            gemv<WT, ROUND>(L, f, rows_per_wave(f.N, L.M));
+
+            GemvP d{};
+            d.W = l.w2; d.x = gf; d.ldx = c.fast_intermediate_size; d.out = xf; d.ldo = Df; d.resid = xf; d.ldr = Df;
+            d.N = Df; d.K = c.fast_intermediate_size; d.pro = PRO_NONE; d.epi = EPI_RESID;
+            gemv<WT, ROUND>(L, d, rows_per_wave(d.N, L.M));
+        }
+        if (cb == 0) continue;  // logits of position 0 are discarded (inference.py:122)
+        GemvP h{};
+        h.W = ctx->fast_out; h.x = xf; h.ldx = Df; h.gain = ctx->fast_norm; h.eps = c.norm_eps;
+        h.out = ctx->flog + (size_t)m0 * ctx->fastV; h.ldo = ctx->fastV; h.N = ctx->fastV; h.K = Df;
+        h.pro = PRO_RMSNORM; h.epi = EPI_STORE;
+        gemv<WT, ROUND>(L, h, rows_per_wave(h.N, L.M));
+        enqueue_sample<WT, ROUND>(L, cb, cb == c.num_codebooks - 1);
+    }
+}
+
+// One full frame: slow pass on the current column, semantic sample, fast codebooks (inference.py:83-155).
+template <typename WT, bool ROUND>
+static void enqueue_frame_t(Launch& L, const int* toks, long trs, long tms, int col) {
+    enqueue_slow<WT, ROUND>(L, toks, trs, tms, col, true);
+    enqueue_sample<WT, ROUND>(L, 0, L.ctx->c.num_codebooks == 1);
+    if (L.ctx->c.num_codebooks > 1 || true) enqueue_fast<WT, ROUND>(L);
+}
+
+static void enqueue_frame(Launch& L, const int* toks, long trs, long tms, int col) {
+    if (L.ctx->c.dtype == FT_BF16) enqueue_frame_t<bf16_t, true>(L, toks, trs, tms, col);
+    else enqueue_frame_t<float, false>(L, toks, trs, tms, col);
+}
+static void enqueue_slow_only(Launch& L, const int* toks, long trs, long tms, int col) {
+    if (L.ctx->c.dtype == FT_BF16) enqueue_slow<bf16_t, true>(L, toks, trs, tms, col, false);
+    else enqueue_slow<float, false>(L, toks, trs, tms, col, false);
+}
+
+// ------------------------------------------------------------------------------------------ AR API
+static ft_status ar_ready(ft_ctx* ctx) {
+    if (!ctx) return FT_ERR_ARG;
+    if (!ctx->has_ar) return ft_fail(ctx, FT_ERR_STATE, "context was created without an AR config");
+    if (!ctx->finalized) return ft_fail(ctx, FT_ERR_STATE, "weights not finalized (ft_finalize_weights)");
+    if (hipSetDevice(ctx->device) != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, "hipSetDevice failed");
+    return FT_OK;
+}
+
+extern "C" ft_status ft_ar_reset(ft_ctx* ctx, int32_t slot) {
+    if (!ctx || !ctx->has_ar) return FT_ERR_ARG;
+    if (slot < 0 || slot >= ctx->c.max_batch) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_reset: bad slot");
+    FT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t R = ctx->c.num_codebooks + 1;
+    FT_HIP(ctx, hipMemsetAsync(ctx->d_seq + (size_t)slot * R * ctx->cap, 0, R * ctx->cap * sizeof(int), ctx->stream));
+    FT_HIP(ctx, hipMemsetAsync(ctx->d_pos + slot, 0, sizeof(int), ctx->stream));
+    FT_HIP(ctx, hipMemsetAsync(ctx->d_nf + slot, 0, sizeof(int), ctx->stream));
+    FT_HIP(ctx, hipMemsetAsync(ctx->d_done + slot, 0, sizeof(int), ctx->stream));
+    return FT_OK;
+}
+
+static ft_status upload_ctl(ft_ctx* ctx, int m0, int n, const ft_sampling* sp) {
+    std::vector<RowCtl> h(n);
+    for (int i = 0; i < n; ++i) {
+        h[i].temperature = sp[i].temperature; h[i].top_p = sp[i].top_p; h[i].rep = sp[i].repetition_penalty;
+        h[i].ban_eos = sp[i].ban_eos; h[i].seed = sp[i].seed;
+    }
+    FT_HIP(ctx, hipMemcpyAsync(ctx->d_ctl + m0, h.data(), n * sizeof(RowCtl), hipMemcpyHostToDevice, ctx->stream));
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h goes out of scope
+    return FT_OK;
+}
+
+extern "C" ft_status ft_ar_prefill(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_t Lp,
+                                   const ft_sampling* sp, int32_t* out_frame) {
+    FT_TRY(ar_ready(ctx));
+    const ft_ar_config& c = ctx->c;
+    if (!prompt || !sp || !out_frame) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill: null argument");
+    if (slot < 0 || slot >= c.max_batch) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill: bad slot");
+    if (Lp < 1) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill: empty prompt");
+    if (Lp >= c.max_seq_len) {  // inference.py:296-299
+        char buf[128];
+        snprintf(buf, sizeof buf, "Input sequence length %d exceeds max_seq_len %d", Lp, c.max_seq_len);
+        return ft_fail(ctx, FT_ERR_TOO_LONG, buf);
+    }
+    const int R = c.num_codebooks + 1;
+    FT_TRY(ft_ar_reset(ctx, slot));
+    FT_TRY(upload_ctl(ctx, slot, 1, sp));
+    FT_HIP(ctx, hipMemcpyAsync(ctx->d_prompt, prompt, (size_t)R * Lp * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    Launch L{ctx, ctx->stream, slot, 1, 0};
+    // v0 prefill: the prompt is fed through the S=1 decode kernels position by position (same causal
+    // arithmetic as the reference's S=Lp pass); only the last position runs the head and the fast stack.
+    for (int t = 0; t < Lp - 1; ++t) {
+        L.pos_off = t;
+        enqueue_slow_only(L, ctx->d_prompt, Lp, 0, t);
+    }
+    L.pos_off = Lp - 1;
+    enqueue_frame(L, ctx->d_prompt, Lp, 0, Lp - 1);
+    if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("prefill launch: ") + hipGetErrorString(L.err));
+    // finalize() advanced pos 0 -> 1; the next input position is Lp
+    ctx->h_pin[0] = Lp;
+    FT_HIP(ctx, hipMemcpyAsync(ctx->d_pos + slot, ctx->h_pin, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    FT_HIP(ctx, hipMemcpyAsync(out_frame, ctx->d_tok + (size_t)slot * R, R * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FT_OK;
+}
+
+static ft_status get_graph(ft_ctx* ctx, int M, hipGraphExec_t* out) {
+    auto it = ctx->graphs.find(M);
+    if (it != ctx->graphs.end()) { *out = it->second; return FT_OK; }
+    const int R = ctx->c.num_codebooks + 1;
+    hipGraph_t graph = nullptr;
+    FT_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    Launch L{ctx, ctx->stream, 0, M, 0};
+    enqueue_frame(L, ctx->d_tok, 1, R, 0);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    if (L.err != hipSuccess) e = L.err;
+    if (e != hipSuccess) {
+        if (graph) hipGraphDestroy(graph);
+        return ft_fail(ctx, FT_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(e));
+    }
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("graph instantiate: ") + hipGetErrorString(e));
+    ctx->graphs[M] = exec;
+    *out = exec;
+    return FT_OK;
+}
+
+extern "C" ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames, const ft_sampling* sp,
+                                  int32_t poll, int32_t* out_frames, int32_t* out_n) {
+    FT_TRY(ar_ready(ctx));
+    const ft_ar_config& c = ctx->c;
+    if (!sp || !out_frames || !out_n) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_decode: null argument");
+    if (nslots < 1 || nslots > c.max_batch) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_decode: bad nslots");
+    if (n_frames < 0) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_decode: n_frames < 0");
+    if (poll < 1) poll = 1;
+    const int R = c.num_codebooks + 1;
+    FT_TRY(upload_ctl(ctx, 0, nslots, sp));
+    // state at entry
+    int* h = ctx->h_pin;
+    FT_HIP(ctx, hipMemcpyAsync(h, ctx->d_nf, nslots * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    FT_HIP(ctx, hipMemcpyAsync(h + nslots, ctx->d_pos, nslots * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int> nf0(h, h + nslots);
+    int budget = n_frames;
+    for (int m = 0; m < nslots; ++m) {
+        if (nf0[m] < 1) return ft_fail(ctx, FT_ERR_STATE, "ft_ar_decode: slot has not been prefilled");
+        budget = std::min(budget, ctx->cap - nf0[m]);
+        budget = std::min(budget, ctx->n_slots - h[nslots + m]);  // cache positions left
+    }
+    if (budget < 0) budget = 0;
+    hipGraphExec_t exec = nullptr;
+    const bool eager = getenv("FT_NO_GRAPH") != nullptr;
+    if (!eager && budget > 0) FT_TRY(get_graph(ctx, nslots, &exec));
+    int done_frames = 0;
+    while (done_frames < budget) {
+        const int burst = std::min(poll, budget - done_frames);
+        for (int i = 0; i < burst; ++i) {
+            if (eager) {
+                Launch L{ctx, ctx->stream, 0, nslots, 0};
+                enqueue_frame(L, ctx->d_tok, 1, R, 0);
+                if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("frame launch: ") + hipGetErrorString(L.err));
+            } else {
+                FT_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+            }
+        }
+        done_frames += burst;
+        FT_HIP(ctx, hipMemcpyAsync(h, ctx->d_done, nslots * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        bool all = true;
+        for (int m = 0; m < nslots; ++m) all = all && h[m];
+        if (all) break;
+    }
+    // collect: frames [nf0, nf0+done_frames) of each slot, cut after the first <|im_end|>
+    std::vector<int> seq((size_t)R * ctx->cap);
+    for (int m = 0; m < nslots; ++m) {
+        FT_HIP(ctx, hipMemcpy(seq.data(), ctx->d_seq + (size_t)m * R * ctx->cap, seq.size() * sizeof(int), hipMemcpyDeviceToHost));
+        int n = 0;
+        for (int f = 0; f < done_frames; ++f) {
+            const int col = nf0[m] + f;
+            for (int r = 0; r < R; ++r) out_frames[((size_t)m * n_frames + f) * R + r] = seq[(size_t)r * ctx->cap + col];
+            n = f + 1;
+            if (seq[col] == c.im_end_id) break;
+        }
+        // a slot that had already emitted <|im_end|> before this call produces nothing new
+        if (nf0[m] >= 1 && seq[nf0[m] - 1] == c.im_end_id) n = 0;
+        out_n[m] = n;
+    }
+    return FT_OK;
+}
+
+extern "C" ft_status ft_ar_set_noise(ft_ctx* ctx, const float* q, int64_t n_rows, int64_t row_len) {
+    if (!ctx || !ctx->has_ar) return FT_ERR_ARG;
+    FT_HIP(ctx, hipSetDevice(ctx->device));
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& kv : ctx->graphs) hipGraphExecDestroy(kv.second);  // captured launches hold the old pointer
+    ctx->graphs.clear();
+    if (ctx->noise) { hipFree(ctx->noise); ctx->noise = nullptr; }
+    ctx->noise_rows = ctx->noise_row_len = 0;
+    if (!q) return FT_OK;
+    const int64_t need = (int64_t)ctx->c.vocab_size + (int64_t)(ctx->c.num_codebooks - 1) * ctx->fastV;
+    if (row_len < need) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_set_noise: row_len too small");
+    FT_HIP(ctx, hipMalloc((void**)&ctx->noise, (size_t)n_rows * row_len * sizeof(float)));
+    FT_HIP(ctx, hipMemcpy(ctx->noise, q, (size_t)n_rows * row_len * sizeof(float), hipMemcpyDefault));
+    ctx->noise_rows = n_rows;
+    ctx->noise_row_len = row_len;
+    return FT_OK;
+}
+
+extern "C" ft_status ft_ar_get_debug(ft_ctx* ctx, int32_t slot, float* logits, float* hidden) {
+    FT_TRY(ar_ready(ctx));
+    if (slot < 0 || slot >= ctx->c.max_batch) return ft_fail(ctx, FT_ERR_ARG, "bad slot");
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (logits)
+        FT_HIP(ctx, hipMemcpy(logits, ctx->logits + (size_t)slot * ctx->c.vocab_size, ctx->c.vocab_size * sizeof(float), hipMemcpyDeviceToHost));
+    if (hidden)
+        FT_HIP(ctx, hipMemcpy(hidden, ctx->hid + (size_t)slot * ctx->c.fast_dim, ctx->c.fast_dim * sizeof(float), hipMemcpyDeviceToHost));
+    return FT_OK;
+}
+
+extern "C" ft_status ft_ar_profile_gemv(ft_ctx* ctx, int32_t frames, const ft_sampling* sp, double* ms,
+                                        int64_t* launches, int64_t* bytes) {
+    FT_TRY(ar_ready(ctx));
+    if (!sp || !ms || !launches || !bytes) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_profile_gemv: null argument");
+    const int R = ctx->c.num_codebooks + 1;
+    FT_TRY(upload_ctl(ctx, 0, 1, sp));
+    for (auto e : ctx->prof_ev) hipEventDestroy(e);
+    ctx->prof_ev.clear();
+    ctx->prof_bytes = ctx->prof_launches = 0;
+    ctx->prof = true;
+    for (int f = 0; f < frames; ++f) {
+        Launch L{ctx, ctx->stream, 0, 1, 0};
+        enqueue_frame(L, ctx->d_tok, 1, R, 0);
+        if (L.err != hipSuccess) { ctx->prof = false; return ft_fail(ctx, FT_ERR_HIP, "profile launch failed"); }
+    }
+    ctx->prof = false;
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < ctx->prof_ev.size(); i += 2) {
+        float t = 0.f;
+        hipEventElapsedTime(&t, ctx->prof_ev[i], ctx->prof_ev[i + 1]);
+        tot += t;
+    }
+    *ms = tot; *launches = ctx->prof_launches; *bytes = ctx->prof_bytes;
+    for (auto e : ctx->prof_ev) hipEventDestroy(e);
+    ctx->prof_ev.clear();
+    return FT_OK;
+}

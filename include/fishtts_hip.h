@@ -1,0 +1,123 @@
+/* libfishtts_hip.so — C ABI of the MI355X (gfx950) hot path: dual-AR semantic-token decode +
+ * DAC codec decode.  Plain pointers and sizes only; no torch types.
+ *
+ * The reference (smolGura/fish-tts) is pure Python and has no FFI; the seams this library
+ * sits behind are the Python-level operators named in SURVEY.md §8(b).  Each entry point
+ * cites the reference interface it replaces (paths relative to /root/reference).
+ *
+ * Threading: AR calls on one ctx are serialized by the caller (as the reference's
+ * synthesize() is not re-entrant: synthesizer.py:431-481 shares one KV cache);
+ * ft_codec_decode is re-entrant with respect to AR calls and runs on its own HIP stream
+ * (mirrors the decoder thread of synthesizer.py:513-528).  One ctx per GPU.
+ *
+ * Ownership: the caller owns every buffer it passes; the library copies weights into its
+ * own HBM allocations and never frees caller memory.  Errors: integer status + a message
+ * from ft_last_error(); the Python host maps them to the reference's ValueError/RuntimeError.
+ */
+#ifndef FISHTTS_HIP_H
+#define FISHTTS_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ft_ctx ft_ctx;
+typedef int32_t ft_status;
+
+enum { FT_OK = 0, FT_ERR_ARG = 1, FT_ERR_HIP = 2, FT_ERR_STATE = 3, FT_ERR_UNSUPPORTED = 4,
+       FT_ERR_NOMEM = 5, FT_ERR_TOO_LONG = 6, FT_ERR_MISSING_WEIGHT = 7 };
+enum { FT_F32 = 0, FT_BF16 = 1 };
+
+/* Field names and meaning = config.json / DualARModelArgs (fish_tts/models/llama.py:31-123);
+ * the three token ids come from the tokenizer layout (fish_tts/models/tokenizer.py:83-101). */
+typedef struct ft_ar_config {
+    int32_t dtype;  /* FT_BF16 | FT_F32: model precision (fish_tts/synthesizer.py:122-128) */
+    int32_t vocab_size, n_layer, n_head, dim, intermediate_size, n_local_heads, head_dim;
+    float rope_base, norm_eps;
+    int32_t max_seq_len, tie_word_embeddings, attention_qkv_bias, attention_o_bias, attention_qk_norm;
+    int32_t codebook_size, num_codebooks, scale_codebook_embeddings;
+    int32_t n_fast_layer, fast_dim, fast_n_head, fast_n_local_heads, fast_head_dim,
+        fast_intermediate_size, fast_attention_qkv_bias, fast_attention_qk_norm, fast_attention_o_bias;
+    int32_t semantic_begin_id, semantic_end_id, im_end_id;
+    int32_t max_batch;      /* utterance slots decoded in lock step (reference: 1, inference.py:313-317) */
+    int32_t max_new_tokens; /* per-slot capacity for generated frames */
+} ft_ar_config;
+
+/* Hyper-parameters of the DAC decode path; the reference hard-codes them in
+ * fish_tts/synthesizer.py:199-269 (and fish_tts/models/vocoder.py:824-872). */
+typedef struct ft_codec_config {
+    int32_t dtype;                 /* FT_BF16 | FT_F32 arithmetic of the conv/linear contractions */
+    int32_t n_codebooks;           /* residual codebooks (9); +1 semantic */
+    int32_t codebook_size, semantic_codebook_size, codebook_dim, latent_dim; /* 1024, 4096, 8, 1024 */
+    int32_t n_tf_layer, tf_n_head, tf_head_dim, tf_ffn, tf_window;           /* 8, 16, 64, 3072, 128 */
+    float tf_rope_base, tf_norm_eps;                                          /* 1e4, 1e-5 */
+    int32_t n_upsample;            /* 2 (x2 each) */
+    int32_t decoder_dim;           /* 1536 */
+    int32_t n_rates;               /* 4 */
+    int32_t rates[8];              /* 8,8,4,2 */
+    int32_t max_frames;            /* longest code sequence per call */
+    int32_t max_batch;
+} ft_codec_config;
+
+/* Sampling scalars of synthesize()/generate_long() (synthesizer.py:431-439, inference.py:741-765). */
+typedef struct ft_sampling {
+    float temperature, top_p, repetition_penalty;
+    int32_t ban_eos;   /* 1: mask <|im_end|> before sampling (fixed-length synthetic benches only) */
+    uint64_t seed;     /* counter-based RNG stream for the Exp(1) race (inference.py:24-27) */
+} ft_sampling;
+
+/* Lifecycle.  Replaces init_model() + setup_caches() (inference.py:387-414, llama.py:378-398,544-559)
+ * and _load_vocoder() (synthesizer.py:188-293).  Either config may be NULL. */
+ft_status ft_create(const ft_ar_config* ar, const ft_codec_config* codec, int32_t device, ft_ctx** out);
+void ft_destroy(ft_ctx* ctx);
+const char* ft_last_error(const ft_ctx* ctx); /* ctx may be NULL: last create-time error */
+
+/* Weight ingestion under the reference's state-dict names (llama.py:349-359,510-535 after the
+ * wq/wk/wv->wqkv fuse of llama.py:222-227; codec names as vocoder.py modules after weight-norm
+ * folding).  `src` may be a host or a device pointer; `src_dtype` FT_F32|FT_BF16; the tensor is
+ * converted to the ctx precision and repacked.  Replaces load_state_dict (llama.py:498). */
+ft_status ft_load_weight(ft_ctx* ctx, const char* name, const void* src, int32_t src_dtype,
+                         const int64_t* shape, int32_t ndim);
+ft_status ft_finalize_weights(ft_ctx* ctx); /* checks completeness, builds fused layouts + tables */
+
+/* AR path.  A "slot" is one utterance's state (KV cache, position, penalty window, RNG). */
+ft_status ft_ar_reset(ft_ctx* ctx, int32_t slot);
+/* Prefill = the un-compiled first decode_one_token_ar call of generate()/generate_streaming()
+ * (inference.py:353-362, 709-718): prompt is (num_codebooks+1) x Lp int32 row-major, host memory
+ * (ContentSequence.encode_for_inference output, inference.py:611-640).  Writes the first
+ * generated frame (num_codebooks+1 int32) to out_frame (host).  No repetition penalty. */
+ft_status ft_ar_prefill(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_t Lp,
+                        const ft_sampling* sp, int32_t* out_frame);
+/* Decode loop = decode_n_tokens[_streaming] (inference.py:158-276) driving decode_one_token_ar
+ * (inference.py:83-155), for slots [0, nslots) in lock step, up to n_frames more frames each.
+ * out_frames: nslots x n_frames x (num_codebooks+1) int32 (host), frame-major; out_n[slot] =
+ * frames produced (the <|im_end|> frame included, as the streaming loop yields it).
+ * The step is hipGraph-captured; EOS is polled every `poll` frames (>=1). */
+ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames, const ft_sampling* sp,
+                       int32_t poll, int32_t* out_frames, int32_t* out_n);
+/* Test hooks: inject the Exp(1) noise the sampler divides by (inference.py:26), one row of
+ * `row_len` floats per generated frame (slow vocab draws first, then (num_codebooks-1) x 1024);
+ * q == NULL restores the RNG.  Read back the last slow logits / pre-norm hidden of a slot. */
+ft_status ft_ar_set_noise(ft_ctx* ctx, const float* q, int64_t n_rows, int64_t row_len);
+ft_status ft_ar_get_debug(ft_ctx* ctx, int32_t slot, float* logits /*vocab*/, float* hidden /*fast_dim*/);
+
+/* Codec path = DAC.decode (vocoder.py:906-912) incl. DownsampleResidualVectorQuantize.decode
+ * (vocoder.py:800-814) and Decoder (vocoder.py:605-640).  codes: B x (n_codebooks+1) x T int32
+ * (host), right-padded; lens[b] valid frames.  audio: B x (T*frame_len) float32 (host),
+ * samples beyond lens[b]*frame_len are written but meaningless (the codec is causal). */
+ft_status ft_codec_decode(ft_ctx* ctx, const int32_t* codes, int32_t B, int32_t T, const int32_t* lens,
+                          float* audio);
+int32_t ft_codec_frame_len(const ft_ctx* ctx); /* samples per code frame (2048) */
+
+/* Measurement hooks used by bench.py (never by the product path).  Runs `frames` decode frames
+ * eagerly (not graph-replayed) on slot 0 with HIP events around every launch of the
+ * weight-streaming GEMV kernel family on the engine's own stream; returns summed device ms,
+ * launch count and the algorithmic bytes those launches stream. */
+ft_status ft_ar_profile_gemv(ft_ctx* ctx, int32_t frames, const ft_sampling* sp, double* ms,
+                             int64_t* launches, int64_t* bytes);
+ft_status ft_sync(ft_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
