@@ -166,6 +166,17 @@ class ARHipEngine:
                                              hidden.ctypes.data_as(C.c_void_p)), "ft_ar_get_debug")
         return logits, hidden
 
+    def test_sample(self, logits: np.ndarray, cb: int, sampling: L.ft_sampling, window=None, q=None) -> int:
+        logits = np.ascontiguousarray(logits, dtype=np.float32)
+        w = None if window is None else np.ascontiguousarray(window, dtype=np.int32)
+        qq = None if q is None else np.ascontiguousarray(q, dtype=np.float32)
+        out = np.zeros(1, dtype=np.int32)
+        self._check(self.lib.ft_test_sample(
+            self._h, logits.ctypes.data_as(C.c_void_p), cb, C.byref(sampling),
+            None if w is None else w.ctypes.data_as(C.c_void_p),
+            None if qq is None else qq.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), "ft_test_sample")
+        return int(out[0])
+
     def sync(self):
         self._check(self.lib.ft_sync(self._h), "ft_sync")
 

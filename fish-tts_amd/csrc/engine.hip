@@ -818,3 +818,45 @@ extern "C" ft_status ft_ar_profile_gemv(ft_ctx* ctx, int32_t frames, const ft_sa
     ctx->prof_ev.clear();
     return FT_OK;
 }
+
+extern "C" ft_status ft_test_sample(ft_ctx* ctx, const float* logits, int32_t cb, const ft_sampling* sp,
+                                    const int32_t* window, const float* q, int32_t* out_index) {
+    FT_TRY(ar_ready(ctx));
+    const ft_ar_config& c = ctx->c;
+    if (!logits || !sp || !out_index || cb < 0 || cb >= c.num_codebooks) return ft_fail(ctx, FT_ERR_ARG, "ft_test_sample: bad argument");
+    const int R = c.num_codebooks + 1;
+    const int V = cb == 0 ? c.vocab_size : ctx->fastV;
+    FT_TRY(ft_ar_reset(ctx, 0));
+    FT_TRY(upload_ctl(ctx, 0, 1, sp));
+    FT_HIP(ctx, hipMemcpy(cb == 0 ? ctx->logits : ctx->flog, logits, (size_t)V * sizeof(float), hipMemcpyHostToDevice));
+    int nfv = 0;
+    if (window) {
+        nfv = 1;  // iteration i = 0: the window is hist[:, 0:16] = seq[:, 1:17]
+        for (int r = 0; r < R; ++r)
+            FT_HIP(ctx, hipMemcpy(ctx->d_seq + (size_t)r * ctx->cap + 1, window + (size_t)r * 16, 16 * sizeof(int), hipMemcpyHostToDevice));
+        FT_HIP(ctx, hipMemcpy(ctx->d_nf, &nfv, sizeof(int), hipMemcpyHostToDevice));
+    }
+    float* saved = ctx->noise;
+    const long srows = ctx->noise_rows, slen = ctx->noise_row_len;
+    float* tmp = nullptr;
+    if (q) {
+        const long need = (long)c.vocab_size + (long)(c.num_codebooks - 1) * ctx->fastV;
+        FT_HIP(ctx, hipMalloc((void**)&tmp, (size_t)(nfv + 1) * need * sizeof(float)));
+        const long off = cb == 0 ? 0 : (long)c.vocab_size + (long)(cb - 1) * ctx->fastV;
+        FT_HIP(ctx, hipMemcpy(tmp + (size_t)nfv * need + off, q, (size_t)V * sizeof(float), hipMemcpyHostToDevice));
+        ctx->noise = tmp; ctx->noise_rows = nfv + 1; ctx->noise_row_len = need;
+    } else {
+        ctx->noise = nullptr; ctx->noise_rows = 0;
+    }
+    Launch L{ctx, ctx->stream, 0, 1, 0};
+    if (c.dtype == FT_BF16) enqueue_sample<bf16_t, true>(L, cb, false);
+    else enqueue_sample<float, false>(L, cb, false);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    ctx->noise = saved; ctx->noise_rows = srows; ctx->noise_row_len = slen;
+    if (tmp) hipFree(tmp);
+    if (L.err != hipSuccess || e != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, "ft_test_sample launch failed");
+    int tokn[2] = {0, 0};
+    FT_HIP(ctx, hipMemcpy(tokn, ctx->d_tokn + (cb == 0 ? 0 : cb + 1), sizeof(int), hipMemcpyDeviceToHost));
+    *out_index = tokn[0];
+    return ft_ar_reset(ctx, 0);
+}

@@ -116,6 +116,12 @@ int32_t ft_codec_frame_len(const ft_ctx* ctx); /* samples per code frame (2048) 
 ft_status ft_ar_profile_gemv(ft_ctx* ctx, int32_t frames, const ft_sampling* sp, double* ms,
                              int64_t* launches, int64_t* bytes);
 ft_status ft_sync(ft_ctx* ctx);
+/* Test hook: one draw of the sampling kernel (inference.py:30-80) on caller-supplied logits.
+ * cb = 0 draws from `vocab_size` logits, cb >= 1 from min(1024, codebook_size); window is the
+ * (num_codebooks+1) x 16 penalty window of inference.py:187-191 or NULL (no penalty); q the Exp(1)
+ * noise (same length as the logits) or NULL (RNG).  Clobbers slot 0. */
+ft_status ft_test_sample(ft_ctx* ctx, const float* logits, int32_t cb, const ft_sampling* sp,
+                         const int32_t* window, const float* q, int32_t* out_index);
 
 #ifdef __cplusplus
 }
