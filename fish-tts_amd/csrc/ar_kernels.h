@@ -36,29 +36,38 @@ struct GemvP {
     int ldr;
     int N, K;
     int pro, epi;
+    int nt;  // non-temporal weight loads
 };
 
-template <typename WT, int NT, int R, bool ROUND, typename XLoad>
-__device__ __forceinline__ void gemv_rows(const GemvP& p, const int m, const int row0, const int lane,
-                                          XLoad xload) {
+template <typename WT, int NT, int R>
+__device__ __forceinline__ void gemv_issue(const GemvP& p, const int row0, const int lane, U4 (&raw)[R][NT]) {
     constexpr int VEC = Vec<WT>::N;
     constexpr int TILE = 64 * VEC;
     const WT* W = reinterpret_cast<const WT*>(p.W);
-    const int K = p.K, N = p.N;
-
-    U4 raw[R][NT];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int row = row0 + r;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int k = t * TILE + lane * VEC;
-            if (row < N && k < K)
-                raw[r][t] = *reinterpret_cast<const U4*>(W + (size_t)row * K + k);
-            else
+            if (row < p.N && k < p.K) {
+                const U4* src = reinterpret_cast<const U4*>(W + (size_t)row * p.K + k);
+                // streamed-once weights (slow layers, vocab head) bypass the caches' retention;
+                // the fast stack's weights are re-read 10x per frame and stay default-policy
+                raw[r][t] = p.nt ? __builtin_nontemporal_load(src) : *src;
+            } else {
                 raw[r][t] = U4{0u, 0u, 0u, 0u};
+            }
         }
     }
+}
+
+template <typename WT, int NT, int R, bool ROUND, typename XLoad>
+__device__ __forceinline__ void gemv_finish(const GemvP& p, const int m, const int row0, const int lane,
+                                            U4 (&raw)[R][NT], XLoad xload) {
+    constexpr int VEC = Vec<WT>::N;
+    constexpr int TILE = 64 * VEC;
+    const int K = p.K, N = p.N;
 
     float xv[NT][VEC];
 #pragma unroll
@@ -129,6 +138,13 @@ __device__ __forceinline__ void gemv_rows(const GemvP& p, const int m, const int
             }
         }
     }
+}
+
+template <typename WT, int NT, int R, bool ROUND, typename XLoad>
+__device__ __forceinline__ void gemv_rows(const GemvP& p, const int m, const int row0, const int lane, XLoad xload) {
+    U4 raw[R][NT];
+    gemv_issue<WT, NT, R>(p, row0, lane, raw);
+    gemv_finish<WT, NT, R, ROUND>(p, m, row0, lane, raw, xload);
 }
 
 template <typename WT, int NT, int R, bool ROUND>
@@ -405,21 +421,50 @@ struct FastAttnP {
 
 constexpr int FAST_MAXCB = 16;
 
+// LDS carve (floats): y_s[H*hd] | q_s[H*hd] | kL[Hkv*ncb*hd] | vL[Hkv*ncb*hd]
+__host__ __device__ inline size_t fast_attn_lds_floats(int H, int Hkv, int hd, int ncb) {
+    return (size_t)2 * H * hd + (size_t)2 * Hkv * ncb * hd;
+}
+
 template <typename WT, bool ROUND>
-__device__ __forceinline__ void fast_attention_to_lds(const FastAttnP& a, const int m, float* smem,
-                                                      float* y_s) {
+__device__ __forceinline__ void fast_attention_to_lds(const FastAttnP& a, const int m, float* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hd = a.hd, hp = hd >> 1, H = a.H, Hkv = a.Hkv, G = H / Hkv, c = a.c;
-    float* q_s = smem;              // [H][hd]
-    float* k_new = q_s + H * hd;    // [Hkv][hd]
-    float* v_new = k_new + Hkv * hd;
+    const int hd = a.hd, hp = hd >> 1, H = a.H, Hkv = a.Hkv, G = H / Hkv, c = a.c, ncb = a.ncb;
+    float* y_s = smem;
+    float* q_s = y_s + H * hd;
+    float* kL = q_s + H * hd;            // [Hkv][ncb][hd]
+    float* vL = kL + Hkv * ncb * hd;
     const float* qkv = a.qkv + (size_t)m * a.ldq;
     const WT* qn = reinterpret_cast<const WT*>(a.qn);
     const WT* kn = reinterpret_cast<const WT*>(a.kn);
+    WT* kc = reinterpret_cast<WT*>(a.kc) + (size_t)m * a.cache_m_stride;
+    WT* vc = reinterpret_cast<WT*>(a.vc) + (size_t)m * a.cache_m_stride;
+    // cached positions j < c: one coalesced sweep HBM/L2 -> LDS (8 elements per thread per step)
+    {
+        const int per_head = c * hd;  // valid elements per kv head (positions 0..c-1 are contiguous)
+        const int vecs = per_head >> 3;
+        for (int i = tid; i < Hkv * vecs; i += 256) {
+            const int kvh = i / vecs, o = (i % vecs) << 3;
+            float kv[8], vv[8];
+            const size_t g = (size_t)kvh * ncb * hd + o;
+            if constexpr (sizeof(WT) == 2) {
+                Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(kc) + g, kv);
+                Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(vc) + g, vv);
+            } else {
+                const float* kf = reinterpret_cast<const float*>(kc) + g;
+                const float* vf = reinterpret_cast<const float*>(vc) + g;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { kv[e] = kf[e]; vv[e] = vf[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kL[g + e] = kv[e]; vL[g + e] = vv[e]; }
+        }
+    }
+    // new q (all heads), new k -> slot c of kL, new v -> slot c of vL
     for (int item = wave; item < H + Hkv; item += 4) {
         const float* src = qkv + (size_t)item * hd;
         const WT* gain = item < H ? qn : kn;
-        float* dst = item < H ? q_s + item * hd : k_new + (item - H) * hd;
+        float* dst = item < H ? q_s + item * hd : kL + ((size_t)(item - H) * ncb + c) * hd;
         float x0 = 0.f, x1 = 0.f;
         if (lane < hp) { x0 = src[2 * lane]; x1 = src[2 * lane + 1]; }
         if (gain) {
@@ -437,48 +482,44 @@ __device__ __forceinline__ void fast_attention_to_lds(const FastAttnP& a, const 
             dst[2 * lane + 1] = rb<ROUND>(x1 * cs + x0 * sn);
         }
     }
-    for (int e = tid; e < Hkv * hd; e += 256) v_new[e] = qkv[(size_t)(H + Hkv) * hd + e];
+    for (int e = tid; e < Hkv * hd; e += 256) {
+        const int kvh = e / hd, d = e % hd;
+        vL[((size_t)kvh * ncb + c) * hd + d] = qkv[(size_t)(H + Hkv) * hd + e];
+    }
     __syncthreads();
-    WT* kc = reinterpret_cast<WT*>(a.kc) + (size_t)m * a.cache_m_stride;
-    WT* vc = reinterpret_cast<WT*>(a.vc) + (size_t)m * a.cache_m_stride;
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0) {  // KV-cache append (llama.py:142-149) by one block
         for (int e = tid; e < Hkv * hd; e += 256) {
             const int kvh = e / hd, d = e % hd;
-            st_elem(kc, ((size_t)kvh * a.ncb + c) * hd + d, k_new[e]);
-            st_elem(vc, ((size_t)kvh * a.ncb + c) * hd + d, v_new[e]);
+            const size_t g = ((size_t)kvh * ncb + c) * hd + d;
+            st_elem(kc, g, kL[g]);
+            st_elem(vc, g, vL[g]);
         }
     }
-    // 16 lanes per head, EPT = hd/16 dims per lane
+    // 16 lanes per head, EPT = hd/16 dims per lane; everything below reads LDS only
     const int EPT = hd >> 4;
     const int sub = tid & 15;
     for (int h0 = 0; h0 < H; h0 += 16) {
         const int h = h0 + (tid >> 4);
         const bool hv = h < H;
         const int kvh = hv ? h / G : 0;
-        // cached positions j < c come from HBM, the current position c from LDS; the two sources are
-        // kept in separate statements (a merged LDS/global pointer select miscompiles on ROCm 7.2)
+        const float* kh = kL + (size_t)kvh * ncb * hd;
+        const float* vh = vL + (size_t)kvh * ncb * hd;
         float s[FAST_MAXCB];
-        float dcur = 0.f;
-        if (hv) {
-            for (int e = 0; e < EPT; ++e) {
-                const int dd = sub * EPT + e;
-                dcur = fmaf(q_s[h * hd + dd], k_new[kvh * hd + dd], dcur);
-            }
-        }
-        dcur += __shfl_xor(dcur, 8, 64); dcur += __shfl_xor(dcur, 4, 64);
-        dcur += __shfl_xor(dcur, 2, 64); dcur += __shfl_xor(dcur, 1, 64);
 #pragma unroll
         for (int j = 0; j < FAST_MAXCB; ++j) {
             float d = 0.f;
-            if (hv && j < c) {
+            if (hv && j <= c)
                 for (int e = 0; e < EPT; ++e) {
                     const int dd = sub * EPT + e;
-                    d = fmaf(q_s[h * hd + dd], ld_elem(kc, ((size_t)kvh * a.ncb + j) * hd + dd), d);
+                    d = fmaf(q_s[h * hd + dd], kh[j * hd + dd], d);
                 }
-            }
+            s[j] = d;
+        }
+#pragma unroll
+        for (int j = 0; j < FAST_MAXCB; ++j) {
+            float d = s[j];
             d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64);
             d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
-            d = (j == c) ? dcur : d;
             s[j] = (j <= c) ? rb<ROUND>(rb<ROUND>(d) * a.scale) : -INFINITY;
         }
         float mx = -INFINITY;
@@ -490,16 +531,12 @@ __device__ __forceinline__ void fast_attention_to_lds(const FastAttnP& a, const 
 #pragma unroll
         for (int j = 0; j < FAST_MAXCB; ++j) s[j] = rb<ROUND>(s[j] / sum);
         if (hv) {
-            float pc = 0.f;  // weight of the current position
-#pragma unroll
-            for (int j = 0; j < FAST_MAXCB; ++j) pc = (j == c) ? s[j] : pc;
             for (int e = 0; e < EPT; ++e) {
                 const int dd = sub * EPT + e;
                 float o = 0.f;
 #pragma unroll
                 for (int j = 0; j < FAST_MAXCB; ++j)
-                    if (j < c) o = fmaf(s[j], ld_elem(vc, ((size_t)kvh * a.ncb + j) * hd + dd), o);
-                o = fmaf(pc, v_new[kvh * hd + dd], o);
+                    if (j <= c) o = fmaf(s[j], vh[j * hd + dd], o);
                 y_s[h * hd + dd] = rb<ROUND>(o);
             }
         }
@@ -511,14 +548,15 @@ template <typename WT, int NT, int R, bool ROUND>
 __global__ __launch_bounds__(256) void fast_attn_wo_kernel(GemvP p, FastAttnP a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int m = blockIdx.y;
-    float* y_s = smem;                       // [H*hd] (16-byte aligned: first in LDS)
-    float* scratch = smem + a.H * a.hd;      // q, k_new, v_new
-    fast_attention_to_lds<WT, ROUND>(a, m, scratch, y_s);
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    U4 raw[R][NT];
+    gemv_issue<WT, NT, R>(p, row0, lane, raw);  // Wo rows are in flight while the attention is rebuilt
+    fast_attention_to_lds<WT, ROUND>(a, m, smem);
     if (row0 >= p.N) return;
     constexpr int VEC = Vec<WT>::N;
-    gemv_rows<WT, NT, R, ROUND>(p, m, row0, lane, [&](int k, float(&v)[VEC]) {
+    const float* y_s = smem;
+    gemv_finish<WT, NT, R, ROUND>(p, m, row0, lane, raw, [&](int k, float(&v)[VEC]) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) v[j] = y_s[k + j];
     });
@@ -616,8 +654,43 @@ __device__ __forceinline__ ArgMax block_argmax(ArgMax a, float* redv, int* redi)
     return t;
 }
 
+// frame bookkeeping after a draw (inference.py:123-126, 148-155, 206-210); called by all threads of
+// the (single) finishing block of row m
+template <typename WT>
+__device__ __forceinline__ void finish_draw(const SampP& p, const int m, const int winner, const int nfv) {
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int R = p.ncb + 1;
+    int* tokn = p.tokn + (size_t)m * R;
+    int* seq = p.seq + (size_t)m * R * p.cap;
+    int code = winner;
+    if (p.cb == 0) {
+        if (tid == 0) tokn[0] = winner;
+        code = winner - p.sem_begin;
+        code = code < 0 ? 0 : code;
+        code = code >= p.cbsize ? p.cbsize - 1 : code;  // reference would raise IndexError here
+        if (tid == 0) tokn[1] = code;
+    } else if (tid == 0) {
+        tokn[p.cb + 1] = code;
+    }
+    const WT* fe = reinterpret_cast<const WT*>(p.fast_emb);
+    for (int d = tid; d < p.Df; d += T) p.femb[(size_t)m * p.Df + d] = ld_elem(fe, (size_t)code * p.Df + d);
+    if (p.last) {
+        __syncthreads();
+        if (tid < R) {
+            const int v = tokn[tid];
+            p.tok[(size_t)m * R + tid] = v;
+            if (nfv < p.cap) seq[(size_t)tid * p.cap + nfv] = v;
+        }
+        if (tid == 0) {
+            p.pos[m] += 1;
+            p.nf[m] = nfv + 1;
+            if (tokn[0] == p.im_end) p.done[m] = 1;
+        }
+    }
+}
+
 template <typename WT, bool ROUND>
-__global__ __launch_bounds__(1024) void sample_kernel(SampP p) {
+__global__ __launch_bounds__(1024) void sample_block_kernel(SampP p) {
     __shared__ float red[16];
     __shared__ int redi[16];
     __shared__ float pen_val[32];
@@ -772,33 +845,485 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampP p) {
         winner = best.i;
     }
 
-    // -- frame bookkeeping (inference.py:123-126, 148-155, 206-210)
-    int* tokn = p.tokn + (size_t)m * R;
-    int code = winner;
-    if (p.cb == 0) {
-        if (tid == 0) tokn[0] = winner;
-        code = winner - p.sem_begin;
-        code = code < 0 ? 0 : code;
-        code = code >= p.cbsize ? p.cbsize - 1 : code;  // reference would raise IndexError here
-        if (tid == 0) tokn[1] = code;
-    } else if (tid == 0) {
-        tokn[p.cb + 1] = code;
+    finish_draw<WT>(p, m, winner, nfv);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Same draw for V <= 1024 (the fast codebooks, inference.py:134) by ONE wave: 16 logits per lane
+// live in registers, every reduction is a wave butterfly, no barriers.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ ArgMax wave_argmax(ArgMax a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgMax b;
+        b.v = __shfl_xor(a.v, o, 64);
+        b.i = __shfl_xor(a.i, o, 64);
+        a = better(a, b);
     }
-    const WT* fe = reinterpret_cast<const WT*>(p.fast_emb);
-    for (int d = tid; d < p.Df; d += T) p.femb[(size_t)m * p.Df + d] = ld_elem(fe, (size_t)code * p.Df + d);
-    if (p.last) {
+    return a;
+}
+
+__device__ __forceinline__ float draw_noise(const SampP& p, const RowCtl& ctl, const float* qrow, int i, int nfv, int m) {
+    if (qrow) return qrow[i];
+    const uint32_t w = philox_word((uint32_t)i, (uint32_t)p.cb, (uint32_t)nfv, (uint32_t)m,
+                                   (uint32_t)ctl.seed, (uint32_t)(ctl.seed >> 32));
+    const float u = ((float)(w >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+    return fmaxf(-logf(u), 1e-30f);
+}
+
+template <typename WT, bool ROUND>
+__global__ __launch_bounds__(64) void sample_wave_kernel(SampP p) {
+    constexpr int E = 16;
+    const int m = blockIdx.x, lane = threadIdx.x;
+    float* L = p.logits + (size_t)m * p.ldl;
+    const int V = p.V;
+    const RowCtl ctl = p.ctl[m];
+    const int nfv = p.nf[m];
+    const int R = p.ncb + 1;
+    const int* seq = p.seq + (size_t)m * R * p.cap;
+    float l[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const int i = lane + 64 * e; l[e] = i < V ? L[i] : -INFINITY; }
+    if (nfv > 0) {  // repetition penalty: gather all, then scatter (duplicates write the same value)
+        const int it = nfv - 1;
+        const int ws = it < 16 ? 0 : it - 16;
+        const int npen = p.cb == 0 ? R : 16;
+        int id = -1;
+        float nv = 0.f;
+        if (lane < npen) {
+            id = p.cb == 0 ? seq[(size_t)lane * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + lane];
+            if (id >= 0 && id < V) {
+                const float sv = L[id];
+                nv = sv < 0.f ? rb<ROUND>(sv * ctl.rep) : rb<ROUND>(sv / ctl.rep);
+            } else id = -1;
+        }
+        for (int k = 0; k < npen; ++k) {
+            const int idk = __shfl(id, k, 64);
+            const float nvk = __shfl(nv, k, 64);
+            if (idk >= 0 && (idk & 63) == lane) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) if ((idk >> 6) == e) l[e] = nvk;
+            }
+        }
+    }
+    if (p.cb == 0 && ctl.ban_eos && p.im_end < V && (p.im_end & 63) == lane) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) if ((p.im_end >> 6) == e) l[e] = -INFINITY;
+    }
+    ArgMax am{-INFINITY, 0x7fffffff};
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const int i = lane + 64 * e; if (i < V) am = better(am, ArgMax{l[e], i}); }
+    am = wave_argmax(am);
+    const float Lmax = am.v;
+    float ex[E];
+    float z = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { ex[e] = (lane + 64 * e) < V ? expf(l[e] - Lmax) : 0.f; z += ex[e]; }
+    const float Z = wave_sum(z);
+    const float tp = rb<ROUND>(ctl.top_p);
+    auto removed = [&](float cum) { return rb<ROUND>(cum) > tp; };
+    float pr[E];
+    uint32_t key[E];
+    constexpr uint32_t cmask = ROUND ? 0xffff0000u : 0xffffffffu;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        pr[e] = (lane + 64 * e) < V ? rb<ROUND>(ex[e] / Z) : 0.f;
+        key[e] = (lane + 64 * e) < V ? (order_key(l[e]) & cmask) : 0u;
+    }
+    uint32_t kstar = 0;
+    int nk = 0;
+    bool all_kept = false, only_top = false;
+    if (removed(rb<ROUND>(1.0f / Z))) {  // expf(0)/Z: the mass of rank 0
+        only_top = true;
+    } else {
+        float tot = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) tot += pr[e];
+        tot = wave_sum(tot);
+        if (!removed(tot)) {
+            all_kept = true;
+        } else {
+            constexpr int lowbit = ROUND ? 16 : 0;
+            for (int bit = 31; bit >= lowbit; --bit) {
+                const uint32_t cand = kstar | (1u << bit);
+                float ms = 0.f;
+#pragma unroll
+                for (int e = 0; e < E; ++e) ms += key[e] >= cand ? pr[e] : 0.f;
+                ms = wave_sum(ms);
+                if (removed(ms)) kstar = cand;
+            }
+            float above = 0.f, cnt = 0.f, pk = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (key[e] > kstar) above += pr[e];
+                else if (key[e] == kstar && (lane + 64 * e) < V) { cnt += 1.f; pk = pr[e]; }
+            }
+            above = wave_sum(above);
+            const int icnt = (int)wave_sum(cnt);
+            pk = wave_max(pk);
+            int lo_n = 0, hi_n = icnt;
+            while (lo_n < hi_n) {
+                const int mid = (lo_n + hi_n + 1) >> 1;
+                if (removed(fmaf((float)mid, pk, above))) hi_n = mid - 1; else lo_n = mid;
+            }
+            nk = lo_n;
+        }
+    }
+    int winner = am.i;
+    if (!only_top) {
+        const float Tc = fmaxf(ctl.temperature, 1e-5f);
+        const float Mt = rb<ROUND>(Lmax / Tc);
+        // members of the cut class are kept in index order: i = lane + 64 e, e-major
+        bool keep[E];
+        int seen = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool valid = (lane + 64 * e) < V;
+            const bool member = valid && !all_kept && key[e] == kstar;
+            const unsigned long long bal = __ballot(member);
+            const int rank = seen + __popcll(bal & ((1ull << lane) - 1ull));
+            seen += __popcll(bal);
+            keep[e] = valid && (all_kept || key[e] > kstar || (member && rank < nk));
+        }
+        float z2 = 0.f;
+        float et[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { et[e] = keep[e] ? expf(rb<ROUND>(l[e] / Tc) - Mt) : 0.f; z2 += et[e]; }
+        const float Z2 = wave_sum(z2);
+        const float* qrow = nullptr;
+        if (p.noise && nfv < p.noise_rows) qrow = p.noise + (size_t)nfv * p.noise_row_len + p.noise_off;
+        ArgMax best{-1.f, 0x7fffffff};
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane + 64 * e;
+            if (i < V) {
+                const float prob = keep[e] ? rb<ROUND>(et[e] / Z2) : 0.f;
+                const float q = rb<ROUND>(draw_noise(p, ctl, qrow, i, nfv, m));
+                best = better(best, ArgMax{rb<ROUND>(prob / q), i});
+            }
+        }
+        winner = wave_argmax(best).i;
+    }
+    finish_draw<WT>(p, m, winner, nfv);
+}
+
+// ------------------------------------------------------------------------------------------
+// The same draw for a large vocabulary in bf16 precision, spread over the chip in five short
+// launches (one CU cannot evaluate 155 776 exponentials several times per frame in time):
+//   1 samp_hist      penalty + ban; COUNT histogram over the 65 536 possible bf16 logit values
+//                    (every member of a class has the same probability, so counts are enough and
+//                    integer atomics keep it deterministic)
+//   2 samp_threshold one block walks the histogram from the top: max, softmax normaliser,
+//                    inclusive cumulative mass, the cut class k*, how many of its members stay (nk),
+//                    the normaliser of the kept set after temperature
+//   3 samp_count     members of class k* per 1024-logit chunk (ranks tied members by index)
+//   4 samp_race      p/q for every kept logit, best per chunk
+//   5 samp_finish    best over chunks + frame bookkeeping
+// ------------------------------------------------------------------------------------------
+struct SampCut {
+    unsigned kstar;   // 16-bit class of the cut (valid unless all_kept)
+    int nk;           // members of class kstar that stay
+    int all_kept;
+    int argmax;       // lowest index is not tracked here; filled by samp_race when needed
+    float Lmax, Mt, Z2, Tc;
+};
+
+struct SampBigP {
+    SampP s;
+    unsigned* hist;      // [M][65536]
+    SampCut* cut;        // [M]
+    int* chunk_cnt;      // [M][nchunk]
+    float* part_score;   // [M][nchunk]
+    int* part_idx;       // [M][nchunk]
+    int nchunk;
+};
+
+__device__ __forceinline__ float key16_value(unsigned k16) {
+    const uint32_t k = k16 << 16;
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~(k | 0xffffu);
+    return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(256) void samp_hist_kernel(SampBigP b) {
+    __shared__ int pen_id[32];
+    __shared__ float pen_val[32];
+    const SampP& p = b.s;
+    const int m = blockIdx.y, tid = threadIdx.x;
+    const int c0 = blockIdx.x * 1024;
+    float* L = p.logits + (size_t)m * p.ldl;
+    const int V = p.V;
+    const RowCtl ctl = p.ctl[m];
+    const int nfv = p.nf[m];
+    const int R = p.ncb + 1;
+    const int* seq = p.seq + (size_t)m * R * p.cap;
+    if (nfv > 0) {
+        const int it = nfv - 1;
+        const int ws = it < 16 ? 0 : it - 16;
+        const int npen = p.cb == 0 ? R : 16;
+        if (tid < npen) {
+            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
+            pen_id[tid] = -1;
+            if (id >= c0 && id < c0 + 1024 && id < V) {
+                const float sv = L[id];
+                pen_id[tid] = id;
+                pen_val[tid] = sv < 0.f ? round_bf16(sv * ctl.rep) : round_bf16(sv / ctl.rep);
+            }
+        }
         __syncthreads();
-        if (tid < R) {
-            const int v = tokn[tid];
-            p.tok[(size_t)m * R + tid] = v;
-            if (nfv < p.cap) seq[(size_t)tid * p.cap + nfv] = v;
-        }
-        if (tid == 0) {
-            p.pos[m] += 1;
-            p.nf[m] = nfv + 1;
-            if (tokn[0] == p.im_end) p.done[m] = 1;
+        if (tid < npen && pen_id[tid] >= 0) L[pen_id[tid]] = pen_val[tid];
+    }
+    if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end >= c0 && p.im_end < c0 + 1024 && p.im_end < V)
+        L[p.im_end] = -INFINITY;
+    __syncthreads();
+    unsigned* hist = b.hist + (size_t)m * 65536;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = c0 + e * 256 + tid;
+        if (i < V) atomicAdd(&hist[order_key(L[i]) >> 16], 1u);
+    }
+}
+
+// LDS image of the histogram: thread t owns classes [64 t, 64 t + 64) as 32 dwords of two u16 counts,
+// rows padded to 33 dwords so the 64 lanes of a wave hit 32 different banks.  Counts >= 65535 (only
+// possible for a handful of classes) are kept exactly in a side table.
+constexpr int SAMP_TH_THREADS = 1024;
+constexpr int SAMP_TH_ROW = 33;
+constexpr int SAMP_TH_OVF = 8;
+constexpr size_t SAMP_TH_LDS = (size_t)SAMP_TH_THREADS * SAMP_TH_ROW * 4;
+
+__global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cimg[];
+    __shared__ float red[16];
+    __shared__ int redi[16];
+    __shared__ float wsum[16];
+    __shared__ unsigned ovf_key[SAMP_TH_OVF];
+    __shared__ unsigned ovf_cnt[SAMP_TH_OVF];
+    __shared__ int ovf_n;
+    __shared__ SampCut cut_s;
+    const SampP& p = b.s;
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const RowCtl ctl = p.ctl[m];
+    unsigned* hist = b.hist + (size_t)m * 65536;
+    if (tid == 0) ovf_n = 0;
+    __syncthreads();
+    uint32_t* row = cimg + tid * SAMP_TH_ROW;
+    int kmax_t = -1;
+    {
+        U4* h4 = reinterpret_cast<U4*>(hist + 64 * tid);
+#pragma unroll 4
+        for (int v = 0; v < 16; ++v) {
+            const U4 r = h4[v];
+            h4[v] = U4{0u, 0u, 0u, 0u};  // cleared for the next draw
+            const unsigned cs[4] = {r.x, r.y, r.z, r.w};
+            unsigned packed[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned c = cs[q];
+                if (c) kmax_t = 64 * tid + 4 * v + q;
+                if (c >= 65535u) {
+                    const int slot = atomicAdd(&ovf_n, 1);
+                    if (slot < SAMP_TH_OVF) { ovf_key[slot] = 64 * tid + 4 * v + q; ovf_cnt[slot] = c; }
+                    c = 65535u;
+                }
+                if (q & 1) packed[q >> 1] |= c << 16; else packed[q >> 1] = c;
+            }
+            row[2 * v] = packed[0];
+            row[2 * v + 1] = packed[1];
         }
     }
+    __syncthreads();
+    auto count_of = [&](int j) -> float {  // exact member count of my class j
+        const uint32_t w = row[j >> 1];
+        unsigned c = (j & 1) ? (w >> 16) : (w & 0xffffu);
+        if (c == 65535u) {
+            const unsigned k = 64 * tid + j;
+            for (int i = 0; i < ovf_n && i < SAMP_TH_OVF; ++i) if (ovf_key[i] == k) c = ovf_cnt[i];
+        }
+        return (float)c;
+    };
+    ArgMax km = block_argmax(ArgMax{(float)kmax_t, tid}, red, redi);
+    const unsigned kmax = (unsigned)(int)km.v;
+    const float Lmax = key16_value(kmax);
+    float z = 0.f;
+    for (int j = 0; j < 64; ++j) {
+        const float c = count_of(j);
+        if (c > 0.f) z = fmaf(c, expf(key16_value(64 * tid + j) - Lmax), z);
+    }
+    const float Z = block_sum(z, red);
+    const float tp = round_bf16(ctl.top_p);
+    auto removed = [&](float cum) { return round_bf16(cum) > tp; };
+    auto prob = [&](unsigned k16) { return round_bf16(expf(key16_value(k16) - Lmax) / Z); };
+    // mass of this thread's classes, then of everything above them (suffix over threads)
+    float mt = 0.f;
+    for (int j = 0; j < 64; ++j) {
+        const float c = count_of(j);
+        if (c > 0.f) mt = fmaf(c, prob(64 * tid + j), mt);
+    }
+    float suf = mt;  // inclusive suffix within the wave (lanes >= mine)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_down(suf, o, 64);
+        if (lane + o < 64) suf += t;
+    }
+    __syncthreads();
+    if (lane == 0) wsum[wave] = suf;
+    __syncthreads();
+    float above = suf - mt;
+    for (int w = wave + 1; w < 16; ++w) above += wsum[w];
+    // walk my classes from the top; the cut is the first class whose inclusive mass is removed
+    int found = -1;
+    float f_above = 0.f, f_cnt = 0.f;
+    float run = above;
+    for (int j = 63; j >= 0; --j) {
+        const float c = count_of(j);
+        if (c > 0.f) {
+            const float nxt = fmaf(c, prob(64 * tid + j), run);
+            if (found < 0 && removed(nxt)) { found = j; f_above = run; f_cnt = c; }
+            run = nxt;
+        }
+    }
+    ArgMax who = block_argmax(ArgMax{found >= 0 ? (float)tid : -1.f, tid}, red, redi);
+    if (tid == 0) { cut_s.all_kept = who.v < 0.f ? 1 : 0; cut_s.kstar = 0; cut_s.nk = 0; }
+    __syncthreads();
+    if (who.v >= 0.f && tid == (int)who.v) {
+        const unsigned ks = 64 * tid + found;
+        const float pk = prob(ks);
+        int lo_n = 0, hi_n = (int)f_cnt;
+        while (lo_n < hi_n) {
+            const int mid = (lo_n + hi_n + 1) >> 1;
+            if (removed(fmaf((float)mid, pk, f_above))) hi_n = mid - 1; else lo_n = mid;
+        }
+        if (ks == kmax && lo_n < 1) lo_n = 1;  // rank 0 is always kept (inference.py:53)
+        cut_s.kstar = ks;
+        cut_s.nk = lo_n;
+    }
+    __syncthreads();
+    const unsigned kstar = cut_s.kstar;
+    const int nk = cut_s.nk, all_kept = cut_s.all_kept;
+    const float Tc = fmaxf(ctl.temperature, 1e-5f);
+    const float Mt = round_bf16(Lmax / Tc);
+    float z2 = 0.f;
+    for (int j = 0; j < 64; ++j) {
+        const float c = count_of(j);
+        if (c > 0.f) {
+            const unsigned k = 64 * tid + j;
+            float n = 0.f;
+            if (all_kept || k > kstar) n = c;
+            else if (k == kstar) n = (float)nk;
+            if (n > 0.f) z2 = fmaf(n, expf(round_bf16(key16_value(k) / Tc) - Mt), z2);
+        }
+    }
+    const float Z2 = block_sum(z2, red);
+    if (tid == 0) {
+        SampCut o;
+        o.kstar = kstar; o.nk = nk; o.all_kept = all_kept; o.argmax = 0;
+        o.Lmax = Lmax; o.Mt = Mt; o.Z2 = Z2; o.Tc = Tc;
+        b.cut[m] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void samp_count_kernel(SampBigP b) {
+    __shared__ float red[4];
+    const SampP& p = b.s;
+    const int m = blockIdx.y, tid = threadIdx.x;
+    const int c0 = blockIdx.x * 1024;
+    const float* L = p.logits + (size_t)m * p.ldl;
+    const SampCut cut = b.cut[m];
+    float c = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = c0 + 4 * tid + e;
+        if (i < p.V && (order_key(L[i]) >> 16) == cut.kstar) c += 1.f;
+    }
+    c = wave_sum(c);
+    if ((tid & 63) == 0) red[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) b.chunk_cnt[(size_t)m * b.nchunk + blockIdx.x] = (int)(red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void samp_race_kernel(SampBigP b) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    __shared__ int wcnt[4];
+    const SampP& p = b.s;
+    const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * 1024;
+    const float* L = p.logits + (size_t)m * p.ldl;
+    const int V = p.V;
+    const RowCtl ctl = p.ctl[m];
+    const int nfv = p.nf[m];
+    const SampCut cut = b.cut[m];
+    // rank base: members of the cut class in earlier chunks
+    float basef = 0.f;
+    for (int i = tid; i < (int)blockIdx.x; i += 256) basef += (float)b.chunk_cnt[(size_t)m * b.nchunk + i];
+    basef = wave_sum(basef);
+    if (lane == 0) red[wave] = basef;
+    __syncthreads();
+    const int base = (int)(red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();
+    // this thread owns 4 consecutive logits, so index order = thread order
+    float l[4];
+    bool member[4];
+    int mine = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = c0 + 4 * tid + e;
+        l[e] = i < V ? L[i] : -INFINITY;
+        member[e] = i < V && !cut.all_kept && (order_key(l[e]) >> 16) == cut.kstar;
+        mine += member[e] ? 1 : 0;
+    }
+    int incl = mine;  // inclusive prefix over lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wcnt[wave] = incl;
+    __syncthreads();
+    int rank = base + incl - mine;
+    for (int w = 0; w < wave; ++w) rank += wcnt[w];
+    const float* qrow = nullptr;
+    if (p.noise && nfv < p.noise_rows) qrow = p.noise + (size_t)nfv * p.noise_row_len + p.noise_off;
+    ArgMax best{-1.f, 0x7fffffff};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = c0 + 4 * tid + e;
+        if (i < V) {
+            bool keep = cut.all_kept || (order_key(l[e]) >> 16) > cut.kstar;
+            if (member[e]) { keep = rank < cut.nk; ++rank; }
+            const float prob = keep ? round_bf16(expf(round_bf16(l[e] / cut.Tc) - cut.Mt) / cut.Z2) : 0.f;
+            const float q = round_bf16(draw_noise(p, ctl, qrow, i, nfv, m));
+            best = better(best, ArgMax{round_bf16(prob / q), i});
+        }
+    }
+    best = wave_argmax(best);
+    if (lane == 0) { red[wave] = best.v; redi[wave] = best.i; }
+    __syncthreads();
+    if (tid == 0) {
+        ArgMax t{red[0], redi[0]};
+        for (int w = 1; w < 4; ++w) t = better(t, ArgMax{red[w], redi[w]});
+        b.part_score[(size_t)m * b.nchunk + blockIdx.x] = t.v;
+        b.part_idx[(size_t)m * b.nchunk + blockIdx.x] = t.i;
+    }
+}
+
+template <typename WT>
+__global__ __launch_bounds__(256) void samp_finish_kernel(SampBigP b) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    const SampP& p = b.s;
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ArgMax best{-2.f, 0x7fffffff};
+    for (int i = tid; i < b.nchunk; i += 256)
+        best = better(best, ArgMax{b.part_score[(size_t)m * b.nchunk + i], b.part_idx[(size_t)m * b.nchunk + i]});
+    best = wave_argmax(best);
+    if (lane == 0) { red[wave] = best.v; redi[wave] = best.i; }
+    __syncthreads();
+    ArgMax t{red[0], redi[0]};
+    for (int w = 1; w < 4; ++w) t = better(t, ArgMax{red[w], redi[w]});
+    __syncthreads();
+    finish_draw<WT>(p, m, t.i, p.nf[m]);
 }
 
 }  // namespace ft

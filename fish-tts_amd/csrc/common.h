@@ -7,7 +7,7 @@ namespace ft {
 
 typedef uint16_t bf16_t;  // raw bf16 bits
 
-struct alignas(16) U4 { uint32_t x, y, z, w; };
+typedef uint32_t U4 __attribute__((ext_vector_type(4)));  // one 16-byte load
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
 

@@ -7,7 +7,12 @@
 #include <vector>
 
 #include "../../include/fishtts_hip.h"
-#include "ar_kernels.h"
+#include "common.h"
+
+namespace ft {
+struct RowCtl;
+struct SampCut;
+}  // namespace ft (kernels live in ar_kernels.h, included by engine.hip only)
 
 struct FtTensor {
     void* p = nullptr;
@@ -61,6 +66,15 @@ struct ft_ctx {
     int *h_pin = nullptr;  // pinned scratch (2*max_batch + 4 ints)
     float* noise = nullptr;
     long noise_rows = 0, noise_row_len = 0;
+
+    // large-vocabulary sampler scratch
+    unsigned* samp_hist = nullptr;
+    ft::SampCut* samp_cut = nullptr;
+    int* samp_chunk_cnt = nullptr;
+    float* samp_part_score = nullptr;
+    int* samp_part_idx = nullptr;
+    bool force_block_sampler = false;
+    int nt_weights = 1;
 
     std::map<int, hipGraphExec_t> graphs;
 

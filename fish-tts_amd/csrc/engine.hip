@@ -1,6 +1,7 @@
 // libfishtts_hip.so: context, weight ingestion, the AR prefill/decode drivers (hipGraph-captured
 // frame step) and the C ABI declared in include/fishtts_hip.h.
 #include "engine.h"
+#include "ar_kernels.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -124,6 +125,7 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     ctx->n_slots = c.max_seq_len + ((8 - c.max_seq_len % 8) % 8);  // llama.py:387
     const char* ns = getenv("FT_ATTN_NSPLIT");
     ctx->nsplit = ns ? atoi(ns) : (ctx->n_slots > 512 ? 8 : 1);
+    ctx->nt_weights = getenv("FT_NO_NT") ? 0 : 1;
     if (ctx->nsplit < 1) ctx->nsplit = 1;
     ctx->cap = c.max_new_tokens + 24;
     ctx->fastV = c.codebook_size < 1024 ? c.codebook_size : 1024;  // inference.py:134
@@ -164,6 +166,13 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     FT_TRY(dmalloc(ctx, &ctx->d_done, M));
     FT_TRY(dmalloc(ctx, &ctx->d_prompt, R * (size_t)c.max_seq_len));
     FT_TRY(dmalloc(ctx, &ctx->d_ctl, M));
+    const size_t nchunk = ((size_t)c.vocab_size + 1023) / 1024;
+    FT_TRY(dmalloc(ctx, &ctx->samp_hist, M * 65536));
+    FT_TRY(dmalloc(ctx, &ctx->samp_cut, M));
+    FT_TRY(dmalloc(ctx, &ctx->samp_chunk_cnt, M * nchunk));
+    FT_TRY(dmalloc(ctx, &ctx->samp_part_score, M * nchunk));
+    FT_TRY(dmalloc(ctx, &ctx->samp_part_idx, M * nchunk));
+    ctx->force_block_sampler = getenv("FT_SAMPLER_BLOCK") != nullptr;
     FT_HIP(ctx, hipHostMalloc((void**)&ctx->h_pin, (2 * M + 8) * sizeof(int), hipHostMallocDefault));
     return FT_OK;
 }
@@ -220,6 +229,11 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     int* ibufs[] = {ctx->d_pos, ctx->d_tok, ctx->d_tokn, ctx->d_seq, ctx->d_nf, ctx->d_done, ctx->d_prompt};
     for (int* b : ibufs) if (b) hipFree(b);
     if (ctx->d_ctl) hipFree(ctx->d_ctl);
+    if (ctx->samp_hist) hipFree(ctx->samp_hist);
+    if (ctx->samp_cut) hipFree(ctx->samp_cut);
+    if (ctx->samp_chunk_cnt) hipFree(ctx->samp_chunk_cnt);
+    if (ctx->samp_part_score) hipFree(ctx->samp_part_score);
+    if (ctx->samp_part_idx) hipFree(ctx->samp_part_idx);
     if (ctx->h_pin) hipHostFree(ctx->h_pin);
     for (auto e : ctx->prof_ev) hipEventDestroy(e);
     codec_destroy(ctx);
@@ -461,7 +475,7 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
         const FtLayer& l = ctx->layers[li];
         GemvP p{};
         p.W = l.wqkv; p.bias = l.bqkv; p.x = x; p.ldx = c.dim; p.gain = l.attn_norm; p.eps = c.norm_eps;
-        p.out = qkv; p.ldo = (int)qkvN; p.N = (int)qkvN; p.K = c.dim; p.pro = PRO_RMSNORM; p.epi = EPI_STORE;
+        p.out = qkv; p.ldo = (int)qkvN; p.N = (int)qkvN; p.K = c.dim; p.pro = PRO_RMSNORM; p.epi = EPI_STORE; p.nt = ctx->nt_weights;
         gemv<WT, ROUND>(L, p, rows_per_wave(p.N, L.M));
 
         AttnP a{};
@@ -478,24 +492,24 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
 
         GemvP o{};
         o.W = l.wo; o.bias = l.bo; o.x = y; o.ldx = c.n_head * c.head_dim; o.out = x; o.ldo = c.dim;
-        o.resid = x; o.ldr = c.dim; o.N = c.dim; o.K = c.n_head * c.head_dim; o.pro = PRO_NONE; o.epi = EPI_RESID;
+        o.resid = x; o.ldr = c.dim; o.N = c.dim; o.K = c.n_head * c.head_dim; o.pro = PRO_NONE; o.epi = EPI_RESID; o.nt = ctx->nt_weights;
         gemv<WT, ROUND>(L, o, rows_per_wave(o.N, L.M));
 
         GemvP f{};
         f.W = l.w13; f.x = x; f.ldx = c.dim; f.gain = l.ffn_norm; f.eps = c.norm_eps; f.out = g;
-        f.ldo = c.intermediate_size; f.N = 2 * c.intermediate_size; f.K = c.dim; f.pro = PRO_RMSNORM; f.epi = EPI_SWIGLU;
+        f.ldo = c.intermediate_size; f.N = 2 * c.intermediate_size; f.K = c.dim; f.pro = PRO_RMSNORM; f.epi = EPI_SWIGLU; f.nt = ctx->nt_weights;
         gemv<WT, ROUND>(L, f, rows_per_wave(f.N, L.M));
 
         GemvP d{};
         d.W = l.w2; d.x = g; d.ldx = c.intermediate_size; d.out = x; d.ldo = c.dim; d.resid = x; d.ldr = c.dim;
-        d.N = c.dim; d.K = c.intermediate_size; d.pro = PRO_NONE; d.epi = EPI_RESID;
+        d.N = c.dim; d.K = c.intermediate_size; d.pro = PRO_NONE; d.epi = EPI_RESID; d.nt = ctx->nt_weights;
         gemv<WT, ROUND>(L, d, rows_per_wave(d.N, L.M));
     }
     if (!with_head) return;
     GemvP h{};
     h.W = ctx->head; h.x = x; h.ldx = c.dim; h.gain = ctx->norm; h.eps = c.norm_eps;
     h.out = ctx->logits + (size_t)m0 * c.vocab_size; h.ldo = c.vocab_size; h.N = c.vocab_size; h.K = c.dim;
-    h.pro = PRO_RMSNORM; h.epi = EPI_STORE;
+    h.pro = PRO_RMSNORM; h.epi = EPI_STORE; h.nt = ctx->nt_weights;
     gemv<WT, ROUND>(L, h, rows_per_wave(h.N, L.M));
     if (c.fast_dim != c.dim) {  // fast_project_in on the pre-norm hidden state (llama.py:453,590)
         GemvP q{};
@@ -521,7 +535,32 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
     s.noise_row_len = ctx->noise_row_len; s.noise_rows = ctx->noise_rows;
     s.noise_off = cb == 0 ? 0 : (long)c.vocab_size + (long)(cb - 1) * ctx->fastV;
     s.last = last ? 1 : 0; s.tok = ctx->d_tok + (size_t)m0 * R; s.pos = ctx->d_pos + m0; s.done = ctx->d_done + m0;
-    sample_kernel<WT, ROUND><<<L.M, 1024, 0, L.s>>>(s);
+    if (s.V <= 1024 && !ctx->force_block_sampler) {
+        sample_wave_kernel<WT, ROUND><<<L.M, 64, 0, L.s>>>(s);
+    } else if (ROUND && !ctx->force_block_sampler) {
+        SampBigP b{};
+        b.s = s; b.nchunk = (s.V + 1023) / 1024;
+        b.hist = ctx->samp_hist + (size_t)m0 * 65536; b.cut = ctx->samp_cut + m0;
+        b.chunk_cnt = ctx->samp_chunk_cnt + (size_t)m0 * b.nchunk;
+        b.part_score = ctx->samp_part_score + (size_t)m0 * b.nchunk;
+        b.part_idx = ctx->samp_part_idx + (size_t)m0 * b.nchunk;
+        const dim3 gridc(b.nchunk, L.M);
+        samp_hist_kernel<<<gridc, 256, 0, L.s>>>(b);
+        {
+            static bool attr_done = false;
+            if (!attr_done) {
+                hipFuncSetAttribute((const void*)samp_threshold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)SAMP_TH_LDS);
+                attr_done = true;
+            }
+        }
+        samp_threshold_kernel<<<L.M, SAMP_TH_THREADS, SAMP_TH_LDS, L.s>>>(b);
+        samp_count_kernel<<<gridc, 256, 0, L.s>>>(b);
+        samp_race_kernel<<<gridc, 256, 0, L.s>>>(b);
+        samp_finish_kernel<WT><<<L.M, 256, 0, L.s>>>(b);
+    } else {
+        sample_block_kernel<WT, ROUND><<<L.M, 1024, 0, L.s>>>(s);
+    }
     L.chk();
 }
 
@@ -536,7 +575,7 @@ static void enqueue_fast(Launch& L) {
     float* xf = ctx->xf + (size_t)m0 * Df;
     float* qkvf = ctx->qkvf + (size_t)m0 * qkvN;
     float* gf = ctx->gf + (size_t)m0 * c.fast_intermediate_size;
-    const size_t lds = (size_t)(2 * Hf + 2 * Hkvf) * hdf * sizeof(float);
+    const size_t lds = fast_attn_lds_floats(Hf, Hkvf, hdf, c.num_codebooks) * sizeof(float);
     for (int cb = 0; cb < c.num_codebooks; ++cb) {
         const float* xin = cb == 0 ? ctx->hid + (size_t)m0 * Df : ctx->femb + (size_t)m0 * Df;
         for (int li = 0; li < c.n_fast_layer; ++li) {
