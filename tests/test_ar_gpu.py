@@ -239,7 +239,7 @@ def test_sampling_kernel_vs_oracle(precision):
             n_cases += 1
             # an exact tie of logits has no defined survivor (the reference's sort is unstable):
             # any member of the same tie class is accepted
-            if got != want and not (trial % 5 == 0 and logits[got] == logits[want]):
+            if got != want and not (logits[got] == logits[want]):
                 bad.append((trial, cb, tp, temp, rep, got, want))
     eng.close()
     assert not bad, f"{len(bad)}/{n_cases} draws differ: {bad[:8]}"
