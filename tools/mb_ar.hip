@@ -1,0 +1,127 @@
+// Kernel-level microbenchmark for the AR decode kernels (build + run on the GPU box):
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -I fish-tts_amd/csrc tools/mb_ar.hip -o /tmp/mb_ar && /tmp/mb_ar
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <functional>
+#include <vector>
+
+#include "ar_kernels.h"
+using namespace ft;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("ERR %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__global__ void clock_probe(unsigned long long* out, int iters) {
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    float a = threadIdx.x;
+    for (int i = 0; i < iters; ++i) a = fmaf(a, 1.0001f, 0.5f);
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+    if (a == 12345.f) out[2] = 1;
+}
+__global__ void dep_load_kernel(const float* p, float* o, int hops) {  // trivial kernel with a dependent load chain
+    int idx = threadIdx.x;
+    float v = 0.f;
+    for (int h = 0; h < hops; ++h) { v = p[idx]; idx = ((int)v + idx * 7 + 13) & 1023; }
+    o[threadIdx.x] = v;
+}
+
+static hipStream_t s;
+static float time_graph(const std::function<void()>& enqueue, int launches_per_graph, int reps = 20) {
+    hipGraph_t g; hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    enqueue();
+    CK(hipStreamEndCapture(s, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, s));
+    CK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) CK(hipGraphLaunch(ge, s));
+    CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+    return ms * 1e3f / (reps * launches_per_graph);
+}
+
+template <int NT, int R>
+static void launch_gemv(GemvP p, int M) {
+    gemv_kernel<bf16_t, NT, R, true><<<dim3((p.N + 4 * R - 1) / (4 * R), M), 256, 0, s>>>(p);
+}
+
+int main() {
+    CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    const int L = 28, D = 1024, FF = 3072, QKV = 4096;
+    // per-layer weights, distinct buffers so the stream is cold like the real frame
+    std::vector<bf16_t*> wqkv(L), wo(L), w13(L), w2(L);
+    for (int l = 0; l < L; ++l) {
+        CK(hipMalloc(&wqkv[l], (size_t)QKV * D * 2)); CK(hipMalloc(&wo[l], (size_t)D * 2048 * 2));
+        CK(hipMalloc(&w13[l], (size_t)2 * FF * D * 2)); CK(hipMalloc(&w2[l], (size_t)D * FF * 2));
+        CK(hipMemset(wqkv[l], 0x11, (size_t)QKV * D * 2)); CK(hipMemset(wo[l], 0x11, (size_t)D * 2048 * 2));
+        CK(hipMemset(w13[l], 0x11, (size_t)2 * FF * D * 2)); CK(hipMemset(w2[l], 0x11, (size_t)D * FF * 2));
+    }
+    float *x, *qkv, *y, *g; bf16_t* gain;
+    CK(hipMalloc(&x, D * 4)); CK(hipMalloc(&qkv, QKV * 4)); CK(hipMalloc(&y, 2048 * 4)); CK(hipMalloc(&g, FF * 4));
+    CK(hipMalloc(&gain, 4096 * 2)); CK(hipMemset(gain, 0x3f, 4096 * 2));
+    CK(hipMemset(x, 0, D * 4)); CK(hipMemset(y, 0, 2048 * 4)); CK(hipMemset(g, 0, FF * 4));
+    unsigned long long* clk; CK(hipMalloc(&clk, 64));
+
+    // 0. clocks
+    for (int rep = 0; rep < 3; ++rep) {
+        clock_probe<<<1, 64, 0, s>>>(clk, 200000);
+        CK(hipStreamSynchronize(s));
+        unsigned long long h[2]; CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+        printf("clock probe: memtime %llu realtime %llu -> shader clock ~ %.0f MHz\n", h[0], h[1], (double)h[0] / h[1] * 100.0);
+    }
+    // 1. trivial dependent-load kernels
+    for (int hops : {1, 2, 4}) {
+        float us = time_graph([&] { for (int i = 0; i < 200; ++i) dep_load_kernel<<<16, 128, 0, s>>>(x, qkv, hops); }, 200);
+        printf("dep_load hops=%d: %.2f us/kernel\n", hops, us);
+    }
+    auto mk = [&](const void* W, const float* xin, int ldx, float* out, int ldo, int N, int K, int pro, int epi, int nt) {
+        GemvP p{}; p.W = W; p.x = xin; p.ldx = ldx; p.out = out; p.ldo = ldo; p.N = N; p.K = K; p.pro = pro; p.epi = epi;
+        p.gain = gain; p.eps = 1e-6f; p.resid = out; p.ldr = ldo; p.nt = nt; return p;
+    };
+    for (int nt = 0; nt < 2; ++nt) {
+        printf("---- nt=%d\n", nt);
+        // 2. each GEMV shape alone, cycling layers
+        float us;
+        us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 2>(mk(wqkv[l], x, D, qkv, QKV, QKV, D, PRO_RMSNORM, EPI_STORE, nt), 1); }, L);
+        printf("qkv   N=4096 K=1024 R=2: %.2f us  (%.0f GB/s)\n", us, QKV * D * 2.0 / us / 1e3);
+        us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 1>(mk(wqkv[l], x, D, qkv, QKV, QKV, D, PRO_RMSNORM, EPI_STORE, nt), 1); }, L);
+        printf("qkv   N=4096 K=1024 R=1: %.2f us  (%.0f GB/s)\n", us, QKV * D * 2.0 / us / 1e3);
+        us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 4>(mk(wqkv[l], x, D, qkv, QKV, QKV, D, PRO_RMSNORM, EPI_STORE, nt), 1); }, L);
+        printf("qkv   N=4096 K=1024 R=4: %.2f us  (%.0f GB/s)\n", us, QKV * D * 2.0 / us / 1e3);
+        us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<4, 1>(mk(wo[l], y, 2048, x, D, D, 2048, PRO_NONE, EPI_RESID, nt), 1); }, L);
+        printf("wo    N=1024 K=2048 R=1: %.2f us  (%.0f GB/s)\n", us, D * 2048 * 2.0 / us / 1e3);
+        us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 2>(mk(w13[l], x, D, g, FF, 2 * FF, D, PRO_RMSNORM, EPI_SWIGLU, nt), 1); }, L);
+        printf("w13   N=6144 K=1024 R=2: %.2f us  (%.0f GB/s)\n", us, 2.0 * FF * D * 2.0 / us / 1e3);
+        us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 4>(mk(w13[l], x, D, g, FF, 2 * FF, D, PRO_RMSNORM, EPI_SWIGLU, nt), 1); }, L);
+        printf("w13   N=6144 K=1024 R=4: %.2f us  (%.0f GB/s)\n", us, 2.0 * FF * D * 2.0 / us / 1e3);
+        us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<6, 1>(mk(w2[l], g, FF, x, D, D, FF, PRO_NONE, EPI_RESID, nt), 1); }, L);
+        printf("w2    N=1024 K=3072 R=1: %.2f us  (%.0f GB/s)\n", us, D * FF * 2.0 / us / 1e3);
+        // 3. the four GEMVs of a layer in sequence over all layers
+        us = time_graph([&] {
+            for (int l = 0; l < L; ++l) {
+                launch_gemv<2, 2>(mk(wqkv[l], x, D, qkv, QKV, QKV, D, PRO_RMSNORM, EPI_STORE, nt), 1);
+                launch_gemv<4, 1>(mk(wo[l], y, 2048, x, D, D, 2048, PRO_NONE, EPI_RESID, nt), 1);
+                launch_gemv<2, 2>(mk(w13[l], x, D, g, FF, 2 * FF, D, PRO_RMSNORM, EPI_SWIGLU, nt), 1);
+                launch_gemv<6, 1>(mk(w2[l], g, FF, x, D, D, FF, PRO_NONE, EPI_RESID, nt), 1);
+            }
+        }, L);
+        printf("layer (4 gemv, 31.5 MB): %.2f us/layer  (%.0f GB/s)\n", us, 31.46e6 / us / 1e3);
+    }
+    // 4. fast stack weights (MALL resident): 4 layers re-read
+    {
+        float us = time_graph([&] {
+            for (int rep = 0; rep < 10; ++rep)
+                for (int l = 0; l < 4; ++l) {
+                    launch_gemv<2, 2>(mk(wqkv[l], x, D, qkv, 2048, 2048, D, PRO_RMSNORM, EPI_STORE, 0), 1);
+                    launch_gemv<2, 1>(mk(wo[l], y, 1024, x, D, D, 1024, PRO_NONE, EPI_RESID, 0), 1);
+                    launch_gemv<2, 2>(mk(w13[l], x, D, g, FF, 2 * FF, D, PRO_RMSNORM, EPI_SWIGLU, 0), 1);
+                    launch_gemv<6, 1>(mk(w2[l], g, FF, x, D, D, FF, PRO_NONE, EPI_RESID, 0), 1);
+                }
+        }, 40);
+        printf("fast layer (4 gemv, 25 MB, cache-resident): %.2f us/layer\n", us);
+    }
+    return 0;
+}
