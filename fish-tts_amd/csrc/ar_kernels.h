@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
             float d = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) d = fmaf(qr[g][e], kv[e], d);
-            for (int o = LPP >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            if (LPP > 1) d = group_sum_rt(d, LPP);
             if (valid) {
                 const float s = d * p.scale;
                 const float mn = fmaxf(mrun[g], s);
@@ -379,24 +379,36 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     }
 }
 
-template <bool ROUND>
-__global__ __launch_bounds__(128) void attn_combine_kernel(AttnP p) {
-    const int head = blockIdx.x, m = blockIdx.y;
-    const size_t base = ((size_t)m * p.H + head) * p.nsplit;
-    float M = -INFINITY;
-    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, p.part_ml[(base + s) * 2]);
-    for (int e = threadIdx.x; e < p.hd; e += 128) {
-        float L = 0.f, O = 0.f;
-        for (int s = 0; s < p.nsplit; ++s) {
-            const float ms = p.part_ml[(base + s) * 2];
+// Wo GEMV (+ residual) whose input vector is assembled on the fly from the split-KV partials of
+// attn_decode_kernel: y[head][e] = sum_s O_s w_s / sum_s l_s w_s, w_s = exp(m_s - max m).  Saves the
+// separate combine launch; each lane merges only the 8 (4) consecutive elements it multiplies.
+template <typename WT, int NT, int R, bool ROUND>
+__global__ __launch_bounds__(256) void gemv_attn_combine_kernel(GemvP p, AttnP a) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= p.N) return;
+    const int m = blockIdx.y;
+    constexpr int VEC = Vec<WT>::N;
+    gemv_rows<WT, NT, R, ROUND>(p, m, row0, lane, [&](int k, float(&v)[VEC]) {
+        const int head = k / a.hd, e = k % a.hd;
+        const size_t base = ((size_t)m * a.H + head) * a.nsplit;
+        float M = -INFINITY;
+        for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, a.part_ml[(base + s) * 2]);
+        float L = 0.f, O[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) O[j] = 0.f;
+        for (int s = 0; s < a.nsplit; ++s) {
+            const float ms = a.part_ml[(base + s) * 2];
             if (ms > -INFINITY) {
                 const float w = expf(ms - M);
-                L += p.part_ml[(base + s) * 2 + 1] * w;
-                O += p.part_o[(base + s) * p.hd + e] * w;
+                L += a.part_ml[(base + s) * 2 + 1] * w;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) O[j] += a.part_o[(base + s) * a.hd + e + j] * w;
             }
         }
-        p.y[(size_t)m * p.ldy + head * p.hd + e] = rb<ROUND>(O / L);
-    }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = rb<ROUND>(O[j] / L);
+    });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -461,6 +473,17 @@ __device__ __forceinline__ void fast_attention_to_lds(const FastAttnP& a, const 
         }
     }
     // new q (all heads), new k -> slot c of kL, new v -> slot c of vL
+    if (!qn && !kn) {
+        // no per-head norm (the s1-mini fast stack): every rotation pair is independent
+        for (int pi = tid; pi < (H + Hkv) * hp; pi += 256) {
+            const int item = pi / hp, i = pi % hp;
+            const float x0 = qkv[(size_t)item * hd + 2 * i], x1 = qkv[(size_t)item * hd + 2 * i + 1];
+            const float cs = a.rope[((size_t)c * hp + i) * 2], sn = a.rope[((size_t)c * hp + i) * 2 + 1];
+            float* dst = item < H ? q_s + item * hd : kL + ((size_t)(item - H) * ncb + c) * hd;
+            dst[2 * i] = rb<ROUND>(x0 * cs - x1 * sn);
+            dst[2 * i + 1] = rb<ROUND>(x1 * cs + x0 * sn);
+        }
+    } else
     for (int item = wave; item < H + Hkv; item += 4) {
         const float* src = qkv + (size_t)item * hd;
         const WT* gain = item < H ? qn : kn;
@@ -517,9 +540,7 @@ __device__ __forceinline__ void fast_attention_to_lds(const FastAttnP& a, const 
         }
 #pragma unroll
         for (int j = 0; j < FAST_MAXCB; ++j) {
-            float d = s[j];
-            d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64);
-            d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
+            const float d = row16_sum(s[j]);
             s[j] = (j <= c) ? rb<ROUND>(rb<ROUND>(d) * a.scale) : -INFINITY;
         }
         float mx = -INFINITY;
@@ -605,8 +626,9 @@ __device__ __forceinline__ uint32_t order_key(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__device__ __forceinline__ uint32_t philox_word(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                                uint32_t k0, uint32_t k1) {
+struct Philox4 { uint32_t w[4]; };
+__device__ __forceinline__ Philox4 philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
@@ -618,7 +640,15 @@ __device__ __forceinline__ uint32_t philox_word(uint32_t c0, uint32_t c1, uint32
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    return c0;
+    return Philox4{{c0, c1, c2, c3}};
+}
+__device__ __forceinline__ uint32_t philox_word(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                uint32_t k0, uint32_t k1) {
+    return philox4(c0 >> 2, c1, c2, c3, k0, k1).w[c0 & 3];
+}
+__device__ __forceinline__ float exp1_from_word(uint32_t w) {
+    const float u = ((float)(w >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+    return fmaxf(-logf(u), 1e-30f);
 }
 
 struct ArgMax { float v; int i; };
@@ -637,14 +667,18 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
     return t;
 }
+__device__ __forceinline__ ArgMax wave_argmax(ArgMax a) {
+#define FT_AM_STEP(C) { ArgMax b_; b_.v = dpp_f<C>(a.v); b_.i = dpp_i<C>(a.i); a = better(a, b_); }
+    FT_AM_STEP(DPP_XOR1) FT_AM_STEP(DPP_XOR2) FT_AM_STEP(DPP_HALF_MIRROR) FT_AM_STEP(DPP_MIRROR)
+#undef FT_AM_STEP
+    ArgMax r{lane_f(a.v, 0), __builtin_amdgcn_readlane(a.i, 0)};
+    r = better(r, ArgMax{lane_f(a.v, 16), __builtin_amdgcn_readlane(a.i, 16)});
+    r = better(r, ArgMax{lane_f(a.v, 32), __builtin_amdgcn_readlane(a.i, 32)});
+    r = better(r, ArgMax{lane_f(a.v, 48), __builtin_amdgcn_readlane(a.i, 48)});
+    return r;
+}
 __device__ __forceinline__ ArgMax block_argmax(ArgMax a, float* redv, int* redi) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ArgMax b;
-        b.v = __shfl_xor(a.v, o, 64);
-        b.i = __shfl_xor(a.i, o, 64);
-        a = better(a, b);
-    }
+    a = wave_argmax(a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) { redv[wave] = a.v; redi[wave] = a.i; }
@@ -832,11 +866,8 @@ __global__ __launch_bounds__(1024) void sample_block_kernel(SampP p) {
             float q;
             if (qrow) q = qrow[i];
             else {
-                const uint32_t w = philox_word((uint32_t)i, (uint32_t)p.cb, (uint32_t)nfv, (uint32_t)m,
-                                               (uint32_t)ctl.seed, (uint32_t)(ctl.seed >> 32));
-                const float u = ((float)(w >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
-                q = -logf(u);
-                q = fmaxf(q, 1e-30f);
+                q = exp1_from_word(philox_word((uint32_t)i, (uint32_t)p.cb, (uint32_t)nfv, (uint32_t)m,
+                                               (uint32_t)ctl.seed, (uint32_t)(ctl.seed >> 32)));
             }
             q = rb<ROUND>(q);
             best = better(best, ArgMax{rb<ROUND>(pr / q), i});
@@ -853,23 +884,23 @@ __global__ __launch_bounds__(1024) void sample_block_kernel(SampP p) {
 // Same draw for V <= 1024 (the fast codebooks, inference.py:134) by ONE wave: 16 logits per lane
 // live in registers, every reduction is a wave butterfly, no barriers.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ ArgMax wave_argmax(ArgMax a) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ArgMax b;
-        b.v = __shfl_xor(a.v, o, 64);
-        b.i = __shfl_xor(a.i, o, 64);
-        a = better(a, b);
-    }
-    return a;
-}
-
 __device__ __forceinline__ float draw_noise(const SampP& p, const RowCtl& ctl, const float* qrow, int i, int nfv, int m) {
     if (qrow) return qrow[i];
-    const uint32_t w = philox_word((uint32_t)i, (uint32_t)p.cb, (uint32_t)nfv, (uint32_t)m,
-                                   (uint32_t)ctl.seed, (uint32_t)(ctl.seed >> 32));
-    const float u = ((float)(w >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
-    return fmaxf(-logf(u), 1e-30f);
+    return exp1_from_word(philox_word((uint32_t)i, (uint32_t)p.cb, (uint32_t)nfv, (uint32_t)m,
+                                      (uint32_t)ctl.seed, (uint32_t)(ctl.seed >> 32)));
+}
+// the four draws of elements 4g .. 4g+3 from one Philox call
+__device__ __forceinline__ void draw_noise4(const SampP& p, const RowCtl& ctl, const float* qrow, int i4, int nfv,
+                                            int m, int V, float (&q)[4]) {
+    if (qrow) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = (i4 + e) < V ? qrow[i4 + e] : 1.f;
+        return;
+    }
+    const Philox4 r = philox4((uint32_t)(i4 >> 2), (uint32_t)p.cb, (uint32_t)nfv, (uint32_t)m,
+                              (uint32_t)ctl.seed, (uint32_t)(ctl.seed >> 32));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q[e] = exp1_from_word(r.w[e]);
 }
 
 template <typename WT, bool ROUND>
@@ -882,9 +913,11 @@ __global__ __launch_bounds__(64) void sample_wave_kernel(SampP p) {
     const int nfv = p.nf[m];
     const int R = p.ncb + 1;
     const int* seq = p.seq + (size_t)m * R * p.cap;
+    // element e of this lane is logit IDX(e): four consecutive logits per lane and 256-block
+#define IDX(e) (256 * ((e) >> 2) + 4 * lane + ((e) & 3))
     float l[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) { const int i = lane + 64 * e; l[e] = i < V ? L[i] : -INFINITY; }
+    for (int e = 0; e < E; ++e) { const int i = IDX(e); l[e] = i < V ? L[i] : -INFINITY; }
     if (nfv > 0) {  // repetition penalty: gather all, then scatter (duplicates write the same value)
         const int it = nfv - 1;
         const int ws = it < 16 ? 0 : it - 16;
@@ -901,25 +934,25 @@ __global__ __launch_bounds__(64) void sample_wave_kernel(SampP p) {
         for (int k = 0; k < npen; ++k) {
             const int idk = __shfl(id, k, 64);
             const float nvk = __shfl(nv, k, 64);
-            if (idk >= 0 && (idk & 63) == lane) {
+            if (idk >= 0 && ((idk & 255) >> 2) == lane) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) if ((idk >> 6) == e) l[e] = nvk;
+                for (int e = 0; e < E; ++e) if (IDX(e) == idk) l[e] = nvk;
             }
         }
     }
-    if (p.cb == 0 && ctl.ban_eos && p.im_end < V && (p.im_end & 63) == lane) {
+    if (p.cb == 0 && ctl.ban_eos && p.im_end < V) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) if ((p.im_end >> 6) == e) l[e] = -INFINITY;
+        for (int e = 0; e < E; ++e) if (IDX(e) == p.im_end) l[e] = -INFINITY;
     }
     ArgMax am{-INFINITY, 0x7fffffff};
 #pragma unroll
-    for (int e = 0; e < E; ++e) { const int i = lane + 64 * e; if (i < V) am = better(am, ArgMax{l[e], i}); }
+    for (int e = 0; e < E; ++e) { const int i = IDX(e); if (i < V) am = better(am, ArgMax{l[e], i}); }
     am = wave_argmax(am);
     const float Lmax = am.v;
     float ex[E];
     float z = 0.f;
 #pragma unroll
-    for (int e = 0; e < E; ++e) { ex[e] = (lane + 64 * e) < V ? expf(l[e] - Lmax) : 0.f; z += ex[e]; }
+    for (int e = 0; e < E; ++e) { ex[e] = IDX(e) < V ? expf(l[e] - Lmax) : 0.f; z += ex[e]; }
     const float Z = wave_sum(z);
     const float tp = rb<ROUND>(ctl.top_p);
     auto removed = [&](float cum) { return rb<ROUND>(cum) > tp; };
@@ -928,8 +961,8 @@ __global__ __launch_bounds__(64) void sample_wave_kernel(SampP p) {
     constexpr uint32_t cmask = ROUND ? 0xffff0000u : 0xffffffffu;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        pr[e] = (lane + 64 * e) < V ? rb<ROUND>(ex[e] / Z) : 0.f;
-        key[e] = (lane + 64 * e) < V ? (order_key(l[e]) & cmask) : 0u;
+        pr[e] = IDX(e) < V ? rb<ROUND>(ex[e] / Z) : 0.f;
+        key[e] = IDX(e) < V ? (order_key(l[e]) & cmask) : 0u;
     }
     uint32_t kstar = 0;
     int nk = 0;
@@ -957,7 +990,7 @@ __global__ __launch_bounds__(64) void sample_wave_kernel(SampP p) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 if (key[e] > kstar) above += pr[e];
-                else if (key[e] == kstar && (lane + 64 * e) < V) { cnt += 1.f; pk = pr[e]; }
+                else if (key[e] == kstar && IDX(e) < V) { cnt += 1.f; pk = pr[e]; }
             }
             above = wave_sum(above);
             const int icnt = (int)wave_sum(cnt);
@@ -974,17 +1007,32 @@ __global__ __launch_bounds__(64) void sample_wave_kernel(SampP p) {
     if (!only_top) {
         const float Tc = fmaxf(ctl.temperature, 1e-5f);
         const float Mt = rb<ROUND>(Lmax / Tc);
-        // members of the cut class are kept in index order: i = lane + 64 e, e-major
+        // members of the cut class are kept in index order: 256-blocks, then lanes, then the 4 sub-indices
         bool keep[E];
         int seen = 0;
+        const unsigned long long lower = (1ull << lane) - 1ull;
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const bool valid = (lane + 64 * e) < V;
-            const bool member = valid && !all_kept && key[e] == kstar;
-            const unsigned long long bal = __ballot(member);
-            const int rank = seen + __popcll(bal & ((1ull << lane) - 1ull));
-            seen += __popcll(bal);
-            keep[e] = valid && (all_kept || key[e] > kstar || (member && rank < nk));
+        for (int g = 0; g < E / 4; ++g) {
+            bool mem[4];
+            unsigned long long bal[4];
+            int below = 0, total = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = 4 * g + u;
+                mem[u] = IDX(e) < V && !all_kept && key[e] == kstar;
+                bal[u] = __ballot(mem[u]);
+                below += __popcll(bal[u] & lower);
+                total += __popcll(bal[u]);
+            }
+            int rank = seen + below;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = 4 * g + u;
+                const bool valid = IDX(e) < V;
+                keep[e] = valid && (all_kept || key[e] > kstar || (mem[u] && rank < nk));
+                rank += mem[u] ? 1 : 0;
+            }
+            seen += total;
         }
         float z2 = 0.f;
         float et[E];
@@ -995,16 +1043,22 @@ __global__ __launch_bounds__(64) void sample_wave_kernel(SampP p) {
         if (p.noise && nfv < p.noise_rows) qrow = p.noise + (size_t)nfv * p.noise_row_len + p.noise_off;
         ArgMax best{-1.f, 0x7fffffff};
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int i = lane + 64 * e;
-            if (i < V) {
-                const float prob = keep[e] ? rb<ROUND>(et[e] / Z2) : 0.f;
-                const float q = rb<ROUND>(draw_noise(p, ctl, qrow, i, nfv, m));
-                best = better(best, ArgMax{rb<ROUND>(prob / q), i});
+        for (int g = 0; g < E / 4; ++g) {
+            float q4[4];
+            draw_noise4(p, ctl, qrow, IDX(4 * g), nfv, m, V, q4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = 4 * g + u;
+                const int i = IDX(e);
+                if (i < V) {
+                    const float prob = keep[e] ? rb<ROUND>(et[e] / Z2) : 0.f;
+                    best = better(best, ArgMax{rb<ROUND>(prob / rb<ROUND>(q4[u])), i});
+                }
             }
         }
         winner = wave_argmax(best).i;
     }
+#undef IDX
     finish_draw<WT>(p, m, winner, nfv);
 }
 
@@ -1029,9 +1083,11 @@ struct SampCut {
     float Lmax, Mt, Z2, Tc;
 };
 
+constexpr size_t SAMP_HIST_STRIDE = 65536 + 1024;
+
 struct SampBigP {
     SampP s;
-    unsigned* hist;      // [M][65536]
+    unsigned* hist;      // [M][65536 + 1024]: class counts, then counts per group of 64 classes
     SampCut* cut;        // [M]
     int* chunk_cnt;      // [M][nchunk]
     float* part_score;   // [M][nchunk]
@@ -1076,11 +1132,27 @@ __global__ __launch_bounds__(256) void samp_hist_kernel(SampBigP b) {
     if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end >= c0 && p.im_end < c0 + 1024 && p.im_end < V)
         L[p.im_end] = -INFINITY;
     __syncthreads();
-    unsigned* hist = b.hist + (size_t)m * 65536;
+    unsigned* hist = b.hist + (size_t)m * SAMP_HIST_STRIDE;
+    unsigned* grp = hist + 65536;
+    const int lane = tid & 63;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int i = c0 + e * 256 + tid;
-        if (i < V) atomicAdd(&hist[order_key(L[i]) >> 16], 1u);
+        const bool valid = i < V;
+        const unsigned k = valid ? order_key(L[i]) >> 16 : 0u;
+        // one atomic per distinct class per wave (peaked or flat logits put many lanes in one class)
+        unsigned long long active = __ballot(valid);
+        while (active) {
+            const int leader = __ffsll((long long)active) - 1;
+            const unsigned kk = (unsigned)__builtin_amdgcn_readlane((int)k, leader);
+            const unsigned long long same = __ballot(valid && k == kk);
+            if (lane == leader) {
+                const unsigned n = (unsigned)__popcll(same);
+                atomicAdd(&hist[kk], n);
+                atomicAdd(&grp[kk >> 6], n);
+            }
+            active &= ~same;
+        }
     }
 }
 
@@ -1104,12 +1176,15 @@ __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
     const SampP& p = b.s;
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RowCtl ctl = p.ctl[m];
-    unsigned* hist = b.hist + (size_t)m * 65536;
+    unsigned* hist = b.hist + (size_t)m * SAMP_HIST_STRIDE;
+    unsigned* grp = hist + 65536;
     if (tid == 0) ovf_n = 0;
     __syncthreads();
     uint32_t* row = cimg + tid * SAMP_TH_ROW;
     int kmax_t = -1;
-    {
+    const bool has = grp[tid] != 0u;  // any logit in my 64 classes?
+    if (has) {
+        grp[tid] = 0u;
         U4* h4 = reinterpret_cast<U4*>(hist + 64 * tid);
 #pragma unroll 4
         for (int v = 0; v < 16; ++v) {
@@ -1146,7 +1221,7 @@ __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
     const unsigned kmax = (unsigned)(int)km.v;
     const float Lmax = key16_value(kmax);
     float z = 0.f;
-    for (int j = 0; j < 64; ++j) {
+    if (has) for (int j = 0; j < 64; ++j) {
         const float c = count_of(j);
         if (c > 0.f) z = fmaf(c, expf(key16_value(64 * tid + j) - Lmax), z);
     }
@@ -1156,7 +1231,7 @@ __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
     auto prob = [&](unsigned k16) { return round_bf16(expf(key16_value(k16) - Lmax) / Z); };
     // mass of this thread's classes, then of everything above them (suffix over threads)
     float mt = 0.f;
-    for (int j = 0; j < 64; ++j) {
+    if (has) for (int j = 0; j < 64; ++j) {
         const float c = count_of(j);
         if (c > 0.f) mt = fmaf(c, prob(64 * tid + j), mt);
     }
@@ -1175,7 +1250,7 @@ __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
     int found = -1;
     float f_above = 0.f, f_cnt = 0.f;
     float run = above;
-    for (int j = 63; j >= 0; --j) {
+    if (has) for (int j = 63; j >= 0; --j) {
         const float c = count_of(j);
         if (c > 0.f) {
             const float nxt = fmaf(c, prob(64 * tid + j), run);
@@ -1204,7 +1279,7 @@ __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
     const float Tc = fmaxf(ctl.temperature, 1e-5f);
     const float Mt = round_bf16(Lmax / Tc);
     float z2 = 0.f;
-    for (int j = 0; j < 64; ++j) {
+    if (has) for (int j = 0; j < 64; ++j) {
         const float c = count_of(j);
         if (c > 0.f) {
             const unsigned k = 64 * tid + j;
@@ -1286,6 +1361,8 @@ __global__ __launch_bounds__(256) void samp_race_kernel(SampBigP b) {
     const float* qrow = nullptr;
     if (p.noise && nfv < p.noise_rows) qrow = p.noise + (size_t)nfv * p.noise_row_len + p.noise_off;
     ArgMax best{-1.f, 0x7fffffff};
+    float q4[4];
+    draw_noise4(p, ctl, qrow, c0 + 4 * tid, nfv, m, V, q4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int i = c0 + 4 * tid + e;
@@ -1293,8 +1370,7 @@ __global__ __launch_bounds__(256) void samp_race_kernel(SampBigP b) {
             bool keep = cut.all_kept || (order_key(l[e]) >> 16) > cut.kstar;
             if (member[e]) { keep = rank < cut.nk; ++rank; }
             const float prob = keep ? round_bf16(expf(round_bf16(l[e] / cut.Tc) - cut.Mt) / cut.Z2) : 0.f;
-            const float q = round_bf16(draw_noise(p, ctl, qrow, i, nfv, m));
-            best = better(best, ArgMax{round_bf16(prob / q), i});
+            best = better(best, ArgMax{round_bf16(prob / round_bf16(q4[e])), i});
         }
     }
     best = wave_argmax(best);

@@ -67,20 +67,45 @@ template <> struct Vec<float> {
     __device__ static __forceinline__ void zero(float (&v)[4]) { v[0] = v[1] = v[2] = v[3] = 0.f; }
 };
 
-// butterfly reductions: every lane ends with the full result, same order on every run
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave reductions on the DPP crossbar (no LDS round trips): four row steps leave every lane of a
+// 16-lane row with the row total, the four row totals are then combined in a fixed order, so every
+// lane ends with the same bits on every run.  All 64 lanes must be active.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+constexpr int DPP_XOR1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <-> 7-i within 8
+constexpr int DPP_MIRROR = 0x140;       // lane i <-> 15-i within 16
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+__device__ __forceinline__ float row16_sum(float v) {  // every lane: sum over its 16-lane row
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    v += dpp_f<DPP_MIRROR>(v);
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return ((lane_f(v, 0) + lane_f(v, 16)) + lane_f(v, 32)) + lane_f(v, 48);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_MIRROR>(v));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
-template <int W> __device__ __forceinline__ float group_sum(float v) {  // W lanes, W power of two <= 64
-#pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// sum over aligned groups of W lanes (W = 2, 4, 8, 16), result in every lane of the group
+__device__ __forceinline__ float group_sum_rt(float v, int W) {
+    v += dpp_f<DPP_XOR1>(v);
+    if (W >= 4) v += dpp_f<DPP_XOR2>(v);
+    if (W >= 8) v += dpp_f<DPP_HALF_MIRROR>(v);
+    if (W >= 16) v += dpp_f<DPP_MIRROR>(v);
     return v;
 }
 

@@ -167,7 +167,7 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     FT_TRY(dmalloc(ctx, &ctx->d_prompt, R * (size_t)c.max_seq_len));
     FT_TRY(dmalloc(ctx, &ctx->d_ctl, M));
     const size_t nchunk = ((size_t)c.vocab_size + 1023) / 1024;
-    FT_TRY(dmalloc(ctx, &ctx->samp_hist, M * 65536));
+    FT_TRY(dmalloc(ctx, &ctx->samp_hist, M * SAMP_HIST_STRIDE));
     FT_TRY(dmalloc(ctx, &ctx->samp_cut, M));
     FT_TRY(dmalloc(ctx, &ctx->samp_chunk_cnt, M * nchunk));
     FT_TRY(dmalloc(ctx, &ctx->samp_part_score, M * nchunk));
@@ -407,7 +407,7 @@ static int rows_per_wave(int N, int M) {
     // enough waves to cover the chip (256 CUs x 4 SIMDs) a few times over; big matrices amortise
     const long waves1 = (long)N * M;
     if (waves1 >= 65536) return 4;
-    if (waves1 >= 4096) return 2;
+    if (waves1 >= 2048) return 2;
     return 1;
 }
 
@@ -443,11 +443,15 @@ static void attn_decode(Launch& L, const AttnP& p) {
         default: L.err = hipErrorInvalidValue;
     }
     L.chk();
-    if (p.nsplit > 1) {
-        attn_combine_kernel<ROUND><<<dim3(p.H, L.M), 128, 0, L.s>>>(p);
-        L.chk();
-    }
     (void)ctx;
+}
+
+template <typename WT, bool ROUND, int R>
+static void gemv_combine_nt(Launch& L, const GemvP& p, const AttnP& a, int nt) {
+    const dim3 grid((p.N + 4 * R - 1) / (4 * R), L.M), block(256);
+#define FT_NT(n) case n: gemv_attn_combine_kernel<WT, n, R, ROUND><<<grid, block, 0, L.s>>>(p, a); break;
+    switch (nt) { FT_NT(1) FT_NT(2) FT_NT(3) FT_NT(4) FT_NT(6) FT_NT(8) FT_NT(12) default: L.err = hipErrorInvalidValue; }
+#undef FT_NT
 }
 
 // One slow-transformer pass over the current input column of rows [m0, m0+M) (llama.py:400-453).
@@ -493,7 +497,22 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
         GemvP o{};
         o.W = l.wo; o.bias = l.bo; o.x = y; o.ldx = c.n_head * c.head_dim; o.out = x; o.ldo = c.dim;
         o.resid = x; o.ldr = c.dim; o.N = c.dim; o.K = c.n_head * c.head_dim; o.pro = PRO_NONE; o.epi = EPI_RESID; o.nt = ctx->nt_weights;
-        gemv<WT, ROUND>(L, o, rows_per_wave(o.N, L.M));
+        if (ctx->nsplit > 1) {  // split-KV partials are merged inside the Wo kernel
+            const int nt = pick_nt(o.K, Vec<WT>::N);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (ctx->prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, L.s); }
+            if (rows_per_wave(o.N, L.M) >= 2) gemv_combine_nt<WT, ROUND, 2>(L, o, a, nt);
+            else gemv_combine_nt<WT, ROUND, 1>(L, o, a, nt);
+            if (ctx->prof) {
+                hipEventRecord(e1, L.s);
+                ctx->prof_ev.push_back(e0); ctx->prof_ev.push_back(e1);
+                ctx->prof_bytes += (int64_t)o.N * o.K * sizeof(WT);
+                ctx->prof_launches += 1;
+            }
+            L.chk();
+        } else {
+            gemv<WT, ROUND>(L, o, rows_per_wave(o.N, L.M));
+        }
 
         GemvP f{};
         f.W = l.w13; f.x = x; f.ldx = c.dim; f.gain = l.ffn_norm; f.eps = c.norm_eps; f.out = g;
@@ -540,7 +559,7 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
     } else if (ROUND && !ctx->force_block_sampler) {
         SampBigP b{};
         b.s = s; b.nchunk = (s.V + 1023) / 1024;
-        b.hist = ctx->samp_hist + (size_t)m0 * 65536; b.cut = ctx->samp_cut + m0;
+        b.hist = ctx->samp_hist + (size_t)m0 * SAMP_HIST_STRIDE; b.cut = ctx->samp_cut + m0;
         b.chunk_cnt = ctx->samp_chunk_cnt + (size_t)m0 * b.nchunk;
         b.part_score = ctx->samp_part_score + (size_t)m0 * b.nchunk;
         b.part_idx = ctx->samp_part_idx + (size_t)m0 * b.nchunk;
