@@ -390,24 +390,37 @@ __global__ __launch_bounds__(256) void gemv_attn_combine_kernel(GemvP p, AttnP a
     const int m = blockIdx.y;
     constexpr int VEC = Vec<WT>::N;
     gemv_rows<WT, NT, R, ROUND>(p, m, row0, lane, [&](int k, float(&v)[VEC]) {
+        constexpr int MAXS = 8;  // nsplit <= 8 (engine enforces)
         const int head = k / a.hd, e = k % a.hd;
         const size_t base = ((size_t)m * a.H + head) * a.nsplit;
-        float M = -INFINITY;
-        for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, a.part_ml[(base + s) * 2]);
-        float L = 0.f, O[VEC];
+        float ms[MAXS], ls[MAXS], O[MAXS][VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) O[j] = 0.f;
-        for (int s = 0; s < a.nsplit; ++s) {
-            const float ms = a.part_ml[(base + s) * 2];
-            if (ms > -INFINITY) {
-                const float w = expf(ms - M);
-                L += a.part_ml[(base + s) * 2 + 1] * w;
+        for (int s = 0; s < MAXS; ++s) {  // all loads first, no data-dependent control flow
+            const bool on = s < a.nsplit;
+            const size_t bi = base + (on ? s : 0);
+            ms[s] = on ? a.part_ml[bi * 2] : -INFINITY;
+            ls[s] = on ? a.part_ml[bi * 2 + 1] : 0.f;
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) O[j] += a.part_o[(base + s) * a.hd + e + j] * w;
+            for (int j = 0; j < VEC; j += 4) {
+                const float4 f = *reinterpret_cast<const float4*>(a.part_o + bi * a.hd + e + j);
+                O[s][j] = f.x; O[s][j + 1] = f.y; O[s][j + 2] = f.z; O[s][j + 3] = f.w;
             }
         }
+        float M = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) v[j] = rb<ROUND>(O[j] / L);
+        for (int s = 0; s < MAXS; ++s) M = fmaxf(M, ms[s]);
+        float L = 0.f, acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const float w = ms[s] > -INFINITY ? expf(ms[s] - M) : 0.f;
+            L += ls[s] * w;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += (s < a.nsplit ? O[s][j] : 0.f) * w;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = rb<ROUND>(acc[j] / L);
     });
 }
 
@@ -548,9 +561,11 @@ __device__ __forceinline__ void fast_attention_to_lds(const FastAttnP& a, const 
         for (int j = 0; j < FAST_MAXCB; ++j) mx = fmaxf(mx, s[j]);
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < FAST_MAXCB; ++j) { s[j] = (j <= c) ? expf(s[j] - mx) : 0.f; sum += s[j]; }
+        for (int j = 0; j < FAST_MAXCB; ++j) {
+            if (j <= c) { s[j] = expf(s[j] - mx); sum += s[j]; } else s[j] = 0.f;
+        }
 #pragma unroll
-        for (int j = 0; j < FAST_MAXCB; ++j) s[j] = rb<ROUND>(s[j] / sum);
+        for (int j = 0; j < FAST_MAXCB; ++j) if (j <= c) s[j] = rb<ROUND>(s[j] / sum);
         if (hv) {
             for (int e = 0; e < EPT; ++e) {
                 const int dd = sub * EPT + e;
@@ -1063,6 +1078,174 @@ __global__ __launch_bounds__(64) void sample_wave_kernel(SampP p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// V <= 1024 with one 256-thread block: 4 consecutive logits per thread in registers, wave
+// reductions on DPP, one barrier per block-wide reduction (partials alternate between two LDS
+// slots).  This is the kernel the nine codebook draws of every frame use.
+// ------------------------------------------------------------------------------------------
+struct Red4 {
+    float* buf;  // [2][4]
+    int phase;
+    __device__ __forceinline__ float sum(float v) {
+        v = wave_sum(v);
+        float* slot = buf + 4 * (phase & 1);
+        ++phase;
+        if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return ((slot[0] + slot[1]) + slot[2]) + slot[3];
+    }
+};
+
+template <typename WT, bool ROUND>
+__global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
+    __shared__ float redbuf[8];
+    __shared__ float amv[4];
+    __shared__ int ami[4];
+    __shared__ int wcnt[4];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* L = p.logits + (size_t)m * p.ldl;
+    const int V = p.V;
+    const RowCtl ctl = p.ctl[m];
+    const int nfv = p.nf[m];
+    const int R = p.ncb + 1;
+    const int* seq = p.seq + (size_t)m * R * p.cap;
+    Red4 red{redbuf, 0};
+    const int i0 = 4 * tid;
+    float l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) l[e] = (i0 + e) < V ? L[i0 + e] : -INFINITY;
+    if (nfv > 0) {  // repetition penalty: every thread scans the (<= 16) ids; values come from HBM (pre-penalty)
+        const int it = nfv - 1;
+        const int ws = it < 16 ? 0 : it - 16;
+        const int npen = p.cb == 0 ? R : 16;
+        for (int k = 0; k < npen; ++k) {
+            const int id = p.cb == 0 ? seq[(size_t)k * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + k];
+            if (id >= i0 && id < i0 + 4 && id < V) {
+                const float sv = L[id];
+                const float nv = sv < 0.f ? rb<ROUND>(sv * ctl.rep) : rb<ROUND>(sv / ctl.rep);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (i0 + e == id) l[e] = nv;
+            }
+        }
+    }
+    if (p.cb == 0 && ctl.ban_eos && p.im_end < V) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (i0 + e == p.im_end) l[e] = -INFINITY;
+    }
+    auto block_best = [&](ArgMax a) {
+        a = wave_argmax(a);
+        __syncthreads();
+        if (lane == 0) { amv[wave] = a.v; ami[wave] = a.i; }
+        __syncthreads();
+        ArgMax t{amv[0], ami[0]};
+        for (int w = 1; w < 4; ++w) t = better(t, ArgMax{amv[w], ami[w]});
+        return t;
+    };
+    ArgMax am{-INFINITY, 0x7fffffff};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (i0 + e < V) am = better(am, ArgMax{l[e], i0 + e});
+    am = block_best(am);
+    const float Lmax = am.v;
+    float ex[4], z = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ex[e] = (i0 + e) < V ? expf(l[e] - Lmax) : 0.f; z += ex[e]; }
+    const float Z = red.sum(z);
+    const float tp = rb<ROUND>(ctl.top_p);
+    auto removed = [&](float cum) { return rb<ROUND>(cum) > tp; };
+    constexpr uint32_t cmask = ROUND ? 0xffff0000u : 0xffffffffu;
+    float pr[4];
+    uint32_t key[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        pr[e] = (i0 + e) < V ? rb<ROUND>(ex[e] / Z) : 0.f;
+        key[e] = (i0 + e) < V ? (order_key(l[e]) & cmask) : 0u;
+    }
+    uint32_t kstar = 0;
+    int nk = 0;
+    bool all_kept = false, only_top = false;
+    if (removed(rb<ROUND>(1.0f / Z))) {
+        only_top = true;
+    } else {
+        const float tot = red.sum((pr[0] + pr[1]) + (pr[2] + pr[3]));
+        if (!removed(tot)) {
+            all_kept = true;
+        } else {
+            constexpr int lowbit = ROUND ? 16 : 0;
+            for (int bit = 31; bit >= lowbit; --bit) {
+                const uint32_t cand = kstar | (1u << bit);
+                float ms = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ms += key[e] >= cand ? pr[e] : 0.f;
+                if (removed(red.sum(ms))) kstar = cand;
+            }
+            float above = 0.f, cnt = 0.f, pk = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (key[e] > kstar) above += pr[e];
+                else if (key[e] == kstar && (i0 + e) < V) { cnt += 1.f; pk = pr[e]; }
+            }
+            above = red.sum(above);
+            const int icnt = (int)red.sum(cnt);
+            const uint32_t ubits = (kstar & 0x80000000u) ? (kstar & 0x7fffffffu) : ~(kstar | ~cmask);
+            pk = rb<ROUND>(expf(__uint_as_float(ubits) - Lmax) / Z);
+            int lo_n = 0, hi_n = icnt;
+            while (lo_n < hi_n) {
+                const int mid = (lo_n + hi_n + 1) >> 1;
+                if (removed(fmaf((float)mid, pk, above))) hi_n = mid - 1; else lo_n = mid;
+            }
+            nk = lo_n;
+        }
+    }
+    int winner = am.i;
+    if (!only_top) {
+        const float Tc = fmaxf(ctl.temperature, 1e-5f);
+        const float Mt = rb<ROUND>(Lmax / Tc);
+        // members of the cut class stay in index order = thread order, then element order
+        bool mem[4];
+        int mine = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mem[e] = (i0 + e) < V && !all_kept && key[e] == kstar; mine += mem[e] ? 1 : 0; }
+        int below = 0, wtot = 0;
+        const unsigned long long lower = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int c = 1; c <= 4; ++c) {  // lanes with >= c members
+            const unsigned long long bal = __ballot(mine >= c);
+            below += __popcll(bal & lower);
+            wtot += __popcll(bal);
+        }
+        __syncthreads();
+        if (lane == 0) wcnt[wave] = wtot;
+        __syncthreads();
+        int rank = below;
+        for (int w = 0; w < wave; ++w) rank += wcnt[w];
+        bool keep[4];
+        float et[4], z2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            keep[e] = (i0 + e) < V && (all_kept || key[e] > kstar || (mem[e] && rank < nk));
+            rank += mem[e] ? 1 : 0;
+            et[e] = keep[e] ? expf(rb<ROUND>(l[e] / Tc) - Mt) : 0.f;
+            z2 += et[e];
+        }
+        const float Z2 = red.sum(z2);
+        const float* qrow = nullptr;
+        if (p.noise && nfv < p.noise_rows) qrow = p.noise + (size_t)nfv * p.noise_row_len + p.noise_off;
+        float q4[4];
+        draw_noise4(p, ctl, qrow, i0, nfv, m, V, q4);
+        ArgMax best{-1.f, 0x7fffffff};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (i0 + e < V) {
+                const float prob = keep[e] ? rb<ROUND>(et[e] / Z2) : 0.f;
+                best = better(best, ArgMax{rb<ROUND>(prob / rb<ROUND>(q4[e])), i0 + e});
+            }
+        }
+        winner = block_best(best).i;
+    }
+    __syncthreads();
+    finish_draw<WT>(p, m, winner, nfv);
+}
+
+// ------------------------------------------------------------------------------------------
 // The same draw for a large vocabulary in bf16 precision, spread over the chip in five short
 // launches (one CU cannot evaluate 155 776 exponentials several times per frame in time):
 //   1 samp_hist      penalty + ban; COUNT histogram over the 65 536 possible bf16 logit values
@@ -1104,6 +1287,7 @@ __device__ __forceinline__ float key16_value(unsigned k16) {
 __global__ __launch_bounds__(256) void samp_hist_kernel(SampBigP b) {
     __shared__ int pen_id[32];
     __shared__ float pen_val[32];
+    __shared__ unsigned grp_s[1024];
     const SampP& p = b.s;
     const int m = blockIdx.y, tid = threadIdx.x;
     const int c0 = blockIdx.x * 1024;
@@ -1135,6 +1319,8 @@ __global__ __launch_bounds__(256) void samp_hist_kernel(SampBigP b) {
     unsigned* hist = b.hist + (size_t)m * SAMP_HIST_STRIDE;
     unsigned* grp = hist + 65536;
     const int lane = tid & 63;
+    for (int i = tid; i < 1024; i += 256) grp_s[i] = 0u;
+    __syncthreads();
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int i = c0 + e * 256 + tid;
@@ -1149,10 +1335,15 @@ __global__ __launch_bounds__(256) void samp_hist_kernel(SampBigP b) {
             if (lane == leader) {
                 const unsigned n = (unsigned)__popcll(same);
                 atomicAdd(&hist[kk], n);
-                atomicAdd(&grp[kk >> 6], n);
+                atomicAdd(&grp_s[kk >> 6], n);  // LDS: one global atomic per touched group per block below
             }
             active &= ~same;
         }
+    }
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+        const unsigned n = grp_s[i];
+        if (n) atomicAdd(&grp[i], n);
     }
 }
 

@@ -73,7 +73,7 @@ struct ft_ctx {
     int* samp_chunk_cnt = nullptr;
     float* samp_part_score = nullptr;
     int* samp_part_idx = nullptr;
-    bool force_block_sampler = false;
+    bool force_block_sampler = false, wave_sampler = false;
     int nt_weights = 1;
 
     std::map<int, hipGraphExec_t> graphs;

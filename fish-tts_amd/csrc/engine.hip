@@ -127,6 +127,7 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     ctx->nsplit = ns ? atoi(ns) : (ctx->n_slots > 512 ? 8 : 1);
     ctx->nt_weights = getenv("FT_NO_NT") ? 0 : 1;
     if (ctx->nsplit < 1) ctx->nsplit = 1;
+    if (ctx->nsplit > 8) ctx->nsplit = 8;
     ctx->cap = c.max_new_tokens + 24;
     ctx->fastV = c.codebook_size < 1024 ? c.codebook_size : 1024;  // inference.py:134
     const size_t qkvN = (size_t)(c.n_head + 2 * c.n_local_heads) * c.head_dim;
@@ -173,6 +174,7 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     FT_TRY(dmalloc(ctx, &ctx->samp_part_score, M * nchunk));
     FT_TRY(dmalloc(ctx, &ctx->samp_part_idx, M * nchunk));
     ctx->force_block_sampler = getenv("FT_SAMPLER_BLOCK") != nullptr;
+    ctx->wave_sampler = getenv("FT_SAMPLER_WAVE") != nullptr;
     FT_HIP(ctx, hipHostMalloc((void**)&ctx->h_pin, (2 * M + 8) * sizeof(int), hipHostMallocDefault));
     return FT_OK;
 }
@@ -555,7 +557,8 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
     s.noise_off = cb == 0 ? 0 : (long)c.vocab_size + (long)(cb - 1) * ctx->fastV;
     s.last = last ? 1 : 0; s.tok = ctx->d_tok + (size_t)m0 * R; s.pos = ctx->d_pos + m0; s.done = ctx->d_done + m0;
     if (s.V <= 1024 && !ctx->force_block_sampler) {
-        sample_wave_kernel<WT, ROUND><<<L.M, 64, 0, L.s>>>(s);
+        if (ctx->wave_sampler) sample_wave_kernel<WT, ROUND><<<L.M, 64, 0, L.s>>>(s);
+        else sample_small_kernel<WT, ROUND><<<L.M, 256, 0, L.s>>>(s);
     } else if (ROUND && !ctx->force_block_sampler) {
         SampBigP b{};
         b.s = s; b.nchunk = (s.V + 1023) / 1024;
