@@ -384,43 +384,46 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
 // separate combine launch; each lane merges only the 8 (4) consecutive elements it multiplies.
 template <typename WT, int NT, int R, bool ROUND>
 __global__ __launch_bounds__(256) void gemv_attn_combine_kernel(GemvP p, AttnP a) {
-    const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
-    if (row0 >= p.N) return;
+    extern __shared__ __attribute__((aligned(16))) float y_s[];  // [H*hd]
+    constexpr int MAXS = 8;  // nsplit <= 8 (engine enforces)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int row0 = (blockIdx.x * 4 + (tid >> 6)) * R;
     const int m = blockIdx.y;
-    constexpr int VEC = Vec<WT>::N;
-    gemv_rows<WT, NT, R, ROUND>(p, m, row0, lane, [&](int k, float(&v)[VEC]) {
-        constexpr int MAXS = 8;  // nsplit <= 8 (engine enforces)
+    U4 raw[R][NT];
+    gemv_issue<WT, NT, R>(p, row0, lane, raw);  // Wo rows stream in while the partials are merged
+    const int K = a.H * a.hd;
+    for (int k = 4 * tid; k < K; k += 1024) {   // 4 consecutive elements of one head per thread
         const int head = k / a.hd, e = k % a.hd;
         const size_t base = ((size_t)m * a.H + head) * a.nsplit;
-        float ms[MAXS], ls[MAXS], O[MAXS][VEC];
+        float ms[MAXS], ls[MAXS];
+        float4 O[MAXS];
 #pragma unroll
-        for (int s = 0; s < MAXS; ++s) {  // all loads first, no data-dependent control flow
+        for (int s = 0; s < MAXS; ++s) {  // every load issued before anything is consumed
             const bool on = s < a.nsplit;
             const size_t bi = base + (on ? s : 0);
             ms[s] = on ? a.part_ml[bi * 2] : -INFINITY;
             ls[s] = on ? a.part_ml[bi * 2 + 1] : 0.f;
-#pragma unroll
-            for (int j = 0; j < VEC; j += 4) {
-                const float4 f = *reinterpret_cast<const float4*>(a.part_o + bi * a.hd + e + j);
-                O[s][j] = f.x; O[s][j + 1] = f.y; O[s][j + 2] = f.z; O[s][j + 3] = f.w;
-            }
+            O[s] = *reinterpret_cast<const float4*>(a.part_o + bi * a.hd + e);
         }
         float M = -INFINITY;
 #pragma unroll
         for (int s = 0; s < MAXS; ++s) M = fmaxf(M, ms[s]);
-        float L = 0.f, acc[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+        float L = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
         for (int s = 0; s < MAXS; ++s) {
             const float w = ms[s] > -INFINITY ? expf(ms[s] - M) : 0.f;
             L += ls[s] * w;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) acc[j] += (s < a.nsplit ? O[s][j] : 0.f) * w;
+            a0 += O[s].x * w; a1 += O[s].y * w; a2 += O[s].z * w; a3 += O[s].w * w;
         }
+        y_s[k] = rb<ROUND>(a0 / L); y_s[k + 1] = rb<ROUND>(a1 / L);
+        y_s[k + 2] = rb<ROUND>(a2 / L); y_s[k + 3] = rb<ROUND>(a3 / L);
+    }
+    __syncthreads();
+    if (row0 >= p.N) return;
+    constexpr int VEC = Vec<WT>::N;
+    gemv_finish<WT, NT, R, ROUND>(p, m, row0, lane, raw, [&](int k, float(&v)[VEC]) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) v[j] = rb<ROUND>(acc[j] / L);
+        for (int j = 0; j < VEC; ++j) v[j] = y_s[k + j];
     });
 }
 
@@ -1098,6 +1101,8 @@ struct Red4 {
 template <typename WT, bool ROUND>
 __global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
     __shared__ float redbuf[8];
+    __shared__ int pen_id[32];
+    __shared__ float pen_val[32];
     __shared__ float amv[4];
     __shared__ int ami[4];
     __shared__ int wcnt[4];
@@ -1113,15 +1118,24 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
     float l[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) l[e] = (i0 + e) < V ? L[i0 + e] : -INFINITY;
-    if (nfv > 0) {  // repetition penalty: every thread scans the (<= 16) ids; values come from HBM (pre-penalty)
+    if (nfv > 0) {  // repetition penalty: lanes fetch the (<= 16) ids and their pre-penalty logits in parallel
         const int it = nfv - 1;
         const int ws = it < 16 ? 0 : it - 16;
         const int npen = p.cb == 0 ? R : 16;
-        for (int k = 0; k < npen; ++k) {
-            const int id = p.cb == 0 ? seq[(size_t)k * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + k];
-            if (id >= i0 && id < i0 + 4 && id < V) {
+        if (tid < npen) {
+            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
+            pen_id[tid] = -1;
+            if (id >= 0 && id < V) {
                 const float sv = L[id];
-                const float nv = sv < 0.f ? rb<ROUND>(sv * ctl.rep) : rb<ROUND>(sv / ctl.rep);
+                pen_id[tid] = id;
+                pen_val[tid] = sv < 0.f ? rb<ROUND>(sv * ctl.rep) : rb<ROUND>(sv / ctl.rep);
+            }
+        }
+        __syncthreads();
+        for (int k = 0; k < npen; ++k) {
+            const int id = pen_id[k];
+            if (id >= i0 && id < i0 + 4) {
+                const float nv = pen_val[k];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (i0 + e == id) l[e] = nv;
             }

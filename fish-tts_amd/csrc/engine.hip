@@ -451,7 +451,7 @@ static void attn_decode(Launch& L, const AttnP& p) {
 template <typename WT, bool ROUND, int R>
 static void gemv_combine_nt(Launch& L, const GemvP& p, const AttnP& a, int nt) {
     const dim3 grid((p.N + 4 * R - 1) / (4 * R), L.M), block(256);
-#define FT_NT(n) case n: gemv_attn_combine_kernel<WT, n, R, ROUND><<<grid, block, 0, L.s>>>(p, a); break;
+#define FT_NT(n) case n: gemv_attn_combine_kernel<WT, n, R, ROUND><<<grid, block, (size_t)a.H * a.hd * sizeof(float), L.s>>>(p, a); break;
     switch (nt) { FT_NT(1) FT_NT(2) FT_NT(3) FT_NT(4) FT_NT(6) FT_NT(8) FT_NT(12) default: L.err = hipErrorInvalidValue; }
 #undef FT_NT
 }
