@@ -1,11 +1,387 @@
-// DAC codec decode path (placeholder until the kernels land in this file).
+// DAC codec decode (DAC.decode, vocoder.py:906-912) on the tap-GEMM kernels of codec_kernels.h.
+#include <string.h>
+
+#include <mutex>
+
+#include "codec_kernels.h"
 #include "engine.h"
 
-ft_status codec_create(ft_ctx* ctx) { return ft_fail(ctx, FT_ERR_UNSUPPORTED, "codec path not built yet"); }
-void codec_destroy(ft_ctx*) {}
-void codec_expected(ft_ctx*) {}
-ft_status codec_finalize(ft_ctx*) { return FT_OK; }
-extern "C" ft_status ft_codec_decode(ft_ctx* ctx, const int32_t*, int32_t, int32_t, const int32_t*, float*) {
-    return ft_fail(ctx, FT_ERR_UNSUPPORTED, "codec path not built yet");
+using namespace ft;
+
+#define FT_TRY(x) do { ft_status s_ = (x); if (s_ != FT_OK) return s_; } while (0)
+
+struct ConvW {            // one packed tap-GEMM weight
+    bf16_t* w = nullptr;  // [ntap][N][K]
+    float* bias = nullptr;
+    int ntap = 1, N = 0, K = 0, n_mod = 0;
+    int offs[8] = {0};
+};
+struct TfLayer { ConvW qkv, wo, w13, w2; float *n1, *n2, *g1, *g2; };
+struct UpStage { ConvW ct; float *dw_w, *dw_b, *ln_w, *ln_b, *gamma; ConvW pw1, pw2; int f; };
+struct ResUnitW { float *a0, *a2; ConvW c7, c1; };
+struct DecBlock { float* a0; ConvW ct; ResUnitW u[3]; int s, cin, cout; };
+
+struct CodecState {
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    float* tables = nullptr;  // RVQ tables
+    float* rope = nullptr;
+    std::vector<TfLayer> tf;
+    float* tf_norm = nullptr;
+    std::vector<UpStage> up;
+    ConvW conv_in;
+    std::vector<DecBlock> blocks;
+    float* a_last = nullptr;
+    float* w_last = nullptr;  // [7][C]
+    float b_last = 0.f;
+    int c_last = 0;
+    std::vector<void*> owned;
+    // activations (one batch item at a time)
+    int* codes = nullptr;
+    float *x = nullptr, *audio = nullptr;
+    bf16_t *xn = nullptr, *qkv = nullptr, *y = nullptr, *g = nullptr;
+    bf16_t* big[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t big_elems = 0;
+    int frame_len = 0, up_total = 1;
+};
+
+static std::string cname(const char* fmt, int a = 0, int b = 0) {
+    char buf[160];
+    snprintf(buf, sizeof buf, fmt, a, b);
+    return buf;
 }
-extern "C" int32_t ft_codec_frame_len(const ft_ctx*) { return 2048; }
+
+void codec_expected(ft_ctx* ctx) {
+    const ft_codec_config& c = ctx->cc;
+    const int D = c.latent_dim, H = c.tf_n_head * c.tf_head_dim;
+    auto E = [&](const std::string& n, std::vector<int64_t> s) { ft_expect(ctx, n, std::move(s), FT_F32); };
+    E("quantizer.semantic_quantizer.quantizers.0.codebook.weight", {c.semantic_codebook_size, c.codebook_dim});
+    E("quantizer.semantic_quantizer.quantizers.0.out_proj.weight", {D, c.codebook_dim, 1});
+    E("quantizer.semantic_quantizer.quantizers.0.out_proj.bias", {D});
+    for (int i = 0; i < c.n_codebooks; ++i) {
+        E(cname("quantizer.quantizer.quantizers.%d.codebook.weight", i), {c.codebook_size, c.codebook_dim});
+        E(cname("quantizer.quantizer.quantizers.%d.out_proj.weight", i), {D, c.codebook_dim, 1});
+        E(cname("quantizer.quantizer.quantizers.%d.out_proj.bias", i), {D});
+    }
+    for (int l = 0; l < c.n_tf_layer; ++l) {
+        const std::string p = cname("quantizer.post_module.layers.%d", l);
+        E(p + ".attention.wqkv.weight", {3 * H, D});
+        E(p + ".attention.wo.weight", {D, H});
+        E(p + ".feed_forward.w1.weight", {c.tf_ffn, D});
+        E(p + ".feed_forward.w3.weight", {c.tf_ffn, D});
+        E(p + ".feed_forward.w2.weight", {D, c.tf_ffn});
+        E(p + ".ffn_norm.weight", {D});
+        E(p + ".attention_norm.weight", {D});
+        E(p + ".attention_layer_scale.gamma", {D});
+        E(p + ".ffn_layer_scale.gamma", {D});
+    }
+    E("quantizer.post_module.norm.weight", {D});
+    for (int j = 0; j < c.n_upsample; ++j) {
+        const std::string p = cname("quantizer.upsample.%d", j);
+        E(p + ".0.conv.weight", {D, D, 2});
+        E(p + ".0.conv.bias", {D});
+        E(p + ".1.dwconv.conv.weight", {D, 1, 7});
+        E(p + ".1.dwconv.conv.bias", {D});
+        E(p + ".1.norm.weight", {D});
+        E(p + ".1.norm.bias", {D});
+        E(p + ".1.pwconv1.weight", {4 * D, D});
+        E(p + ".1.pwconv1.bias", {4 * D});
+        E(p + ".1.pwconv2.weight", {D, 4 * D});
+        E(p + ".1.pwconv2.bias", {D});
+        E(p + ".1.gamma", {D});
+    }
+    E("decoder.model.0.conv.weight", {c.decoder_dim, D, 7});
+    E("decoder.model.0.conv.bias", {c.decoder_dim});
+    for (int i = 0; i < c.n_rates; ++i) {
+        const int cin = c.decoder_dim >> i, cout = c.decoder_dim >> (i + 1), r = c.rates[i];
+        const std::string p = cname("decoder.model.%d.block", i + 1);
+        E(p + ".0.alpha", {1, cin, 1});
+        E(p + ".1.conv.weight", {cin, cout, 2 * r});
+        E(p + ".1.conv.bias", {cout});
+        for (int u = 0; u < 3; ++u) {
+            const std::string q = p + cname(".%d.block", u + 2);
+            E(q + ".0.alpha", {1, cout, 1});
+            E(q + ".1.conv.weight", {cout, cout, 7});
+            E(q + ".1.conv.bias", {cout});
+            E(q + ".2.alpha", {1, cout, 1});
+            E(q + ".3.conv.weight", {cout, cout, 1});
+            E(q + ".3.conv.bias", {cout});
+        }
+    }
+    const int last = c.decoder_dim >> c.n_rates;
+    E(cname("decoder.model.%d.alpha", c.n_rates + 1), {1, last, 1});
+    E(cname("decoder.model.%d.conv.weight", c.n_rates + 2), {1, last, 7});
+    E(cname("decoder.model.%d.conv.bias", c.n_rates + 2), {1});
+    ft_expect(ctx, "rope.codec", {c.max_frames, c.tf_head_dim / 2, 2}, FT_F32);
+}
+
+ft_status codec_create(ft_ctx* ctx) {
+    const ft_codec_config& c = ctx->cc;
+    auto bad = [&](const char* m) { return ft_fail(ctx, FT_ERR_UNSUPPORTED, m); };
+    if (c.dtype != FT_BF16) return bad("codec: only FT_BF16 contractions (f32 accumulate) are implemented");
+    if (c.n_upsample < 0 || c.n_upsample > 4 || c.n_rates < 1 || c.n_rates > 8) return bad("codec: bad stage counts");
+    if (c.latent_dim % 32 || (c.tf_n_head * c.tf_head_dim) % 32 || c.tf_ffn % 32 || c.decoder_dim % 32)
+        return bad("codec: channel counts must be multiples of 32");
+    if ((c.decoder_dim >> c.n_rates) % 32) return bad("codec: decoder_dim / 2^n_rates must be a multiple of 32");
+    if (c.tf_head_dim > 128 || c.tf_head_dim % 8 || c.tf_window > 256) return bad("codec: head_dim <= 128, window <= 256");
+    if (c.max_frames < 1 || c.max_batch < 1) return bad("codec: max_frames / max_batch");
+    CodecState* s = new CodecState();
+    ctx->codec = s;
+    FT_HIP(ctx, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    s->up_total = 1 << c.n_upsample;
+    s->frame_len = s->up_total;
+    for (int i = 0; i < c.n_rates; ++i) s->frame_len *= c.rates[i];
+    return FT_OK;
+}
+
+void codec_destroy(ft_ctx* ctx) {
+    CodecState* s = ctx->codec;
+    if (!s) return;
+    if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+    for (void* p : s->owned) hipFree(p);
+    delete s;
+    ctx->codec = nullptr;
+}
+
+template <typename T>
+static ft_status cmalloc(ft_ctx* ctx, T** p, size_t n) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, n * sizeof(T) + 64);
+    if (e != hipSuccess) return ft_fail(ctx, FT_ERR_NOMEM, std::string("codec hipMalloc: ") + hipGetErrorString(e));
+    ctx->codec->owned.push_back(q);
+    *p = (T*)q;
+    return FT_OK;
+}
+static float* W32(ft_ctx* ctx, const std::string& n) { return (float*)ctx->expected[n].p; }
+static int gridfor(long n) { long b = (n + 255) / 256; return (int)(b < 4096 ? b : 4096); }
+
+static ft_status pack_linear(ft_ctx* ctx, ConvW& cw, const std::string& wname, const std::string& bname, int N, int K) {
+    CodecState* s = ctx->codec;
+    FT_TRY(cmalloc(ctx, &cw.w, (size_t)N * K));
+    pack_rows_kernel<<<gridfor((long)N * K), 256, 0, s->stream>>>(W32(ctx, wname), cw.w, (long)N * K);
+    cw.bias = bname.empty() ? nullptr : W32(ctx, bname);
+    cw.ntap = 1; cw.N = N; cw.K = K; cw.n_mod = N; cw.offs[0] = 0;
+    return FT_OK;
+}
+static ft_status pack_conv(ft_ctx* ctx, ConvW& cw, const std::string& pfx, int Cout, int Cin, int k, int dil) {
+    CodecState* s = ctx->codec;
+    FT_TRY(cmalloc(ctx, &cw.w, (size_t)Cout * Cin * k));
+    pack_conv_kernel<<<gridfor((long)Cout * Cin * k), 256, 0, s->stream>>>(W32(ctx, pfx + ".weight"), cw.w, Cout, Cin, k);
+    cw.bias = W32(ctx, pfx + ".bias");
+    cw.ntap = k; cw.N = Cout; cw.K = Cin; cw.n_mod = Cout;
+    for (int kk = 0; kk < k; ++kk) cw.offs[kk] = (kk - (k - 1)) * dil;
+    return FT_OK;
+}
+static ft_status pack_convT(ft_ctx* ctx, ConvW& cw, const std::string& pfx, int Cin, int Cout, int k, int stride) {
+    CodecState* s = ctx->codec;
+    FT_TRY(cmalloc(ctx, &cw.w, (size_t)Cin * Cout * k));
+    pack_convT_kernel<<<gridfor((long)Cin * Cout * k), 256, 0, s->stream>>>(W32(ctx, pfx + ".weight"), cw.w, Cin, Cout, k, stride);
+    cw.bias = W32(ctx, pfx + ".bias");
+    cw.ntap = k / stride; cw.N = stride * Cout; cw.K = Cin; cw.n_mod = Cout;
+    for (int j = 0; j < cw.ntap; ++j) cw.offs[j] = -j;
+    return FT_OK;
+}
+
+ft_status codec_finalize(ft_ctx* ctx) {
+    const ft_codec_config& c = ctx->cc;
+    CodecState* s = ctx->codec;
+    const int D = c.latent_dim, H = c.tf_n_head * c.tf_head_dim;
+    // RVQ tables: out_proj folded into the codebooks (vocoder.py:809-810 + dac from_codes)
+    FT_TRY(cmalloc(ctx, &s->tables, ((size_t)c.semantic_codebook_size + (size_t)c.n_codebooks * c.codebook_size) * D));
+    {
+        const std::string p = "quantizer.semantic_quantizer.quantizers.0";
+        rvq_table_kernel<<<gridfor((long)c.semantic_codebook_size * D), 256, 0, s->stream>>>(
+            W32(ctx, p + ".codebook.weight"), W32(ctx, p + ".out_proj.weight"), W32(ctx, p + ".out_proj.bias"),
+            s->tables, c.semantic_codebook_size, D, c.codebook_dim);
+        for (int i = 0; i < c.n_codebooks; ++i) {
+            const std::string q = cname("quantizer.quantizer.quantizers.%d", i);
+            rvq_table_kernel<<<gridfor((long)c.codebook_size * D), 256, 0, s->stream>>>(
+                W32(ctx, q + ".codebook.weight"), W32(ctx, q + ".out_proj.weight"), W32(ctx, q + ".out_proj.bias"),
+                s->tables + ((size_t)c.semantic_codebook_size + (size_t)i * c.codebook_size) * D, c.codebook_size, D,
+                c.codebook_dim);
+        }
+    }
+    s->rope = W32(ctx, "rope.codec");
+    s->tf.resize(c.n_tf_layer);
+    for (int l = 0; l < c.n_tf_layer; ++l) {
+        const std::string p = cname("quantizer.post_module.layers.%d", l);
+        TfLayer& t = s->tf[l];
+        FT_TRY(pack_linear(ctx, t.qkv, p + ".attention.wqkv.weight", "", 3 * H, D));
+        FT_TRY(pack_linear(ctx, t.wo, p + ".attention.wo.weight", "", D, H));
+        FT_TRY(pack_linear(ctx, t.w2, p + ".feed_forward.w2.weight", "", D, c.tf_ffn));
+        FT_TRY(cmalloc(ctx, &t.w13.w, (size_t)2 * c.tf_ffn * D));
+        pack_interleave_kernel<<<gridfor((long)c.tf_ffn * D), 256, 0, s->stream>>>(
+            W32(ctx, p + ".feed_forward.w1.weight"), W32(ctx, p + ".feed_forward.w3.weight"), t.w13.w, c.tf_ffn, D);
+        t.w13.ntap = 1; t.w13.N = 2 * c.tf_ffn; t.w13.K = D; t.w13.n_mod = 2 * c.tf_ffn; t.w13.bias = nullptr;
+        t.n1 = W32(ctx, p + ".attention_norm.weight"); t.n2 = W32(ctx, p + ".ffn_norm.weight");
+        t.g1 = W32(ctx, p + ".attention_layer_scale.gamma"); t.g2 = W32(ctx, p + ".ffn_layer_scale.gamma");
+    }
+    s->tf_norm = W32(ctx, "quantizer.post_module.norm.weight");
+    s->up.resize(c.n_upsample);
+    for (int j = 0; j < c.n_upsample; ++j) {
+        const std::string p = cname("quantizer.upsample.%d", j);
+        UpStage& u = s->up[j];
+        u.f = 2;
+        FT_TRY(pack_convT(ctx, u.ct, p + ".0.conv", D, D, 2, 2));
+        u.dw_w = W32(ctx, p + ".1.dwconv.conv.weight"); u.dw_b = W32(ctx, p + ".1.dwconv.conv.bias");
+        u.ln_w = W32(ctx, p + ".1.norm.weight"); u.ln_b = W32(ctx, p + ".1.norm.bias");
+        u.gamma = W32(ctx, p + ".1.gamma");
+        FT_TRY(pack_linear(ctx, u.pw1, p + ".1.pwconv1.weight", p + ".1.pwconv1.bias", 4 * D, D));
+        FT_TRY(pack_linear(ctx, u.pw2, p + ".1.pwconv2.weight", p + ".1.pwconv2.bias", D, 4 * D));
+    }
+    FT_TRY(pack_conv(ctx, s->conv_in, "decoder.model.0.conv", c.decoder_dim, D, 7, 1));
+    s->blocks.resize(c.n_rates);
+    size_t per_frame_max = (size_t)s->up_total * c.decoder_dim;  // conv_in output
+    size_t tmul = s->up_total;
+    for (int i = 0; i < c.n_rates; ++i) {
+        DecBlock& b = s->blocks[i];
+        b.cin = c.decoder_dim >> i; b.cout = c.decoder_dim >> (i + 1); b.s = c.rates[i];
+        const std::string p = cname("decoder.model.%d.block", i + 1);
+        b.a0 = W32(ctx, p + ".0.alpha");
+        FT_TRY(pack_convT(ctx, b.ct, p + ".1.conv", b.cin, b.cout, 2 * b.s, b.s));
+        const int dil[3] = {1, 3, 9};
+        for (int u = 0; u < 3; ++u) {
+            const std::string q = p + cname(".%d.block", u + 2);
+            b.u[u].a0 = W32(ctx, q + ".0.alpha"); b.u[u].a2 = W32(ctx, q + ".2.alpha");
+            FT_TRY(pack_conv(ctx, b.u[u].c7, q + ".1.conv", b.cout, b.cout, 7, dil[u]));
+            FT_TRY(pack_conv(ctx, b.u[u].c1, q + ".3.conv", b.cout, b.cout, 1, 1));
+        }
+        tmul *= b.s;
+        per_frame_max = std::max(per_frame_max, tmul * b.cout);
+    }
+    s->c_last = c.decoder_dim >> c.n_rates;
+    s->a_last = W32(ctx, cname("decoder.model.%d.alpha", c.n_rates + 1));
+    {   // [1][C][7] -> [7][C]
+        const float* w = W32(ctx, cname("decoder.model.%d.conv.weight", c.n_rates + 2));
+        std::vector<float> h((size_t)s->c_last * 7), o((size_t)s->c_last * 7);
+        FT_HIP(ctx, hipMemcpy(h.data(), w, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int ci = 0; ci < s->c_last; ++ci) for (int k = 0; k < 7; ++k) o[(size_t)k * s->c_last + ci] = h[(size_t)ci * 7 + k];
+        FT_TRY(cmalloc(ctx, &s->w_last, o.size()));
+        FT_HIP(ctx, hipMemcpy(s->w_last, o.data(), o.size() * sizeof(float), hipMemcpyHostToDevice));
+        FT_HIP(ctx, hipMemcpy(&s->b_last, W32(ctx, cname("decoder.model.%d.conv.bias", c.n_rates + 2)), sizeof(float), hipMemcpyDeviceToHost));
+    }
+    // activation buffers for one utterance of max_frames
+    const size_t T = c.max_frames;
+    per_frame_max = std::max(per_frame_max, (size_t)s->up_total * 4 * D);  // ConvNeXt hidden
+    s->big_elems = T * per_frame_max;
+    for (int i = 0; i < 4; ++i) FT_TRY(cmalloc(ctx, &s->big[i], s->big_elems));
+    FT_TRY(cmalloc(ctx, &s->codes, (size_t)(c.n_codebooks + 1) * T));
+    FT_TRY(cmalloc(ctx, &s->x, T * D));
+    FT_TRY(cmalloc(ctx, &s->xn, T * D));
+    FT_TRY(cmalloc(ctx, &s->qkv, T * 3 * H));
+    FT_TRY(cmalloc(ctx, &s->y, T * H));
+    FT_TRY(cmalloc(ctx, &s->g, T * c.tf_ffn));
+    FT_TRY(cmalloc(ctx, &s->audio, T * s->frame_len));
+    FT_HIP(ctx, hipStreamSynchronize(s->stream));
+    return FT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ launch
+struct GemmIO {
+    const bf16_t* X; long ldx; int T_in; int M;
+    const float* gamma = nullptr; const float* resid_f32 = nullptr; const bf16_t* resid_bf = nullptr; long ldr = 0;
+    float* out_f32 = nullptr; bf16_t* out_bf = nullptr; bf16_t* out_act = nullptr; const float* alpha = nullptr;
+    long ldo = 0; int act = ACT_NONE;
+};
+
+static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
+    TapGemmP p{};
+    p.X = io.X; p.ldx = io.ldx; p.x_bstride = 0; p.T_in = io.T_in; p.W = w.w; p.ntap = w.ntap;
+    for (int i = 0; i < w.ntap; ++i) p.offs[i] = w.offs[i];
+    p.M = io.M; p.N = w.N; p.K = w.K; p.bias = w.bias; p.n_mod = w.n_mod; p.act = io.act; p.gamma = io.gamma;
+    p.resid_f32 = io.resid_f32; p.resid_bf = io.resid_bf; p.ldr = io.ldr; p.out_f32 = io.out_f32; p.out_bf = io.out_bf;
+    p.out_act = io.out_act; p.alpha = io.alpha; p.ldo = io.ldo;
+    if (w.N >= 128) {
+        const dim3 grid((io.M + 127) / 128, (w.N + 127) / 128, 1);
+        tapgemm_kernel<128, 128, 2, 2><<<grid, 256, 0, st>>>(p);
+    } else {
+        const dim3 grid((io.M + 127) / 128, (w.N + 63) / 64, 1);
+        tapgemm_kernel<128, 64, 4, 1><<<grid, 256, 0, st>>>(p);
+    }
+}
+
+static ft_status decode_one(ft_ctx* ctx, const int32_t* codes_host, int Tfull, int T, float* audio_host) {
+    const ft_codec_config& c = ctx->cc;
+    CodecState* s = ctx->codec;
+    hipStream_t st = s->stream;
+    const int D = c.latent_dim, H = c.tf_n_head, hd = c.tf_head_dim, HD = H * hd, R = c.n_codebooks + 1;
+    // codes of this item, compacted to [R][T]
+    std::vector<int> hc((size_t)R * T);
+    for (int r = 0; r < R; ++r) memcpy(&hc[(size_t)r * T], codes_host + (size_t)r * Tfull, T * sizeof(int));
+    FT_HIP(ctx, hipMemcpyAsync(s->codes, hc.data(), hc.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    RvqP rq{s->codes, s->tables, c.n_codebooks, c.semantic_codebook_size, c.codebook_size, D, T, s->x};
+    rvq_gather_kernel<<<dim3(T, 1), 256, 0, st>>>(rq);
+    // post transformer (vocoder.py:338-354): residual stream f32, GEMM operands bf16
+    for (int l = 0; l < c.n_tf_layer; ++l) {
+        const TfLayer& t = s->tf[l];
+        rmsnorm_rows_kernel<<<T, 256, 0, st>>>(RowNormP{s->x, t.n1, c.tf_norm_eps, D, s->xn, nullptr});
+        { GemmIO io{s->xn, D, T, T}; io.out_bf = s->qkv; io.ldo = 3 * HD; gemm(st, t.qkv, io); }
+        rope_qk_kernel<<<gridfor((long)T * 2 * H * (hd / 2)), 256, 0, st>>>(s->qkv, s->rope, T, H, hd);
+        window_attn_kernel<<<(T * H + 3) / 4, 256, 0, st>>>(WinAttnP{s->qkv, s->y, T, H, hd, c.tf_window, 1.0f / sqrtf((float)hd)});
+        { GemmIO io{s->y, HD, T, T}; io.gamma = t.g1; io.resid_f32 = s->x; io.ldr = D; io.out_f32 = s->x; io.ldo = D; gemm(st, t.wo, io); }
+        rmsnorm_rows_kernel<<<T, 256, 0, st>>>(RowNormP{s->x, t.n2, c.tf_norm_eps, D, s->xn, nullptr});
+        { GemmIO io{s->xn, D, T, T}; io.act = ACT_SWIGLU; io.out_bf = s->g; io.ldo = c.tf_ffn; gemm(st, t.w13, io); }
+        { GemmIO io{s->g, c.tf_ffn, T, T}; io.gamma = t.g2; io.resid_f32 = s->x; io.ldr = D; io.out_f32 = s->x; io.ldo = D; gemm(st, t.w2, io); }
+    }
+    bf16_t *z = s->big[0], *u = s->big[1], *n = s->big[2], *h = s->big[3];
+    rmsnorm_rows_kernel<<<T, 256, 0, st>>>(RowNormP{s->x, s->tf_norm, c.tf_norm_eps, D, z, nullptr});
+    int Tc = T;
+    for (const UpStage& us : s->up) {  // vocoder.py:737-748: convT k=s=2, then ConvNeXt
+        { GemmIO io{z, D, Tc, Tc}; io.out_bf = u; io.ldo = us.ct.N; gemm(st, us.ct, io); }
+        Tc *= us.f;
+        dwconv_ln_kernel<<<Tc, 256, D * sizeof(float), st>>>(DwLnP{u, us.dw_w, us.dw_b, us.ln_w, us.ln_b, Tc, D, n});
+        { GemmIO io{n, D, Tc, Tc}; io.act = ACT_GELU; io.out_bf = h; io.ldo = 4 * D; gemm(st, us.pw1, io); }
+        { GemmIO io{h, 4 * D, Tc, Tc}; io.gamma = us.gamma; io.resid_bf = u; io.ldr = D; io.out_bf = z; io.ldo = D; gemm(st, us.pw2, io); }
+    }
+    // decoder (vocoder.py:605-640).  Buffers: a = snake'd input of the next conv, r = raw residual
+    bf16_t *a = u, *r = n, *hs = h, *a2 = z;
+    { GemmIO io{z, D, Tc, Tc}; io.out_act = a; io.alpha = s->blocks[0].a0; io.ldo = c.decoder_dim; gemm(st, s->conv_in, io); }
+    // note: conv_in reads z and writes a (= big[1]); z (= big[0]) is free afterwards
+    for (size_t bi = 0; bi < s->blocks.size(); ++bi) {
+        const DecBlock& b = s->blocks[bi];
+        // transposed conv: raw -> r, snake'd by unit 0 -> a2
+        { GemmIO io{a, b.cin, Tc, Tc}; io.out_bf = r; io.out_act = a2; io.alpha = b.u[0].a0; io.ldo = b.ct.N; gemm(st, b.ct, io); }
+        Tc *= b.s;
+        for (int ui = 0; ui < 3; ++ui) {
+            const ResUnitW& ru = b.u[ui];
+            { GemmIO io{a2, b.cout, Tc, Tc}; io.out_act = hs; io.alpha = ru.a2; io.ldo = b.cout; gemm(st, ru.c7, io); }
+            const float* next_alpha = ui < 2 ? b.u[ui + 1].a0 : (bi + 1 < s->blocks.size() ? s->blocks[bi + 1].a0 : s->a_last);
+            bf16_t* act_dst = ui < 2 ? a2 : a;  // the last unit feeds the next block's transposed conv / the output conv
+            { GemmIO io{hs, b.cout, Tc, Tc}; io.resid_bf = r; io.ldr = b.cout; io.out_bf = ui < 2 ? r : nullptr;
+              io.out_act = act_dst; io.alpha = next_alpha; io.ldo = b.cout; gemm(st, ru.c1, io); }
+        }
+    }
+    FinalConvP fp{a, s->w_last, s->b_last, Tc, s->c_last, s->audio};
+    final_conv_tanh_kernel<<<2048, 256, 0, st>>>(fp);
+    FT_HIP(ctx, hipMemcpyAsync(audio_host, s->audio, (size_t)Tc * sizeof(float), hipMemcpyDeviceToHost, st));
+    FT_HIP(ctx, hipStreamSynchronize(st));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("codec launch: ") + hipGetErrorString(e));
+    return FT_OK;
+}
+
+extern "C" ft_status ft_codec_decode(ft_ctx* ctx, const int32_t* codes, int32_t B, int32_t T, const int32_t* lens,
+                                     float* audio) {
+    if (!ctx) return FT_ERR_ARG;
+    if (!ctx->has_codec || !ctx->codec) return ft_fail(ctx, FT_ERR_STATE, "Vocoder not loaded");
+    if (!ctx->finalized) return ft_fail(ctx, FT_ERR_STATE, "weights not finalized (ft_finalize_weights)");
+    if (!codes || !audio || B < 1 || T < 1) return ft_fail(ctx, FT_ERR_ARG, "ft_codec_decode: bad argument");
+    const ft_codec_config& c = ctx->cc;
+    if (T > c.max_frames) return ft_fail(ctx, FT_ERR_TOO_LONG, "ft_codec_decode: T exceeds max_frames");
+    CodecState* s = ctx->codec;
+    std::lock_guard<std::mutex> lock(s->mu);
+    FT_HIP(ctx, hipSetDevice(ctx->device));
+    const int R = c.n_codebooks + 1;
+    const size_t alen = (size_t)T * s->frame_len;
+    for (int b = 0; b < B; ++b) {
+        int Tb = lens ? lens[b] : T;
+        if (Tb < 0 || Tb > T) return ft_fail(ctx, FT_ERR_ARG, "ft_codec_decode: bad length");
+        float* out = audio + (size_t)b * alen;
+        if ((size_t)Tb * s->frame_len < alen) memset(out + (size_t)Tb * s->frame_len, 0, (alen - (size_t)Tb * s->frame_len) * sizeof(float));
+        if (Tb == 0) continue;
+        FT_TRY(decode_one(ctx, codes + (size_t)b * R * T, T, Tb, out));
+    }
+    return FT_OK;
+}
+
+extern "C" int32_t ft_codec_frame_len(const ft_ctx* ctx) { return ctx && ctx->codec ? ctx->codec->frame_len : 0; }

@@ -1,0 +1,372 @@
+// DAC codec decode kernels for gfx950.  Activations are time-major [T][C] bf16 in HBM (the
+// transformer's residual stream is f32); every convolution / linear layer is one "tap GEMM":
+//     Y[t][n] = sum_tap sum_c X[t + off_tap][c] * W[tap][n][c]          (rows t + off < 0 read as 0)
+// on bf16 MFMA (v_mfma_f32_16x16x32_bf16, f32 accumulate) with fused epilogues:
+//   * Conv1d k=7 dilation d (vocoder.py:394-421): 7 taps, off = (kk-6)*d
+//   * ConvTranspose1d k=2s stride s, right-trimmed (vocoder.py:432-455): N = s*Cout, 2 taps (0, -1),
+//     the [T][s][Cout] result IS the [T*s][Cout] output
+//   * Linear / 1x1 conv: one tap
+// Snake (x + sin^2(ax)/a) is applied once per element in the producer's epilogue, never per tap.
+#pragma once
+#include "common.h"
+
+namespace ft {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SWIGLU = 2, ACT_TANH = 3 };
+
+struct TapGemmP {
+    const bf16_t* X;      // [B][T_in][ldx]
+    long ldx, x_bstride;
+    int T_in;
+    const bf16_t* W;      // [ntap][N][K]
+    int ntap;
+    int offs[8];
+    int M, N, K;          // output rows per batch item, output columns, contraction per tap
+    const float* bias;    // [n_mod] or null
+    int n_mod;            // bias/alpha/gamma index = n % n_mod
+    int act;
+    const float* gamma;   // per-column scale (LayerScale / ConvNeXt gamma) or null
+    const float* resid_f32;
+    const bf16_t* resid_bf;
+    long ldr, r_bstride;
+    float* out_f32;
+    bf16_t* out_bf;
+    bf16_t* out_act;      // snake(v, alpha) or null
+    const float* alpha;
+    long ldo, o_bstride;
+};
+
+__device__ __forceinline__ float snake_f(float v, float a) {
+    const float s = sinf(a * v);
+    return v + (1.0f / (a + 1e-9f)) * (s * s);
+}
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+
+// Block tile BM x BN, BK = 32, 256 threads = 4 waves arranged WGM x WGN; each wave owns
+// (BM/WGM) x (BN/WGN) as 16x16 MFMA tiles.  LDS rows are padded to 40 bf16 (80 B) so the 16-byte
+// fragment reads of 16 consecutive rows spread over the banks.
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmP p) {
+    constexpr int BK = 32, LDS_LD = 40;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    __shared__ __attribute__((aligned(16))) bf16_t As[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[BN * LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
+    const bf16_t* X = p.X + (size_t)b * p.x_bstride;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int tap = 0; tap < p.ntap; ++tap) {
+        const int off = p.offs[tap];
+        const bf16_t* Wt = p.W + (size_t)tap * p.N * p.K;
+        for (int k0 = 0; k0 < p.K; k0 += BK) {
+            // stage A (BM x 32) and B (BN x 32): 16-byte chunks, 4 per row
+            for (int c = tid; c < BM * 4; c += 256) {
+                const int r = c >> 2, q = c & 3;
+                const int t = m0 + r + off;
+                U4 v = U4{0u, 0u, 0u, 0u};
+                if (m0 + r < p.M && t >= 0 && t < p.T_in)
+                    v = *reinterpret_cast<const U4*>(X + (size_t)t * p.ldx + k0 + q * 8);
+                *reinterpret_cast<U4*>(&As[r * LDS_LD + q * 8]) = v;
+            }
+            for (int c = tid; c < BN * 4; c += 256) {
+                const int r = c >> 2, q = c & 3;
+                U4 v = U4{0u, 0u, 0u, 0u};
+                if (n0 + r < p.N) v = *reinterpret_cast<const U4*>(Wt + (size_t)(n0 + r) * p.K + k0 + q * 8);
+                *reinterpret_cast<U4*>(&Bs[r * LDS_LD + q * 8]) = v;
+            }
+            __syncthreads();
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * WM + i * 16 + fr) * LDS_LD + fq * 8]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * WN + j * 16 + fr) * LDS_LD + fq * 8]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            __syncthreads();
+        }
+    }
+    // epilogue: lane holds C[row = 4*fq + r][col = fr] of each 16x16 tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + j * 16 + fr;
+            const bool nv = n < p.N;
+            const int nm = nv ? n % p.n_mod : 0;
+            const float bias = (p.bias && nv) ? p.bias[nm] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = m0 + wm * WM + i * 16 + fq * 4 + r;
+                float v = acc[i][j][r] + bias;
+                if (p.act == ACT_SWIGLU) {
+                    // columns (2i, 2i+1) = (gate, up): partner value sits in the neighbouring lane
+                    const float other = dpp_f<DPP_XOR1>(v);
+                    if ((fr & 1) == 0 && nv && t < p.M) {
+                        const float gate = v, up = other;
+                        const float o = (gate / (1.0f + expf(-gate))) * up;
+                        const size_t oi = (size_t)b * p.o_bstride + (size_t)t * p.ldo + (n >> 1);
+                        if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(o);
+                        if (p.out_f32) p.out_f32[oi] = o;
+                    }
+                    continue;
+                }
+                if (!nv || t >= p.M) continue;
+                if (p.act == ACT_GELU) v = gelu_f(v);
+                else if (p.act == ACT_TANH) v = tanhf(v);
+                if (p.gamma) v *= p.gamma[nm];
+                const size_t ri = (size_t)b * p.r_bstride + (size_t)t * p.ldr + n;
+                if (p.resid_f32) v += p.resid_f32[ri];
+                if (p.resid_bf) v += bf16_bits_to_f32(p.resid_bf[ri]);
+                const size_t oi = (size_t)b * p.o_bstride + (size_t)t * p.ldo + n;
+                if (p.out_f32) p.out_f32[oi] = v;
+                if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(v);
+                if (p.out_act) p.out_act[oi] = f32_to_bf16_bits(snake_f(v, p.alpha[nm]));
+            }
+        }
+    }
+}
+
+// ---- residual vector quantiser decode (vocoder.py:800-811): x[t][:] = sum_i table_i[code_i[t]][:]
+// table_i = out_proj_i(codebook_i) + bias_i, precomputed in f32 at load time.
+struct RvqP {
+    const int* codes;        // [B][ncb+1][T]
+    const float* tables;     // semantic table [S0][D] followed by ncb tables [S][D]
+    int ncb, S0, S, D, T;
+    float* x;                // [B][T][D] f32
+};
+__global__ __launch_bounds__(256) void rvq_gather_kernel(RvqP p) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int* cd = p.codes + (size_t)b * (p.ncb + 1) * p.T;
+    for (int d = threadIdx.x; d < p.D; d += 256) {
+        int c0 = cd[t];
+        c0 = c0 < 0 ? 0 : (c0 >= p.S0 ? p.S0 - 1 : c0);
+        float zs = p.tables[(size_t)c0 * p.D + d];
+        float zr = 0.f;
+        for (int i = 0; i < p.ncb; ++i) {
+            int c = cd[(size_t)(i + 1) * p.T + t];
+            c = c < 0 ? 0 : (c >= p.S ? p.S - 1 : c);
+            zr += p.tables[((size_t)p.S0 + (size_t)i * p.S + c) * p.D + d];
+        }
+        p.x[((size_t)b * p.T + t) * p.D + d] = zs + zr;
+    }
+}
+__global__ void rvq_table_kernel(const float* cb, const float* w, const float* bias, float* table, int S, int D, int cd) {
+    // table[s][d] = sum_j w[d][j] * cb[s][j] + bias[d]
+    const long n = (long)S * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(i / D), d = (int)(i % D);
+        float a = 0.f;
+        for (int j = 0; j < cd; ++j) a += w[(size_t)d * cd + j] * cb[(size_t)s * cd + j];
+        table[i] = a + bias[d];
+    }
+}
+
+// ---- RMSNorm over rows (vocoder.py:94-102), f32 in -> bf16 (and optionally f32) out
+struct RowNormP {
+    const float* x;
+    const float* w;
+    float eps;
+    int D;
+    bf16_t* out_bf;
+    float* out_f32;
+};
+__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(RowNormP p) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const float* x = p.x + row * p.D;
+    float ss = 0.f;
+    for (int d = threadIdx.x; d < p.D; d += 256) ss = fmaf(x[d], x[d], ss);
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float inv = rsqrt_exact((((red[0] + red[1]) + red[2]) + red[3]) / (float)p.D + p.eps);
+    for (int d = threadIdx.x; d < p.D; d += 256) {
+        const float v = (x[d] * inv) * p.w[d];
+        if (p.out_bf) p.out_bf[row * p.D + d] = f32_to_bf16_bits(v);
+        if (p.out_f32) p.out_f32[row * p.D + d] = v;
+    }
+}
+
+// ---- RoPE on the q and k thirds of a [T][3*H*hd] bf16 buffer, in place (vocoder.py:145-156)
+__global__ void rope_qk_kernel(bf16_t* qkv, const float* tab, int T, int H, int hd) {
+    const int hp = hd >> 1;
+    const long n = (long)T * 2 * H * hp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int pr = (int)(i % hp);
+        const int h = (int)((i / hp) % (2 * H));  // q heads then k heads
+        const int t = (int)(i / ((long)hp * 2 * H));
+        bf16_t* v = qkv + (size_t)t * 3 * H * hd + (size_t)h * hd + 2 * pr;
+        const float x0 = bf16_bits_to_f32(v[0]), x1 = bf16_bits_to_f32(v[1]);
+        const float c = tab[((size_t)t * hp + pr) * 2], s = tab[((size_t)t * hp + pr) * 2 + 1];
+        v[0] = f32_to_bf16_bits(x0 * c - x1 * s);
+        v[1] = f32_to_bf16_bits(x1 * c + x0 * s);
+    }
+}
+
+// ---- window-limited causal attention (vocoder.py:210-214 with the band mask of 325-332):
+// one wave per (query t, head); lanes over keys for the scores, lanes over dims for P.V
+struct WinAttnP {
+    const bf16_t* qkv;  // [T][3*H*hd], q and k already rotated
+    bf16_t* y;          // [T][H*hd]
+    int T, H, hd, window;
+    float scale;
+};
+__global__ __launch_bounds__(256) void window_attn_kernel(WinAttnP p) {
+    __shared__ float q_s[4][128];
+    __shared__ float p_s[4][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)p.T * p.H) return;
+    const int t = (int)(item / p.H), h = (int)(item % p.H);
+    const int hd = p.hd, ld = 3 * p.H * hd;
+    const bf16_t* q = p.qkv + (size_t)t * ld + (size_t)h * hd;
+    for (int d = lane; d < hd; d += 64) q_s[wave][d] = bf16_bits_to_f32(q[d]);
+    __builtin_amdgcn_wave_barrier();
+    const int j0 = max(0, t - p.window + 1);
+    const int nk = t - j0 + 1;
+    float mx = -INFINITY;
+    for (int jj = lane; jj < nk; jj += 64) {
+        const bf16_t* k = p.qkv + (size_t)(j0 + jj) * ld + (size_t)(p.H + h) * hd;
+        float s = 0.f;
+        for (int d = 0; d < hd; d += 8) {
+            float kv[8];
+            Vec<bf16_t>::load(k + d, kv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(q_s[wave][d + e], kv[e], s);
+        }
+        s *= p.scale;
+        p_s[wave][jj] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int jj = lane; jj < nk; jj += 64) {
+        const float e = expf(p_s[wave][jj] - mx);
+        p_s[wave][jj] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_wave_barrier();
+    for (int d = lane; d < hd; d += 64) {
+        float o = 0.f;
+        for (int jj = 0; jj < nk; ++jj)
+            o = fmaf(p_s[wave][jj], bf16_bits_to_f32(p.qkv[(size_t)(j0 + jj) * ld + (size_t)(2 * p.H + h) * hd + d]), o);
+        p.y[(size_t)t * p.H * hd + (size_t)h * hd + d] = f32_to_bf16_bits(o / sum);
+    }
+}
+
+// ---- ConvNeXt front half (vocoder.py:667-671): depthwise causal conv k=7 + LayerNorm(eps 1e-6)
+struct DwLnP {
+    const bf16_t* x;   // [T][C]
+    const float* w;    // [C][7]
+    const float* b;    // [C]
+    const float* lw;
+    const float* lb;
+    int T, C;
+    bf16_t* out;       // [T][C]
+};
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(DwLnP p) {
+    __shared__ float red[8];
+    extern __shared__ float ybuf[];  // [C]
+    const int t = blockIdx.x;
+    float s1 = 0.f;
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        float a = p.b[c];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int tt = t - 6 + k;
+            if (tt >= 0) a = fmaf(p.w[c * 7 + k], bf16_bits_to_f32(p.x[(size_t)tt * p.C + c]), a);
+        }
+        ybuf[c] = a;
+        s1 += a;
+    }
+    s1 = wave_sum(s1);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s1;
+    __syncthreads();
+    const float mean = (((red[0] + red[1]) + red[2]) + red[3]) / (float)p.C;
+    float s2 = 0.f;
+    for (int c = threadIdx.x; c < p.C; c += 256) { const float d = ybuf[c] - mean; s2 = fmaf(d, d, s2); }
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = s2;
+    __syncthreads();
+    const float var = (((red[4] + red[5]) + red[6]) + red[7]) / (float)p.C;
+    const float inv = rsqrt_exact(var + 1e-6f);
+    for (int c = threadIdx.x; c < p.C; c += 256)
+        p.out[(size_t)t * p.C + c] = f32_to_bf16_bits((ybuf[c] - mean) * inv * p.lw[c] + p.lb[c]);
+}
+
+// ---- last layer (vocoder.py:631-635): conv k=7 C->1 on the snake'd input, tanh -> f32 audio
+struct FinalConvP {
+    const bf16_t* xs;  // [T][C]
+    const float* w;    // [7][C]
+    float bias;
+    int T, C;
+    float* audio;      // [T]
+};
+__global__ __launch_bounds__(256) void final_conv_tanh_kernel(FinalConvP p) {
+    // 16 lanes per output sample, 16 samples per block step
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    for (long t = (long)blockIdx.x * 16 + grp; t < p.T; t += (long)gridDim.x * 16) {
+        float a = 0.f;
+        for (int k = 0; k < 7; ++k) {
+            const long tt = t - 6 + k;
+            if (tt < 0) continue;
+            for (int c = sub; c < p.C; c += 16) a = fmaf(p.w[k * p.C + c], bf16_bits_to_f32(p.xs[(size_t)tt * p.C + c]), a);
+        }
+        a = row16_sum(a);
+        if (sub == 0) p.audio[t] = tanhf(a + p.bias);
+    }
+}
+
+// ---- weight repacks
+__global__ void pack_conv_kernel(const float* w, bf16_t* o, int Cout, int Cin, int k) {
+    // [Cout][Cin][k] -> [k][Cout][Cin]
+    const long n = (long)Cout * Cin * k;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % k), ci = (int)((i / k) % Cin), co = (int)(i / ((long)k * Cin));
+        o[((size_t)kk * Cout + co) * Cin + ci] = f32_to_bf16_bits(w[i]);
+    }
+}
+__global__ void pack_convT_kernel(const float* w, bf16_t* o, int Cin, int Cout, int k, int s) {
+    // [Cin][Cout][k] -> [k/s taps][s*Cout][Cin]; tap j, column (r, co) <- w[ci][co][r + j*s]
+    const long n = (long)Cin * Cout * k;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % k), co = (int)((i / k) % Cout), ci = (int)(i / ((long)k * Cout));
+        const int j = kk / s, r = kk % s;
+        o[((size_t)j * s * Cout + (size_t)r * Cout + co) * Cin + ci] = f32_to_bf16_bits(w[i]);
+    }
+}
+__global__ void pack_rows_kernel(const float* w, bf16_t* o, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        o[i] = f32_to_bf16_bits(w[i]);
+}
+__global__ void pack_interleave_kernel(const float* a, const float* b, bf16_t* o, long rows, long K) {
+    const long n = rows * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / K, k = i % K;
+        o[(2 * r) * K + k] = f32_to_bf16_bits(a[i]);
+        o[(2 * r + 1) * K + k] = f32_to_bf16_bits(b[i]);
+    }
+}
+__global__ void snake_rows_kernel(const float* x, const float* alpha, bf16_t* out, long T, int C) {
+    const long n = T * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = f32_to_bf16_bits(snake_f(x[i], alpha[i % C]));
+}
+
+}  // namespace ft

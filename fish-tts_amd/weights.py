@@ -71,3 +71,97 @@ def load_checkpoint(model_dir) -> Dict[str, torch.Tensor]:
     """model.pth of the reference layout: mmap'd, weights_only (llama.py:476-482)."""
     sd = torch.load(Path(model_dir) / "model.pth", map_location="cpu", mmap=True, weights_only=True)
     return sd["state_dict"] if "state_dict" in sd else sd
+
+
+def codec_state_dict_shapes(a) -> Dict[str, tuple]:
+    """Folded decode-path tensors of the DAC codec under the reference's module paths
+    (vocoder.py Decoder 605-640, DownsampleResidualVectorQuantize 683-757, synthesizer.py:199-269)."""
+    D = a.latent_dim
+    H = a.tf_n_head * a.tf_head_dim
+    s: Dict[str, tuple] = {}
+    s["quantizer.semantic_quantizer.quantizers.0.codebook.weight"] = (a.semantic_codebook_size, a.codebook_dim)
+    s["quantizer.semantic_quantizer.quantizers.0.out_proj.weight"] = (D, a.codebook_dim, 1)
+    s["quantizer.semantic_quantizer.quantizers.0.out_proj.bias"] = (D,)
+    for i in range(a.n_codebooks):
+        s[f"quantizer.quantizer.quantizers.{i}.codebook.weight"] = (a.codebook_size, a.codebook_dim)
+        s[f"quantizer.quantizer.quantizers.{i}.out_proj.weight"] = (D, a.codebook_dim, 1)
+        s[f"quantizer.quantizer.quantizers.{i}.out_proj.bias"] = (D,)
+    for l in range(a.n_tf_layer):
+        p = f"quantizer.post_module.layers.{l}"
+        s[f"{p}.attention.wqkv.weight"] = (3 * H, D)
+        s[f"{p}.attention.wo.weight"] = (D, H)
+        s[f"{p}.feed_forward.w1.weight"] = (a.tf_ffn, D)
+        s[f"{p}.feed_forward.w3.weight"] = (a.tf_ffn, D)
+        s[f"{p}.feed_forward.w2.weight"] = (D, a.tf_ffn)
+        for n in ("ffn_norm.weight", "attention_norm.weight", "attention_layer_scale.gamma", "ffn_layer_scale.gamma"):
+            s[f"{p}.{n}"] = (D,)
+    s["quantizer.post_module.norm.weight"] = (D,)
+    for j, f in enumerate(a.downsample_factor):
+        p = f"quantizer.upsample.{j}"
+        s[f"{p}.0.conv.weight"] = (D, D, f)
+        s[f"{p}.0.conv.bias"] = (D,)
+        s[f"{p}.1.dwconv.conv.weight"] = (D, 1, 7)
+        s[f"{p}.1.dwconv.conv.bias"] = (D,)
+        s[f"{p}.1.norm.weight"] = (D,)
+        s[f"{p}.1.norm.bias"] = (D,)
+        s[f"{p}.1.pwconv1.weight"] = (4 * D, D)
+        s[f"{p}.1.pwconv1.bias"] = (4 * D,)
+        s[f"{p}.1.pwconv2.weight"] = (D, 4 * D)
+        s[f"{p}.1.pwconv2.bias"] = (D,)
+        s[f"{p}.1.gamma"] = (D,)
+    s["decoder.model.0.conv.weight"] = (a.decoder_dim, D, 7)
+    s["decoder.model.0.conv.bias"] = (a.decoder_dim,)
+    for i, r in enumerate(a.decoder_rates):
+        cin, cout = a.decoder_dim // 2 ** i, a.decoder_dim // 2 ** (i + 1)
+        p = f"decoder.model.{i + 1}.block"
+        s[f"{p}.0.alpha"] = (1, cin, 1)
+        s[f"{p}.1.conv.weight"] = (cin, cout, 2 * r)
+        s[f"{p}.1.conv.bias"] = (cout,)
+        for u in range(3):
+            q = f"{p}.{u + 2}.block"
+            s[f"{q}.0.alpha"] = (1, cout, 1)
+            s[f"{q}.1.conv.weight"] = (cout, cout, 7)
+            s[f"{q}.1.conv.bias"] = (cout,)
+            s[f"{q}.2.alpha"] = (1, cout, 1)
+            s[f"{q}.3.conv.weight"] = (cout, cout, 1)
+            s[f"{q}.3.conv.bias"] = (cout,)
+    n = len(a.decoder_rates) + 1
+    last = a.decoder_dim // 2 ** len(a.decoder_rates)
+    s[f"decoder.model.{n}.alpha"] = (1, last, 1)
+    s[f"decoder.model.{n + 1}.conv.weight"] = (1, last, 7)
+    s[f"decoder.model.{n + 1}.conv.bias"] = (1,)
+    return s
+
+
+def random_codec_state_dict(a, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Synthetic codec weights with O(1) activations through the stack (for benches / smoke runs)."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, shp in codec_state_dict_shapes(a).items():
+        if k.endswith("alpha"):
+            w = 0.5 + torch.rand(shp, generator=g)
+        elif k.endswith("gamma"):
+            w = 0.1 + 0.1 * torch.rand(shp, generator=g)
+        elif k.endswith("norm.weight"):
+            w = torch.ones(shp)
+        elif k.endswith(".bias"):
+            w = 0.05 * torch.randn(shp, generator=g)
+        elif "codebook.weight" in k:
+            w = torch.randn(shp, generator=g)
+        else:
+            if k.startswith("quantizer.upsample.") and k.endswith(".0.conv.weight"):
+                fan_in = shp[0]
+            elif k.startswith("decoder.model.") and k.endswith(".block.1.conv.weight"):
+                fan_in = 2 * shp[0]
+            else:
+                fan_in = 1
+                for d in shp[1:]:
+                    fan_in *= d
+            w = torch.randn(shp, generator=g) / math.sqrt(fan_in)
+            if k.endswith(".block.3.conv.weight"):
+                w = 0.3 * w
+            if k.startswith("decoder.model.") and k.endswith(".block.1.conv.weight"):
+                w = 0.7 * w
+        out[k] = w.float()
+    return out
