@@ -1,0 +1,325 @@
+"""Public API of fish-tts on the MI355X path: get_instance / reset_instance / FishTTS / VoiceProfile with the
+signatures, defaults and exceptions of fish_tts/synthesizer.py:47-719.  The dual-AR decode and the DAC decode
+run in libfishtts_hip.so; this file is host logic only (threads, queues, WAV packing)."""
+from __future__ import annotations
+
+import io
+import logging
+import queue
+import threading
+import time
+import wave
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Iterator, List, Literal, Optional
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+_instance: "FishTTS | None" = None
+_instance_lock = threading.Lock()
+
+
+@dataclass
+class VoiceProfile:
+    """Encoded reference audio: (num_codebooks, T) integer codes + transcript (synthesizer.py:47-65)."""
+    codes: np.ndarray
+    text: str = ""
+    name: str = ""
+
+    def save(self, path) -> None:
+        np.save(path, self.codes)
+
+    @classmethod
+    def load(cls, path, text: str = "", name: str = "") -> "VoiceProfile":
+        codes = np.load(path)
+        if not name:
+            name = Path(path).stem
+        return cls(codes=codes, text=text, name=name)
+
+
+@dataclass
+class _PrefillCache:
+    prompt_text: List[str] = field(default_factory=list)
+    prompt_tokens: List[np.ndarray] = field(default_factory=list)
+    profiles: List[VoiceProfile] = field(default_factory=list)
+
+
+class FishTTS:
+    """TTS synthesizer: DualARTransformer + DAC vocoder on one MI355X (one process per GPU)."""
+
+    def __init__(self, model_dir=None, device: Literal["cpu", "cuda"] = "cuda",
+                 precision: Literal["bf16", "fp16", "fp32"] = "bf16", warmup: bool = True, *,
+                 _synthetic: Optional[dict] = None, gpu_index: int = 0):
+        self.device = device
+        self._precision = precision
+        self._warmup = warmup
+        self._engine = None
+        self._tokenizer = None
+        self._vocoder = None
+        self._is_warmed_up = False
+        self._prefill_cache = _PrefillCache()
+        self._prefill_lock = threading.Lock()
+        self._gen_lock = threading.Lock()  # AR calls on one context are serialised
+        self._gpu_index = gpu_index
+        if device != "cuda":
+            raise RuntimeError("fish_tts_amd runs the hot path on an MI355X only: device must be 'cuda' "
+                               "(there is no CPU fallback)")
+        if precision == "fp16":
+            raise NotImplementedError("precision 'fp16' is not implemented on the MI355X path; use 'bf16' or 'fp32'")
+        if _synthetic is not None:
+            self._load_synthetic(**_synthetic)
+        else:
+            self._model_dir = self._ensure_model(model_dir)
+            self._load_models()
+        if warmup:
+            self._run_warmup()
+
+    # ------------------------------------------------------------------ loading
+    def _ensure_model(self, model_dir) -> Path:
+        if model_dir is not None:
+            return Path(model_dir)
+        # the reference downloads fishaudio/openaudio-s1-mini here (synthesizer.py:146-156)
+        raise RuntimeError("model_dir is required: this build does not download checkpoints "
+                           "(pass the directory holding config.json / model.pth / codec.pth / tokenizer.tiktoken)")
+
+    def _load_models(self) -> None:
+        import torch
+
+        from .ar_engine import ARHipEngine
+        from .codec_engine import CodecHipEngine
+        from .config import DualARModelArgs
+        from .tokenizer import IM_END_TOKEN, load_tokenizer
+        from .weights import load_checkpoint
+        t0 = time.perf_counter()
+        args = DualARModelArgs.from_pretrained(str(self._model_dir))
+        self._tokenizer = load_tokenizer(self._model_dir)
+        tok = self._tokenizer
+        self._engine = ARHipEngine(args, tok.semantic_begin_id, tok.semantic_end_id, tok.get_token_id(IM_END_TOKEN),
+                                   precision=self._precision, device=self._gpu_index, max_batch=1, max_new_tokens=2048 + 8)
+        self._engine.load_state_dict(load_checkpoint(self._model_dir))
+        logger.info("Transformer loaded in %.1fs", time.perf_counter() - t0)
+        codec_path = self._model_dir / "codec.pth"
+        if codec_path.exists():
+            sd = torch.load(codec_path, map_location="cpu", weights_only=True)
+            self._vocoder = CodecHipEngine(device=self._gpu_index, max_frames=2048 + 8)
+            self._vocoder.load_state_dict(sd)
+            logger.info("Vocoder loaded (bf16 contractions, f32 accumulate)")
+        else:
+            logger.warning("codec.pth not found, vocoder not loaded")
+
+    def _load_synthetic(self, args, tokenizer, codec_args=None, seed: int = 0, with_codec: bool = True,
+                        max_new_tokens: int = 2048 + 8, std=None):
+        from .ar_engine import ARHipEngine
+        from .codec_engine import CodecHipEngine
+        from .tokenizer import IM_END_TOKEN
+        from .weights import random_state_dict
+        import torch
+        self._tokenizer = tokenizer
+        dtype = torch.bfloat16 if self._precision == "bf16" else torch.float32
+        self._engine = ARHipEngine(args, tokenizer.semantic_begin_id, tokenizer.semantic_end_id,
+                                   tokenizer.get_token_id(IM_END_TOKEN), precision=self._precision,
+                                   device=self._gpu_index, max_batch=1, max_new_tokens=max_new_tokens)
+        self._engine.load_state_dict(random_state_dict(args, seed=seed, dtype=dtype, std=std))
+        if with_codec:
+            self._vocoder = CodecHipEngine.synthetic(device=self._gpu_index, max_frames=max_new_tokens, seed=seed,
+                                                     args=codec_args)
+
+    @classmethod
+    def synthetic(cls, args, tokenizer, codec_args=None, precision="bf16", seed: int = 0, warmup: bool = False,
+                  with_codec: bool = True, max_new_tokens: int = 2048 + 8, std=None, gpu_index: int = 0) -> "FishTTS":
+        """Random-init model of the given shapes (no checkpoint on disk): benches, smoke tests."""
+        return cls(None, "cuda", precision, warmup, gpu_index=gpu_index,
+                   _synthetic=dict(args=args, tokenizer=tokenizer, codec_args=codec_args, seed=seed,
+                                   with_codec=with_codec, max_new_tokens=max_new_tokens, std=std))
+
+    def _run_warmup(self) -> None:
+        logger.info("Running warmup (captures the frame graph)...")
+        t0 = time.perf_counter()
+        try:
+            from .generation import generate_long
+            with self._gen_lock:
+                for response in generate_long(engine=self._engine, tokenizer=self._tokenizer, text="Hello.",
+                                              max_new_tokens=50, temperature=0.7, top_p=0.8, repetition_penalty=1.1,
+                                              prompt_text=[], prompt_tokens=[]):
+                    if response.action == "next":
+                        break
+            self._is_warmed_up = True
+            logger.info("Warmup complete in %.1fs", time.perf_counter() - t0)
+        except Exception as e:  # noqa: BLE001  (the reference only logs a failed warmup, synthesizer.py:322-323)
+            logger.warning("Warmup failed: %s", e)
+
+    def encode_reference(self, audio_bytes: bytes, text: str) -> VoiceProfile:
+        if self._vocoder is None:
+            raise RuntimeError("Vocoder not loaded")
+        raise NotImplementedError("encode_reference (the codec *encoder*) is outside the MI355X hot path; "
+                                  "create profiles offline and load them with VoiceProfile.load")
+
+    # ------------------------------------------------------------------ references (synthesizer.py:363-429)
+    def set_references(self, profiles: List[VoiceProfile]) -> None:
+        with self._prefill_lock:
+            self._prefill_cache = _PrefillCache(prompt_text=[p.text for p in profiles],
+                                                prompt_tokens=[np.asarray(p.codes) for p in profiles],
+                                                profiles=list(profiles))
+            logger.info("Set %d reference(s)", len(profiles))
+
+    def add_reference(self, profile: VoiceProfile) -> None:
+        with self._prefill_lock:
+            self._prefill_cache.profiles.append(profile)
+            self._prefill_cache.prompt_text.append(profile.text)
+            self._prefill_cache.prompt_tokens.append(np.asarray(profile.codes))
+
+    def clear_references(self) -> None:
+        with self._prefill_lock:
+            self._prefill_cache = _PrefillCache()
+
+    def get_references(self) -> List[VoiceProfile]:
+        with self._prefill_lock:
+            return list(self._prefill_cache.profiles)
+
+    @property
+    def num_references(self) -> int:
+        return len(self._prefill_cache.profiles)
+
+    def _get_prompt_data(self, references):
+        if references is not None:
+            return [p.text for p in references], [np.asarray(p.codes) for p in references]
+        with self._prefill_lock:
+            return list(self._prefill_cache.prompt_text), list(self._prefill_cache.prompt_tokens)
+
+    # ------------------------------------------------------------------ synthesis
+    def synthesize(self, text: str, references: Optional[List[VoiceProfile]] = None, temperature: float = 0.7,
+                   top_p: float = 0.8, repetition_penalty: float = 1.1, max_tokens: int = 2048) -> bytes:
+        """Text -> WAV bytes (synthesizer.py:431-481)."""
+        from .generation import generate_long
+        prompt_text, prompt_tokens = self._get_prompt_data(references)
+        codes_list = []
+        with self._gen_lock:
+            for response in generate_long(engine=self._engine, tokenizer=self._tokenizer, text=text,
+                                          max_new_tokens=max_tokens, temperature=temperature, top_p=top_p,
+                                          repetition_penalty=repetition_penalty, prompt_text=prompt_text,
+                                          prompt_tokens=prompt_tokens):
+                if response.action == "sample":
+                    codes_list.append(response.codes)
+                elif response.action == "next":
+                    break
+        if not codes_list:
+            raise RuntimeError("No audio generated")
+        return self._decode_to_wav(np.concatenate(codes_list, axis=1))
+
+    def synthesize_stream(self, text: str, references: Optional[List[VoiceProfile]] = None, chunk_tokens: int = 20,
+                          min_first_chunk: int = 10, **kwargs) -> Iterator[bytes]:
+        """Streaming synthesis: AR generation on this thread, codec decode on a worker thread with two bounded
+        queues; each chunk is decoded independently from zero context (synthesizer.py:483-584)."""
+        from .generation import generate_long
+        prompt_text, prompt_tokens = self._get_prompt_data(references)
+        codes_queue: "queue.Queue" = queue.Queue(maxsize=3)
+        audio_queue: "queue.Queue" = queue.Queue(maxsize=3)
+        error_holder: List[Exception] = []
+
+        def decoder_worker():
+            try:
+                while True:
+                    codes = codes_queue.get()
+                    if codes is None:
+                        break
+                    audio_queue.put(self._decode_to_pcm(codes))
+            except Exception as e:  # noqa: BLE001
+                error_holder.append(e)
+            finally:
+                audio_queue.put(None)
+
+        worker = threading.Thread(target=decoder_worker, daemon=True)
+        worker.start()
+        try:
+            buffer, is_first_chunk, total_tokens = [], True, 0
+            with self._gen_lock:
+                for response in generate_long(engine=self._engine, tokenizer=self._tokenizer, text=text,
+                                              max_new_tokens=kwargs.get("max_tokens", 2048),
+                                              temperature=kwargs.get("temperature", 0.7), top_p=kwargs.get("top_p", 0.8),
+                                              repetition_penalty=kwargs.get("repetition_penalty", 1.1),
+                                              prompt_text=prompt_text, prompt_tokens=prompt_tokens, streaming=True):
+                    if response.action == "sample":
+                        buffer.append(response.codes)
+                        total_tokens += response.codes.shape[1]
+                        threshold = min_first_chunk if is_first_chunk else chunk_tokens
+                        if total_tokens >= threshold:
+                            codes_queue.put(np.concatenate(buffer, axis=1))
+                            buffer, total_tokens, is_first_chunk = [], 0, False
+                            while not audio_queue.empty():
+                                audio = audio_queue.get_nowait()
+                                if audio is not None:
+                                    yield audio
+                    elif response.action == "next":
+                        if buffer:
+                            codes_queue.put(np.concatenate(buffer, axis=1))
+                        break
+        finally:
+            codes_queue.put(None)
+        worker.join()
+        while not audio_queue.empty():
+            audio = audio_queue.get_nowait()
+            if audio is not None:
+                yield audio
+        if error_holder:
+            raise error_holder[0]
+
+    # ------------------------------------------------------------------ codes -> audio (synthesizer.py:586-648)
+    def _decode_to_wav(self, codes: np.ndarray) -> bytes:
+        return self._to_wav_bytes(self._decode_codes(codes))
+
+    def _decode_to_pcm(self, codes: np.ndarray) -> bytes:
+        audio = self._decode_codes(codes)
+        return (audio * 32767).astype(np.int16).tobytes()  # no clip on the PCM path (synthesizer.py:594)
+
+    def _decode_codes(self, codes: np.ndarray) -> np.ndarray:
+        if self._vocoder is None:
+            raise RuntimeError("Vocoder not loaded")
+        codes = np.asarray(codes)
+        if codes.ndim == 2:
+            codes = codes[None]
+        return np.squeeze(self._vocoder.decode(codes))
+
+    @staticmethod
+    def _to_wav_bytes(audio: np.ndarray, sample_rate: int = 44100) -> bytes:
+        audio = np.clip(audio, -1.0, 1.0)
+        audio_int16 = (audio * 32767).astype(np.int16)
+        buffer = io.BytesIO()
+        with wave.open(buffer, "wb") as wf:
+            wf.setnchannels(1)
+            wf.setsampwidth(2)
+            wf.setframerate(sample_rate)
+            wf.writeframes(audio_int16.tobytes())
+        return buffer.getvalue()
+
+    @property
+    def sample_rate(self) -> int:
+        return 44100
+
+    @property
+    def precision(self) -> str:
+        return self._precision
+
+
+def get_instance(model_dir=None, device: Literal["cpu", "cuda"] = "cuda",
+                 precision: Literal["bf16", "fp16", "fp32"] = "bf16", warmup: bool = True) -> FishTTS:
+    """Process-wide singleton; later calls return the first instance and ignore their arguments
+    (synthesizer.py:661-710)."""
+    global _instance
+    if _instance is not None:
+        return _instance
+    with _instance_lock:
+        if _instance is not None:
+            return _instance
+        logger.info("Creating singleton FishTTS instance...")
+        _instance = FishTTS(model_dir=model_dir, device=device, precision=precision, warmup=warmup)
+        return _instance
+
+
+def reset_instance() -> None:
+    global _instance
+    with _instance_lock:
+        if _instance is not None:
+            logger.info("Resetting singleton FishTTS instance")
+            _instance = None

@@ -1,0 +1,122 @@
+"""End-to-end on the GPU through the public API (FishTTS.synthesize / synthesize_stream / references)
+with tiny synthetic models, checked against the oracle pipeline (AR oracle -> codec oracle)."""
+import io
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ar as OA
+from oracle import codec as OC
+from tests.hip_util import args_from_shape
+from tests.shapes import tiny_shape
+from tests.test_codec_gpu import args_from_shape as codec_args_from_shape
+
+pytestmark = pytest.mark.gpu
+
+
+def api_codec_shape():
+    return OC.CodecShape(n_codebooks=9, codebook_size=1024, semantic_codebook_size=2048, codebook_dim=8, latent_dim=64,
+                         n_tf_layer=2, tf_n_head=4, tf_head_dim=16, tf_ffn=96, tf_window=8, tf_block_size=256,
+                         upsample=[2, 2], decoder_dim=128, rates=[4, 2])
+
+
+@pytest.fixture(scope="module")
+def tts():
+    import fish_tts_amd as ft
+    from fish_tts_amd.tokenizer import NAMED_SPECIAL_TOKENS, ByteTokenizer
+    shape = tiny_shape()
+    tok = ByteTokenizer(256, NAMED_SPECIAL_TOKENS + [f"<|semantic:{i}|>" for i in range(2048)])
+    assert tok.semantic_begin_id == shape.semantic_begin_id and tok.get_token_id("<|im_end|>") == shape.im_end_id
+    cshape = api_codec_shape()
+    # engines get the oracle's seeded weights so that both sides run the same model
+    synth = ft.FishTTS.__new__(ft.FishTTS)
+    ft.FishTTS.__init__(synth, None, "cuda", "fp32", False,
+                        _synthetic=dict(args=args_from_shape(shape), tokenizer=tok, codec_args=codec_args_from_shape(cshape),
+                                        with_codec=False, max_new_tokens=96))
+    w = OA.random_weights(shape, seed=0)
+    synth._engine.close()
+    from fish_tts_amd.ar_engine import ARHipEngine
+    from fish_tts_amd.codec_engine import CodecHipEngine
+    synth._engine = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,
+                                precision="fp32", max_new_tokens=96)
+    synth._engine.load_state_dict(w)
+    cw = OC.random_weights(cshape, seed=0)
+    synth._vocoder = CodecHipEngine(codec_args_from_shape(cshape), max_frames=96)
+    synth._vocoder.load_state_dict(cw)
+    orc = OA.AROracle(shape, w, torch.float32)
+    corc = OC.CodecOracle(cshape, cw)
+    yield synth, tok, orc, corc, shape, cshape
+    synth._engine.close()
+    synth._vocoder.close()
+
+
+def _oracle_codes(orc, prompt, n, **kw):
+    orc.reset()
+    seq = orc.generate(torch.from_numpy(prompt), n, **kw).numpy()
+    return seq
+
+
+def test_synthesize_matches_oracle_pipeline(tts):
+    synth, tok, orc, corc, shape, cshape = tts
+    from fish_tts_amd.prompt import build_prompt
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    wav = synth.synthesize("Hi there", max_tokens=12, **kw)
+    prompt = build_prompt(tok, "Hi there", [], [], 10)
+    seq = _oracle_codes(orc, prompt, 12, **kw)
+    codes = seq[1:, prompt.shape[1]:-1]  # batch mode drops the last column (inference.py:839)
+    want, _ = corc.decode(torch.from_numpy(codes.astype(np.int64))[None], torch.tensor([codes.shape[1]]))
+    want = want[0, 0].numpy()
+    with wave.open(io.BytesIO(wav), "rb") as wf:
+        assert (wf.getnchannels(), wf.getsampwidth(), wf.getframerate()) == (1, 2, 44100)
+        pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype=np.int16).astype(np.float32) / 32767
+    assert pcm.shape == want.shape == (codes.shape[1] * cshape.frame_len,)
+    err = np.sqrt(np.mean((pcm - np.clip(want, -1, 1)) ** 2)) / np.sqrt(np.mean(want ** 2))
+    assert err <= 3e-2, err
+
+
+def test_stream_yields_every_frame_in_reference_chunking(tts):
+    synth, tok, orc, corc, shape, cshape = tts
+    from fish_tts_amd.prompt import build_prompt
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    chunks = list(synth.synthesize_stream("Hi there", chunk_tokens=7, min_first_chunk=3, max_tokens=20, **kw))
+    prompt = build_prompt(tok, "Hi there", [], [], 10)
+    seq = _oracle_codes(orc, prompt, 20, **kw)
+    n = seq.shape[1] - prompt.shape[1]  # streaming yields all n frames (inference.py:721, 271)
+    fl = cshape.frame_len
+    sizes = [len(c) // (2 * fl) for c in chunks]
+    want_sizes = [3] + [7] * ((n - 3) // 7) + ([(n - 3) % 7] if (n - 3) % 7 else [])
+    assert sizes == want_sizes, (sizes, want_sizes)
+    # chunks are decoded independently from zero context: compare the first chunk to the oracle
+    first = np.frombuffer(chunks[0], dtype=np.int16).astype(np.float32) / 32767
+    codes0 = seq[1:, prompt.shape[1]: prompt.shape[1] + 3].astype(np.int64)
+    want0, _ = corc.decode(torch.from_numpy(codes0)[None], torch.tensor([3]))
+    err = np.sqrt(np.mean((first - want0[0, 0].numpy()) ** 2)) / np.sqrt(np.mean(want0[0, 0].numpy() ** 2))
+    assert err <= 3e-2, err
+
+
+def test_references_enter_the_prompt(tts):
+    synth, tok, orc, corc, shape, cshape = tts
+    import fish_tts_amd as ft
+    from fish_tts_amd.generation import generate_long
+    from fish_tts_amd.prompt import build_prompt
+    g = np.random.default_rng(4)
+    ref = np.zeros((10, 6), dtype=np.int64)
+    ref[0] = g.integers(0, 2048, 6)
+    ref[1:] = g.integers(0, 1024, (9, 6))
+    prof = ft.VoiceProfile(codes=ref, text="ref text", name="r")
+    synth.set_references([prof])
+    assert synth.num_references == 1 and synth.get_references()[0].name == "r"
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    res = [r for r in generate_long(engine=synth._engine, tokenizer=tok, text="Yo", max_new_tokens=8,
+                                    prompt_text=["ref text"], prompt_tokens=[ref], **kw) if r.action == "sample"]
+    prompt = build_prompt(tok, "Yo", ["ref text"], [ref], 10)
+    seq = _oracle_codes(orc, prompt, 8, **kw)
+    assert np.array_equal(res[0].codes, seq[1:, prompt.shape[1]:-1])
+    wav_with = synth.synthesize("Yo", max_tokens=8, **kw)
+    synth.clear_references()
+    wav_without = synth.synthesize("Yo", max_tokens=8, **kw)
+    assert wav_with != wav_without
+    with pytest.raises(AssertionError, match="top_p"):
+        synth.synthesize("x", top_p=0.0)

@@ -1,0 +1,116 @@
+"""CPU-side host logic: prompt assembly against the reference's golden matrices, WAV/PCM packing,
+VoiceProfile round trip, the public API surface, the singleton, utterance dealing."""
+import inspect
+import io
+import os
+import wave
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_prompt_matrices_match_reference():
+    from fish_tts_amd.prompt import build_prompt
+    from fish_tts_amd.tokenizer import ByteTokenizer
+    gold = np.load(os.path.join(G, "prompt.npz"))
+    tok = ByteTokenizer(151643)
+    for name, nref in (("noref", 0), ("oneref", 1), ("tworef", 2)):
+        texts = [bytes(gold[f"{name}.ref{i}.text"]).decode() for i in range(nref)]
+        codes = [gold[f"{name}.ref{i}.codes"] for i in range(nref)]
+        text = bytes(gold[f"{name}.text"]).decode()
+        got = build_prompt(tok, text, texts, codes, 10)
+        assert got.dtype == np.int32
+        assert np.array_equal(got, gold[f"{name}.prompt"]), name
+
+
+def test_token_layout_pins():
+    """ids pinned by the reference's tests/test_config.py:77-110."""
+    from fish_tts_amd.tokenizer import ByteTokenizer
+    tok = ByteTokenizer()
+    assert tok.get_token_id("<|begin_of_text|>") == 151643
+    assert tok.get_token_id("<|audio_end|>") == 151656
+    assert tok.semantic_begin_id == 151658 and tok.semantic_end_id == 155753
+    assert tok.encode("<|im_end|>ab") == [151647, 97, 98]
+
+
+def test_wav_and_pcm_packing():
+    from fish_tts_amd.synthesizer import FishTTS
+    audio = np.array([0.0, 0.5, -0.5, 1.5, -2.0, 0.999], dtype=np.float32)
+    data = FishTTS._to_wav_bytes(audio)
+    assert len(data) == 44 + 2 * len(audio)
+    with wave.open(io.BytesIO(data), "rb") as wf:
+        assert (wf.getnchannels(), wf.getsampwidth(), wf.getframerate()) == (1, 2, 44100)
+        pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype=np.int16)
+    assert pcm.tolist() == [0, 16383, -16383, 32767, -32767, 32734]  # clipped first (synthesizer.py:638)
+
+
+def test_voice_profile_roundtrip(tmp_path):
+    from fish_tts_amd import VoiceProfile
+    codes = np.random.default_rng(0).integers(0, 1024, size=(10, 50)).astype(np.int64)
+    p = VoiceProfile(codes=codes, text="hello", name="v")
+    f = tmp_path / "voice.npy"
+    p.save(f)
+    q = VoiceProfile.load(f, text="hello")
+    assert q.name == "voice" and q.text == "hello" and q.codes.dtype == np.int64
+    assert np.array_equal(q.codes, codes)
+
+
+def test_public_api_surface():
+    import fish_tts_amd as ft
+    sig = inspect.signature(ft.get_instance)
+    assert list(sig.parameters) == ["model_dir", "device", "precision", "warmup"]
+    assert [p.default for p in sig.parameters.values()] == [None, "cuda", "bf16", True]
+    sig = inspect.signature(ft.FishTTS.synthesize)
+    assert list(sig.parameters) == ["self", "text", "references", "temperature", "top_p", "repetition_penalty", "max_tokens"]
+    assert [p.default for p in list(sig.parameters.values())[2:]] == [None, 0.7, 0.8, 1.1, 2048]
+    sig = inspect.signature(ft.FishTTS.synthesize_stream)
+    assert list(sig.parameters) == ["self", "text", "references", "chunk_tokens", "min_first_chunk", "kwargs"]
+    assert sig.parameters["chunk_tokens"].default == 20 and sig.parameters["min_first_chunk"].default == 10
+    for name in ("set_references", "add_reference", "clear_references", "get_references", "num_references",
+                 "encode_reference", "sample_rate", "precision"):
+        assert hasattr(ft.FishTTS, name), name
+
+
+def test_singleton_ignores_later_arguments(monkeypatch):
+    import fish_tts_amd.synthesizer as S
+    made = []
+
+    class Fake:
+        def __init__(self, **kw):
+            made.append(kw)
+    monkeypatch.setattr(S, "FishTTS", Fake)
+    S.reset_instance()
+    a = S.get_instance(model_dir="x", warmup=False)
+    b = S.get_instance(model_dir="y", precision="fp32")
+    assert a is b and len(made) == 1 and made[0]["model_dir"] == "x"
+    S.reset_instance()
+    c = S.get_instance(model_dir="z")
+    assert c is not a and len(made) == 2
+    S.reset_instance()
+
+
+def test_cpu_device_and_missing_model_dir_fail_loudly():
+    from fish_tts_amd import FishTTS
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        FishTTS(model_dir="whatever", device="cpu")
+    with pytest.raises(RuntimeError, match="model_dir is required"):
+        FishTTS(model_dir=None, device="cuda", warmup=False)
+
+
+def test_deal_utterances_balances_lengths():
+    from fish_tts_amd.parallel import deal_utterances
+    lens = [430, 108, 300, 250, 120, 400, 200, 180]
+    parts = deal_utterances(lens, 4)
+    assert sorted(i for p in parts for i in p) == list(range(8))
+    loads = [sum(lens[i] for i in p) for p in parts]
+    assert max(loads) - min(loads) <= max(lens) // 2
+
+
+def test_config_defaults_follow_reference_rules():
+    from fish_tts_amd.config import DualARModelArgs, s1_mini_args
+    a = DualARModelArgs(dim=512, n_head=8, head_dim=None, intermediate_size=None)
+    assert a.head_dim == 64 and a.n_local_heads == 8 and a.intermediate_size == 1536 and a.fast_dim == 512
+    b = s1_mini_args()
+    assert (b.dim, b.n_layer, b.n_head, b.num_codebooks, b.codebook_size, b.vocab_size) == (1024, 28, 16, 10, 4096, 155776)
