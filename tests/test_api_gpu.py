@@ -1,5 +1,6 @@
 """End-to-end on the GPU through the public API (FishTTS.synthesize / synthesize_stream / references)
 with tiny synthetic models, checked against the oracle pipeline (AR oracle -> codec oracle)."""
+import dataclasses
 import io
 import wave
 
@@ -26,7 +27,8 @@ def api_codec_shape():
 def tts():
     import fish_tts_amd as ft
     from fish_tts_amd.tokenizer import NAMED_SPECIAL_TOKENS, ByteTokenizer
-    shape = tiny_shape()
+    # generate_long refuses prompts longer than max_seq_len - 2048 (inference.py:794): give the tiny model room
+    shape = dataclasses.replace(tiny_shape(), max_seq_len=2304)
     tok = ByteTokenizer(256, NAMED_SPECIAL_TOKENS + [f"<|semantic:{i}|>" for i in range(2048)])
     assert tok.semantic_begin_id == shape.semantic_begin_id and tok.get_token_id("<|im_end|>") == shape.im_end_id
     cshape = api_codec_shape()
