@@ -1106,6 +1106,10 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
     __shared__ float amv[4];
     __shared__ int ami[4];
     __shared__ int wcnt[4];
+    __shared__ float prL[1024];
+    __shared__ uint32_t keyL[1024];
+    __shared__ uint32_t cut_k;
+    __shared__ int cut_nk, cut_all;
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* L = p.logits + (size_t)m * p.ldl;
     const int V = p.V;
@@ -1166,51 +1170,65 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
     const float tp = rb<ROUND>(ctl.top_p);
     auto removed = [&](float cum) { return rb<ROUND>(cum) > tp; };
     constexpr uint32_t cmask = ROUND ? 0xffff0000u : 0xffffffffu;
-    float pr[4];
     uint32_t key[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        pr[e] = (i0 + e) < V ? rb<ROUND>(ex[e] / Z) : 0.f;
-        key[e] = (i0 + e) < V ? (order_key(l[e]) & cmask) : 0u;
+        const bool v = (i0 + e) < V;
+        key[e] = v ? (order_key(l[e]) & cmask) : 0u;
+        prL[i0 + e] = v ? rb<ROUND>(ex[e] / Z) : 0.f;
+        keyL[i0 + e] = key[e];
     }
-    uint32_t kstar = 0;
-    int nk = 0;
-    bool all_kept = false, only_top = false;
-    if (removed(rb<ROUND>(1.0f / Z))) {
-        only_top = true;
-    } else {
-        const float tot = red.sum((pr[0] + pr[1]) + (pr[2] + pr[3]));
-        if (!removed(tot)) {
-            all_kept = true;
-        } else {
-            constexpr int lowbit = ROUND ? 16 : 0;
-            for (int bit = 31; bit >= lowbit; --bit) {
-                const uint32_t cand = kstar | (1u << bit);
-                float ms = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ms += key[e] >= cand ? pr[e] : 0.f;
-                if (removed(red.sum(ms))) kstar = cand;
-            }
-            float above = 0.f, cnt = 0.f, pk = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (key[e] > kstar) above += pr[e];
-                else if (key[e] == kstar && (i0 + e) < V) { cnt += 1.f; pk = pr[e]; }
-            }
-            above = red.sum(above);
-            const int icnt = (int)red.sum(cnt);
-            const uint32_t ubits = (kstar & 0x80000000u) ? (kstar & 0x7fffffffu) : ~(kstar | ~cmask);
-            pk = rb<ROUND>(expf(__uint_as_float(ubits) - Lmax) / Z);
-            int lo_n = 0, hi_n = icnt;
-            while (lo_n < hi_n) {
-                const int mid = (lo_n + hi_n + 1) >> 1;
-                if (removed(fmaf((float)mid, pk, above))) hi_n = mid - 1; else lo_n = mid;
-            }
-            nk = lo_n;
-        }
-    }
+    const bool only_top = removed(rb<ROUND>(1.0f / Z));  // block-uniform
     int winner = am.i;
     if (!only_top) {
+        __syncthreads();
+        // ---- the top-p cut is searched by ONE wave on all 1024 (mass, key) pairs: 16 per lane, DPP reductions,
+        // no barriers inside the 16 (32) dependent steps
+        if (wave == 0) {
+            float pr[16];
+            uint32_t ky[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { pr[e] = prL[lane + 64 * e]; ky[e] = keyL[lane + 64 * e]; }
+            float tot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tot += pr[e];
+            tot = wave_sum(tot);
+            uint32_t kstar = 0;
+            int nk = 0, all_kept = 0;
+            if (!removed(tot)) {
+                all_kept = 1;
+            } else {
+                constexpr int lowbit = ROUND ? 16 : 0;
+                for (int bit = 31; bit >= lowbit; --bit) {
+                    const uint32_t cand = kstar | (1u << bit);
+                    float ms = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) ms += ky[e] >= cand ? pr[e] : 0.f;
+                    if (removed(wave_sum(ms))) kstar = cand;
+                }
+                float above = 0.f, cnt = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (ky[e] > kstar) above += pr[e];
+                    else if (ky[e] == kstar && (lane + 64 * e) < V) cnt += 1.f;
+                }
+                above = wave_sum(above);
+                const int icnt = (int)wave_sum(cnt);
+                const uint32_t ubits = (kstar & 0x80000000u) ? (kstar & 0x7fffffffu) : ~(kstar | ~cmask);
+                const float pk = rb<ROUND>(expf(__uint_as_float(ubits) - Lmax) / Z);
+                int lo_n = 0, hi_n = icnt;
+                while (lo_n < hi_n) {
+                    const int mid = (lo_n + hi_n + 1) >> 1;
+                    if (removed(fmaf((float)mid, pk, above))) hi_n = mid - 1; else lo_n = mid;
+                }
+                nk = lo_n;
+            }
+            if (lane == 0) { cut_k = kstar; cut_nk = nk; cut_all = all_kept; }
+        }
+        __syncthreads();
+        const uint32_t kstar = cut_k;
+        const int nk = cut_nk;
+        const bool all_kept = cut_all != 0;
         const float Tc = fmaxf(ctl.temperature, 1e-5f);
         const float Mt = rb<ROUND>(Lmax / Tc);
         // members of the cut class stay in index order = thread order, then element order
@@ -1226,7 +1244,6 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
             below += __popcll(bal & lower);
             wtot += __popcll(bal);
         }
-        __syncthreads();
         if (lane == 0) wcnt[wave] = wtot;
         __syncthreads();
         int rank = below;
@@ -1280,7 +1297,9 @@ struct SampCut {
     float Lmax, Mt, Z2, Tc;
 };
 
-constexpr size_t SAMP_HIST_STRIDE = 65536 + 1024;
+constexpr int SAMP_REP = 8;                        // histogram replicas (spreads same-class atomics)
+constexpr size_t SAMP_REP_STRIDE = 65536 + 1024;   // class counts, then counts per group of 64 classes
+constexpr size_t SAMP_HIST_STRIDE = SAMP_REP * SAMP_REP_STRIDE;
 
 struct SampBigP {
     SampP s;
@@ -1330,7 +1349,7 @@ __global__ __launch_bounds__(256) void samp_hist_kernel(SampBigP b) {
     if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end >= c0 && p.im_end < c0 + 1024 && p.im_end < V)
         L[p.im_end] = -INFINITY;
     __syncthreads();
-    unsigned* hist = b.hist + (size_t)m * SAMP_HIST_STRIDE;
+    unsigned* hist = b.hist + (size_t)m * SAMP_HIST_STRIDE + (size_t)(blockIdx.x % SAMP_REP) * SAMP_REP_STRIDE;
     unsigned* grp = hist + 65536;
     const int lane = tid & 63;
     for (int i = tid; i < 1024; i += 256) grp_s[i] = 0u;
@@ -1374,6 +1393,8 @@ __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
     __shared__ float red[16];
     __shared__ int redi[16];
     __shared__ float wsum[16];
+    __shared__ int wact[16];
+    __shared__ int AL[1024];  // active groups, ascending
     __shared__ unsigned ovf_key[SAMP_TH_OVF];
     __shared__ unsigned ovf_cnt[SAMP_TH_OVF];
     __shared__ int ovf_n;
@@ -1381,66 +1402,88 @@ __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
     const SampP& p = b.s;
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RowCtl ctl = p.ctl[m];
-    unsigned* hist = b.hist + (size_t)m * SAMP_HIST_STRIDE;
-    unsigned* grp = hist + 65536;
+    unsigned* hist0 = b.hist + (size_t)m * SAMP_HIST_STRIDE;
     if (tid == 0) ovf_n = 0;
     __syncthreads();
+    // ---- stage: thread t owns group t (classes [64 t, 64 t + 64)); replicas are summed, then cleared
     uint32_t* row = cimg + tid * SAMP_TH_ROW;
     int kmax_t = -1;
-    const bool has = grp[tid] != 0u;  // any logit in my 64 classes?
-    if (has) {
-        grp[tid] = 0u;
-        U4* h4 = reinterpret_cast<U4*>(hist + 64 * tid);
-#pragma unroll 4
-        for (int v = 0; v < 16; ++v) {
-            const U4 r = h4[v];
-            h4[v] = U4{0u, 0u, 0u, 0u};  // cleared for the next draw
-            const unsigned cs[4] = {r.x, r.y, r.z, r.w};
-            unsigned packed[2];
+    unsigned gtot = 0;
+    unsigned gr[SAMP_REP];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned c = cs[q];
-                if (c) kmax_t = 64 * tid + 4 * v + q;
-                if (c >= 65535u) {
-                    const int slot = atomicAdd(&ovf_n, 1);
-                    if (slot < SAMP_TH_OVF) { ovf_key[slot] = 64 * tid + 4 * v + q; ovf_cnt[slot] = c; }
-                    c = 65535u;
+    for (int r = 0; r < SAMP_REP; ++r) { gr[r] = hist0[(size_t)r * SAMP_REP_STRIDE + 65536 + tid]; gtot += gr[r]; }
+    const bool has = gtot != 0u;
+    if (has) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // 32 classes at a time keeps the sums in registers
+            unsigned cs[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) cs[j] = 0u;
+#pragma unroll
+            for (int r = 0; r < SAMP_REP; ++r) {
+                if (gr[r]) {
+                    unsigned* hr = hist0 + (size_t)r * SAMP_REP_STRIDE;
+                    if (half == 1) hr[65536 + tid] = 0u;
+                    U4* h4 = reinterpret_cast<U4*>(hr + 64 * tid + 32 * half);
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        const U4 q = h4[v];
+                        h4[v] = U4{0u, 0u, 0u, 0u};
+                        cs[4 * v] += q.x; cs[4 * v + 1] += q.y; cs[4 * v + 2] += q.z; cs[4 * v + 3] += q.w;
+                    }
                 }
-                if (q & 1) packed[q >> 1] |= c << 16; else packed[q >> 1] = c;
             }
-            row[2 * v] = packed[0];
-            row[2 * v + 1] = packed[1];
+#pragma unroll
+            for (int j = 0; j < 32; j += 2) {
+                const int cj = 32 * half + j;
+                unsigned c0 = cs[j], c1 = cs[j + 1];
+                if (c0) kmax_t = 64 * tid + cj;
+                if (c1) kmax_t = 64 * tid + cj + 1;
+                if (c0 >= 65535u) { const int sl = atomicAdd(&ovf_n, 1); if (sl < SAMP_TH_OVF) { ovf_key[sl] = 64 * tid + cj; ovf_cnt[sl] = c0; } c0 = 65535u; }
+                if (c1 >= 65535u) { const int sl = atomicAdd(&ovf_n, 1); if (sl < SAMP_TH_OVF) { ovf_key[sl] = 64 * tid + cj + 1; ovf_cnt[sl] = c1; } c1 = 65535u; }
+                row[cj >> 1] = c0 | (c1 << 16);
+            }
         }
     }
+    // ---- compact the active groups (ascending) so the arithmetic below is spread over all threads
+    const unsigned long long hb = __ballot(has);
+    if (lane == 0) wact[wave] = __popcll(hb);
     __syncthreads();
-    auto count_of = [&](int j) -> float {  // exact member count of my class j
-        const uint32_t w = row[j >> 1];
-        unsigned c = (j & 1) ? (w >> 16) : (w & 0xffffu);
-        if (c == 65535u) {
-            const unsigned k = 64 * tid + j;
-            for (int i = 0; i < ovf_n && i < SAMP_TH_OVF; ++i) if (ovf_key[i] == k) c = ovf_cnt[i];
-        }
-        return (float)c;
-    };
-    ArgMax km = block_argmax(ArgMax{(float)kmax_t, tid}, red, redi);
+    int abase = 0, n_active = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) abase += wact[w]; n_active += wact[w]; }
+    if (has) AL[abase + __popcll(hb & ((1ull << lane) - 1ull))] = tid;
+    ArgMax km = block_argmax(ArgMax{(float)kmax_t, tid}, red, redi);  // (contains the barriers AL needs)
     const unsigned kmax = (unsigned)(int)km.v;
     const float Lmax = key16_value(kmax);
+    const int n_items = n_active * 64;
+    const int ipt = (n_items + 1023) / 1024;
+    const int i0 = tid * ipt, i1 = min(i0 + ipt, n_items);
+    auto item_count = [&](int i, unsigned& k) -> float {
+        const int g = AL[i >> 6], j = i & 63;
+        k = 64u * g + j;
+        const uint32_t w = cimg[g * SAMP_TH_ROW + (j >> 1)];
+        unsigned c = (j & 1) ? (w >> 16) : (w & 0xffffu);
+        if (c == 65535u)
+            for (int q = 0; q < ovf_n && q < SAMP_TH_OVF; ++q) if (ovf_key[q] == k) c = ovf_cnt[q];
+        return (float)c;
+    };
     float z = 0.f;
-    if (has) for (int j = 0; j < 64; ++j) {
-        const float c = count_of(j);
-        if (c > 0.f) z = fmaf(c, expf(key16_value(64 * tid + j) - Lmax), z);
+    for (int i = i0; i < i1; ++i) {
+        unsigned k;
+        const float c = item_count(i, k);
+        if (c > 0.f) z = fmaf(c, expf(key16_value(k) - Lmax), z);
     }
     const float Z = block_sum(z, red);
     const float tp = round_bf16(ctl.top_p);
     auto removed = [&](float cum) { return round_bf16(cum) > tp; };
     auto prob = [&](unsigned k16) { return round_bf16(expf(key16_value(k16) - Lmax) / Z); };
-    // mass of this thread's classes, then of everything above them (suffix over threads)
     float mt = 0.f;
-    if (has) for (int j = 0; j < 64; ++j) {
-        const float c = count_of(j);
-        if (c > 0.f) mt = fmaf(c, prob(64 * tid + j), mt);
+    for (int i = i0; i < i1; ++i) {
+        unsigned k;
+        const float c = item_count(i, k);
+        if (c > 0.f) mt = fmaf(c, prob(k), mt);
     }
-    float suf = mt;  // inclusive suffix within the wave (lanes >= mine)
+    float suf = mt;  // inclusive suffix within the wave (lanes >= mine own higher classes)
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const float t = __shfl_down(suf, o, 64);
@@ -1451,15 +1494,17 @@ __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
     __syncthreads();
     float above = suf - mt;
     for (int w = wave + 1; w < 16; ++w) above += wsum[w];
-    // walk my classes from the top; the cut is the first class whose inclusive mass is removed
+    // walk my items from the top; the cut is the first class whose inclusive mass is removed
     int found = -1;
+    unsigned f_key = 0;
     float f_above = 0.f, f_cnt = 0.f;
     float run = above;
-    if (has) for (int j = 63; j >= 0; --j) {
-        const float c = count_of(j);
+    for (int i = i1 - 1; i >= i0; --i) {
+        unsigned k;
+        const float c = item_count(i, k);
         if (c > 0.f) {
-            const float nxt = fmaf(c, prob(64 * tid + j), run);
-            if (found < 0 && removed(nxt)) { found = j; f_above = run; f_cnt = c; }
+            const float nxt = fmaf(c, prob(k), run);
+            if (found < 0 && removed(nxt)) { found = i; f_key = k; f_above = run; f_cnt = c; }
             run = nxt;
         }
     }
@@ -1467,15 +1512,14 @@ __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
     if (tid == 0) { cut_s.all_kept = who.v < 0.f ? 1 : 0; cut_s.kstar = 0; cut_s.nk = 0; }
     __syncthreads();
     if (who.v >= 0.f && tid == (int)who.v) {
-        const unsigned ks = 64 * tid + found;
-        const float pk = prob(ks);
+        const float pk = prob(f_key);
         int lo_n = 0, hi_n = (int)f_cnt;
         while (lo_n < hi_n) {
             const int mid = (lo_n + hi_n + 1) >> 1;
             if (removed(fmaf((float)mid, pk, f_above))) hi_n = mid - 1; else lo_n = mid;
         }
-        if (ks == kmax && lo_n < 1) lo_n = 1;  // rank 0 is always kept (inference.py:53)
-        cut_s.kstar = ks;
+        if (f_key == kmax && lo_n < 1) lo_n = 1;  // rank 0 is always kept (inference.py:53)
+        cut_s.kstar = f_key;
         cut_s.nk = lo_n;
     }
     __syncthreads();
@@ -1484,10 +1528,10 @@ __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
     const float Tc = fmaxf(ctl.temperature, 1e-5f);
     const float Mt = round_bf16(Lmax / Tc);
     float z2 = 0.f;
-    if (has) for (int j = 0; j < 64; ++j) {
-        const float c = count_of(j);
+    for (int i = i0; i < i1; ++i) {
+        unsigned k;
+        const float c = item_count(i, k);
         if (c > 0.f) {
-            const unsigned k = 64 * tid + j;
             float n = 0.f;
             if (all_kept || k > kstar) n = c;
             else if (k == kstar) n = (float)nk;

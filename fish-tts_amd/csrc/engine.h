@@ -39,7 +39,9 @@ struct ft_ctx {
     ft_codec_config cc{};
     bool has_codec = false;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool fork_fast0 = true;
     std::string err;
     bool finalized = false;
 

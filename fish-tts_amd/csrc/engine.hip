@@ -175,6 +175,10 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     FT_TRY(dmalloc(ctx, &ctx->samp_part_idx, M * nchunk));
     ctx->force_block_sampler = getenv("FT_SAMPLER_BLOCK") != nullptr;
     ctx->wave_sampler = getenv("FT_SAMPLER_WAVE") != nullptr;
+    ctx->fork_fast0 = getenv("FT_NO_FORK") == nullptr;
+    FT_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    FT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    FT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     FT_HIP(ctx, hipHostMalloc((void**)&ctx->h_pin, (2 * M + 8) * sizeof(int), hipHostMallocDefault));
     return FT_OK;
 }
@@ -239,6 +243,9 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     if (ctx->h_pin) hipHostFree(ctx->h_pin);
     for (auto e : ctx->prof_ev) hipEventDestroy(e);
     codec_destroy(ctx);
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -526,19 +533,25 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
         d.N = c.dim; d.K = c.intermediate_size; d.pro = PRO_NONE; d.epi = EPI_RESID; d.nt = ctx->nt_weights;
         gemv<WT, ROUND>(L, d, rows_per_wave(d.N, L.M));
     }
-    if (!with_head) return;
-    GemvP h{};
-    h.W = ctx->head; h.x = x; h.ldx = c.dim; h.gain = ctx->norm; h.eps = c.norm_eps;
-    h.out = ctx->logits + (size_t)m0 * c.vocab_size; h.ldo = c.vocab_size; h.N = c.vocab_size; h.K = c.dim;
-    h.pro = PRO_RMSNORM; h.epi = EPI_STORE; h.nt = ctx->nt_weights;
-    gemv<WT, ROUND>(L, h, rows_per_wave(h.N, L.M));
     if (c.fast_dim != c.dim) {  // fast_project_in on the pre-norm hidden state (llama.py:453,590)
         GemvP q{};
         q.W = ctx->fproj_w; q.bias = ctx->fproj_b; q.x = x; q.ldx = c.dim;
         q.out = ctx->hid + (size_t)m0 * c.fast_dim; q.ldo = c.fast_dim; q.N = c.fast_dim; q.K = c.dim;
         q.pro = PRO_NONE; q.epi = EPI_STORE;
-        gemv<WT, ROUND>(L, q, rows_per_wave(q.N, L.M));
+        if (with_head) gemv<WT, ROUND>(L, q, rows_per_wave(q.N, L.M));
     }
+}
+
+// final norm + vocabulary head (llama.py:446-451)
+template <typename WT, bool ROUND>
+static void enqueue_head(Launch& L) {
+    ft_ctx* ctx = L.ctx;
+    const ft_ar_config& c = ctx->c;
+    GemvP h{};
+    h.W = ctx->head; h.x = ctx->x + (size_t)L.m0 * c.dim; h.ldx = c.dim; h.gain = ctx->norm; h.eps = c.norm_eps;
+    h.out = ctx->logits + (size_t)L.m0 * c.vocab_size; h.ldo = c.vocab_size; h.N = c.vocab_size; h.K = c.dim;
+    h.pro = PRO_RMSNORM; h.epi = EPI_STORE; h.nt = ctx->nt_weights;
+    gemv<WT, ROUND>(L, h, rows_per_wave(h.N, L.M));
 }
 
 template <typename WT, bool ROUND>
@@ -588,7 +601,7 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
 
 // The fast transformer over codebook positions 0..ncb-1 with its sampling (inference.py:115-149).
 template <typename WT, bool ROUND>
-static void enqueue_fast(Launch& L) {
+static void enqueue_fast_step(Launch& L, const int cb) {
     ft_ctx* ctx = L.ctx;
     const ft_ar_config& c = ctx->c;
     const int m0 = L.m0;
@@ -598,7 +611,7 @@ static void enqueue_fast(Launch& L) {
     float* qkvf = ctx->qkvf + (size_t)m0 * qkvN;
     float* gf = ctx->gf + (size_t)m0 * c.fast_intermediate_size;
     const size_t lds = fast_attn_lds_floats(Hf, Hkvf, hdf, c.num_codebooks) * sizeof(float);
-    for (int cb = 0; cb < c.num_codebooks; ++cb) {
+    {
         const float* xin = cb == 0 ? ctx->hid + (size_t)m0 * Df : ctx->femb + (size_t)m0 * Df;
         for (int li = 0; li < c.n_fast_layer; ++li) {
             const FtLayer& l = ctx->flayers[li];
@@ -643,7 +656,7 @@ static void enqueue_fast(Launch& L) {
             d.N = Df; d.K = c.fast_intermediate_size; d.pro = PRO_NONE; d.epi = EPI_RESID;
             gemv<WT, ROUND>(L, d, rows_per_wave(d.N, L.M));
         }
-        if (cb == 0) continue;  // logits of position 0 are discarded (inference.py:122)
+        if (cb == 0) return;  // logits of position 0 are discarded (inference.py:122)
         GemvP h{};
         h.W = ctx->fast_out; h.x = xf; h.ldx = Df; h.gain = ctx->fast_norm; h.eps = c.norm_eps;
         h.out = ctx->flog + (size_t)m0 * ctx->fastV; h.ldo = ctx->fastV; h.N = ctx->fastV; h.K = Df;
@@ -656,9 +669,27 @@ static void enqueue_fast(Launch& L) {
 // One full frame: slow pass on the current column, semantic sample, fast codebooks (inference.py:83-155).
 template <typename WT, bool ROUND>
 static void enqueue_frame_t(Launch& L, const int* toks, long trs, long tms, int col) {
+    ft_ctx* ctx = L.ctx;
+    const int ncb = ctx->c.num_codebooks;
     enqueue_slow<WT, ROUND>(L, toks, trs, tms, col, true);
-    enqueue_sample<WT, ROUND>(L, 0, L.ctx->c.num_codebooks == 1);
-    if (L.ctx->c.num_codebooks > 1 || true) enqueue_fast<WT, ROUND>(L);
+    // The fast pass at codebook position 0 needs only the hidden state, not the sampled token
+    // (inference.py:121-122): it runs beside the vocabulary head + semantic draw on a second stream
+    // (a forked branch of the captured graph) and joins before position 1.
+    const bool fork = ctx->fork_fast0 && ctx->stream2 != nullptr;
+    if (fork) {
+        hipEventRecord(ctx->ev_fork, L.s);
+        hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
+        Launch L2 = L;
+        L2.s = ctx->stream2;
+        enqueue_fast_step<WT, ROUND>(L2, 0);
+        if (L2.err != hipSuccess) L.err = L2.err;
+        hipEventRecord(ctx->ev_join, ctx->stream2);
+    }
+    enqueue_head<WT, ROUND>(L);
+    enqueue_sample<WT, ROUND>(L, 0, ncb == 1);
+    if (fork) hipStreamWaitEvent(L.s, ctx->ev_join, 0);
+    else enqueue_fast_step<WT, ROUND>(L, 0);
+    for (int cb = 1; cb < ncb; ++cb) enqueue_fast_step<WT, ROUND>(L, cb);
 }
 
 static void enqueue_frame(Launch& L, const int* toks, long trs, long tms, int col) {
