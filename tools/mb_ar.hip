@@ -81,25 +81,28 @@ int main() {
         GemvP p{}; p.W = W; p.x = xin; p.ldx = ldx; p.out = out; p.ldo = ldo; p.N = N; p.K = K; p.pro = pro; p.epi = epi;
         p.gain = gain; p.eps = 1e-6f; p.resid = out; p.ldr = ldo; p.nt = nt; return p;
     };
-    for (int nt = 0; nt < 2; ++nt) {
-        printf("---- nt=%d\n", nt);
-        // 2. each GEMV shape alone, cycling layers
+    {
+        const int nt = 1;
         float us;
-        us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 2>(mk(wqkv[l], x, D, qkv, QKV, QKV, D, PRO_RMSNORM, EPI_STORE, nt), 1); }, L);
-        printf("qkv   N=4096 K=1024 R=2: %.2f us  (%.0f GB/s)\n", us, QKV * D * 2.0 / us / 1e3);
-        us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 1>(mk(wqkv[l], x, D, qkv, QKV, QKV, D, PRO_RMSNORM, EPI_STORE, nt), 1); }, L);
-        printf("qkv   N=4096 K=1024 R=1: %.2f us  (%.0f GB/s)\n", us, QKV * D * 2.0 / us / 1e3);
-        us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 4>(mk(wqkv[l], x, D, qkv, QKV, QKV, D, PRO_RMSNORM, EPI_STORE, nt), 1); }, L);
-        printf("qkv   N=4096 K=1024 R=4: %.2f us  (%.0f GB/s)\n", us, QKV * D * 2.0 / us / 1e3);
+        printf("---- K=1024 shapes: effect of the fused norm and of rows/wave\n");
+        for (int pro = 0; pro < 2; ++pro) {
+            us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 1>(mk(wqkv[l], x, D, qkv, 2048, 2048, D, pro, EPI_STORE, nt), 1); }, L);
+            printf("N=2048 R=1 pro=%d: %.2f us\n", pro, us);
+            us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 2>(mk(wqkv[l], x, D, qkv, 2048, 2048, D, pro, EPI_STORE, nt), 1); }, L);
+            printf("N=2048 R=2 pro=%d: %.2f us\n", pro, us);
+            us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 2>(mk(wqkv[l], x, D, qkv, QKV, QKV, D, pro, EPI_STORE, nt), 1); }, L);
+            printf("N=4096 R=2 pro=%d: %.2f us\n", pro, us);
+            us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 4>(mk(wqkv[l], x, D, qkv, QKV, QKV, D, pro, EPI_STORE, nt), 1); }, L);
+            printf("N=4096 R=4 pro=%d: %.2f us\n", pro, us);
+            us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 2>(mk(w13[l], x, D, g, FF, 2 * FF, D, pro, EPI_SWIGLU, nt), 1); }, L);
+            printf("N=6144 R=2 swiglu pro=%d: %.2f us\n", pro, us);
+            us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 4>(mk(w13[l], x, D, g, FF, 2 * FF, D, pro, EPI_SWIGLU, nt), 1); }, L);
+            printf("N=6144 R=4 swiglu pro=%d: %.2f us\n", pro, us);
+        }
         us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<4, 1>(mk(wo[l], y, 2048, x, D, D, 2048, PRO_NONE, EPI_RESID, nt), 1); }, L);
-        printf("wo    N=1024 K=2048 R=1: %.2f us  (%.0f GB/s)\n", us, D * 2048 * 2.0 / us / 1e3);
-        us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 2>(mk(w13[l], x, D, g, FF, 2 * FF, D, PRO_RMSNORM, EPI_SWIGLU, nt), 1); }, L);
-        printf("w13   N=6144 K=1024 R=2: %.2f us  (%.0f GB/s)\n", us, 2.0 * FF * D * 2.0 / us / 1e3);
-        us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<2, 4>(mk(w13[l], x, D, g, FF, 2 * FF, D, PRO_RMSNORM, EPI_SWIGLU, nt), 1); }, L);
-        printf("w13   N=6144 K=1024 R=4: %.2f us  (%.0f GB/s)\n", us, 2.0 * FF * D * 2.0 / us / 1e3);
+        printf("wo    N=1024 K=2048 R=1: %.2f us\n", us);
         us = time_graph([&] { for (int l = 0; l < L; ++l) launch_gemv<6, 1>(mk(w2[l], g, FF, x, D, D, FF, PRO_NONE, EPI_RESID, nt), 1); }, L);
-        printf("w2    N=1024 K=3072 R=1: %.2f us  (%.0f GB/s)\n", us, D * FF * 2.0 / us / 1e3);
-        // 3. the four GEMVs of a layer in sequence over all layers
+        printf("w2    N=1024 K=3072 R=1: %.2f us\n", us);
         us = time_graph([&] {
             for (int l = 0; l < L; ++l) {
                 launch_gemv<2, 2>(mk(wqkv[l], x, D, qkv, QKV, QKV, D, PRO_RMSNORM, EPI_STORE, nt), 1);
