@@ -79,6 +79,12 @@ __device__ __forceinline__ void gemv_finish(const GemvP& p, const int m, const i
 
     if (p.pro == PRO_RMSNORM) {
         const WT* gain = reinterpret_cast<const WT*>(p.gain);
+        U4 graw[NT];  // gains are fetched before the reduction so their latency overlaps it
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int k = t * TILE + lane * VEC;
+            graw[t] = k < K ? *reinterpret_cast<const U4*>(gain + k) : U4{0u, 0u, 0u, 0u};
+        }
         float ss = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -88,13 +94,10 @@ __device__ __forceinline__ void gemv_finish(const GemvP& p, const int m, const i
         const float inv = rsqrt_exact(ss / (float)K + p.eps);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int k = t * TILE + lane * VEC;
-            if (k < K) {
-                float gv[VEC];
-                Vec<WT>::load(gain + k, gv);
+            float gv[VEC];
+            Vec<WT>::unpack(graw[t], gv);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) xv[t][j] = rb<ROUND>(rb<ROUND>(xv[t][j] * inv) * gv[j]);
-            }
+            for (int j = 0; j < VEC; ++j) xv[t][j] = rb<ROUND>(rb<ROUND>(xv[t][j] * inv) * gv[j]);
         }
     }
 
@@ -467,10 +470,70 @@ __device__ __forceinline__ void fast_attention_to_lds(const FastAttnP& a, const 
     const WT* kn = reinterpret_cast<const WT*>(a.kn);
     WT* kc = reinterpret_cast<WT*>(a.kc) + (size_t)m * a.cache_m_stride;
     WT* vc = reinterpret_cast<WT*>(a.vc) + (size_t)m * a.cache_m_stride;
-    // cached positions j < c: one coalesced sweep HBM/L2 -> LDS (8 elements per thread per step)
+    // every global load of the prologue is issued before anything is consumed (one L2 round trip):
+    // cached K/V positions j < c (8 elements per 16-byte piece), the q/k rotation pairs, the new v
+    constexpr int MAXV = 4, MAXP = 4;
+    const int per_head = c * hd;  // valid cached elements per kv head (positions 0..c-1 are contiguous)
+    const int vecs = per_head >> 3;
+    const int nvec = Hkv * vecs, npair = (H + Hkv) * hp, nv = Hkv * hd;
+    const bool fits = nvec <= MAXV * 256 && npair <= MAXP * 256 && nv <= MAXP * 256 && !qn && !kn;
+    if (fits) {
+        float kv[MAXV][8], vv[MAXV][8];
+        float px0[MAXP], px1[MAXP], pcs[MAXP], psn[MAXP], pv[MAXP];
+#pragma unroll
+        for (int u = 0; u < MAXV; ++u) {
+            const int i = tid + 256 * u;
+            if (i < nvec) {
+                const int kvh = i / vecs, o = (i % vecs) << 3;
+                const size_t g = (size_t)kvh * ncb * hd + o;
+                if constexpr (sizeof(WT) == 2) {
+                    Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(kc) + g, kv[u]);
+                    Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(vc) + g, vv[u]);
+                } else {
+                    const float* kf = reinterpret_cast<const float*>(kc) + g;
+                    const float* vf = reinterpret_cast<const float*>(vc) + g;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { kv[u][e] = kf[e]; vv[u][e] = vf[e]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MAXP; ++u) {
+            const int pi = tid + 256 * u;
+            if (pi < npair) {
+                const int item = pi / hp, i = pi % hp;
+                px0[u] = qkv[(size_t)item * hd + 2 * i];
+                px1[u] = qkv[(size_t)item * hd + 2 * i + 1];
+                pcs[u] = a.rope[((size_t)c * hp + i) * 2];
+                psn[u] = a.rope[((size_t)c * hp + i) * 2 + 1];
+            }
+            const int e = tid + 256 * u;
+            if (e < nv) pv[u] = qkv[(size_t)(H + Hkv) * hd + e];
+        }
+#pragma unroll
+        for (int u = 0; u < MAXV; ++u) {
+            const int i = tid + 256 * u;
+            if (i < nvec) {
+                const int kvh = i / vecs, o = (i % vecs) << 3;
+                const size_t g = (size_t)kvh * ncb * hd + o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { kL[g + e] = kv[u][e]; vL[g + e] = vv[u][e]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MAXP; ++u) {
+            const int pi = tid + 256 * u;
+            if (pi < npair) {
+                const int item = pi / hp, i = pi % hp;
+                float* dst = item < H ? q_s + item * hd : kL + ((size_t)(item - H) * ncb + c) * hd;
+                dst[2 * i] = rb<ROUND>(px0[u] * pcs[u] - px1[u] * psn[u]);
+                dst[2 * i + 1] = rb<ROUND>(px1[u] * pcs[u] + px0[u] * psn[u]);
+            }
+            const int e = tid + 256 * u;
+            if (e < nv) vL[((size_t)(e / hd) * ncb + c) * hd + (e % hd)] = pv[u];
+        }
+    } else {
     {
-        const int per_head = c * hd;  // valid elements per kv head (positions 0..c-1 are contiguous)
-        const int vecs = per_head >> 3;
         for (int i = tid; i < Hkv * vecs; i += 256) {
             const int kvh = i / vecs, o = (i % vecs) << 3;
             float kv[8], vv[8];
@@ -490,7 +553,6 @@ __device__ __forceinline__ void fast_attention_to_lds(const FastAttnP& a, const 
     }
     // new q (all heads), new k -> slot c of kL, new v -> slot c of vL
     if (!qn && !kn) {
-        // no per-head norm (the s1-mini fast stack): every rotation pair is independent
         for (int pi = tid; pi < (H + Hkv) * hp; pi += 256) {
             const int item = pi / hp, i = pi % hp;
             const float x0 = qkv[(size_t)item * hd + 2 * i], x1 = qkv[(size_t)item * hd + 2 * i + 1];
@@ -524,6 +586,7 @@ __device__ __forceinline__ void fast_attention_to_lds(const FastAttnP& a, const 
     for (int e = tid; e < Hkv * hd; e += 256) {
         const int kvh = e / hd, d = e % hd;
         vL[((size_t)kvh * ncb + c) * hd + d] = qkv[(size_t)(H + Hkv) * hd + e];
+    }
     }
     __syncthreads();
     if (blockIdx.x == 0) {  // KV-cache append (llama.py:142-149) by one block
