@@ -452,216 +452,105 @@ struct FastAttnP {
 
 constexpr int FAST_MAXCB = 16;
 
-// LDS carve (floats): y_s[H*hd] | q_s[H*hd] | kL[Hkv*ncb*hd] | vL[Hkv*ncb*hd]
-__host__ __device__ inline size_t fast_attn_lds_floats(int H, int Hkv, int hd, int ncb) {
-    return (size_t)2 * H * hd + (size_t)2 * Hkv * ncb * hd;
-}
-
+// One wave per query head: lane d owns dimension d (hd <= 64) or dimensions d and d+64 (hd = 128).
+// All K/V rows of the <= num_codebooks cached positions are fetched in one round trip.
 template <typename WT, bool ROUND>
-__device__ __forceinline__ void fast_attention_to_lds(const FastAttnP& a, const int m, float* smem) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(64) void fast_attn_kernel(FastAttnP a, float* y, int ldy) {
+    const int h = blockIdx.x, m = blockIdx.y, lane = threadIdx.x;
     const int hd = a.hd, hp = hd >> 1, H = a.H, Hkv = a.Hkv, G = H / Hkv, c = a.c, ncb = a.ncb;
-    float* y_s = smem;
-    float* q_s = y_s + H * hd;
-    float* kL = q_s + H * hd;            // [Hkv][ncb][hd]
-    float* vL = kL + Hkv * ncb * hd;
+    const int kvh = h / G;
     const float* qkv = a.qkv + (size_t)m * a.ldq;
     const WT* qn = reinterpret_cast<const WT*>(a.qn);
     const WT* kn = reinterpret_cast<const WT*>(a.kn);
-    WT* kc = reinterpret_cast<WT*>(a.kc) + (size_t)m * a.cache_m_stride;
-    WT* vc = reinterpret_cast<WT*>(a.vc) + (size_t)m * a.cache_m_stride;
-    // every global load of the prologue is issued before anything is consumed (one L2 round trip):
-    // cached K/V positions j < c (8 elements per 16-byte piece), the q/k rotation pairs, the new v
-    constexpr int MAXV = 4, MAXP = 4;
-    const int per_head = c * hd;  // valid cached elements per kv head (positions 0..c-1 are contiguous)
-    const int vecs = per_head >> 3;
-    const int nvec = Hkv * vecs, npair = (H + Hkv) * hp, nv = Hkv * hd;
-    const bool fits = nvec <= MAXV * 256 && npair <= MAXP * 256 && nv <= MAXP * 256 && !qn && !kn;
-    if (fits) {
-        float kv[MAXV][8], vv[MAXV][8];
-        float px0[MAXP], px1[MAXP], pcs[MAXP], psn[MAXP], pv[MAXP];
+    WT* kc = reinterpret_cast<WT*>(a.kc) + (size_t)m * a.cache_m_stride + (size_t)kvh * ncb * hd;
+    WT* vc = reinterpret_cast<WT*>(a.vc) + (size_t)m * a.cache_m_stride + (size_t)kvh * ncb * hd;
+    constexpr int EPL = 2;  // dims per lane: d = lane + 64 e, valid while d < hd
+    // issue every load first: cached rows, the new q/k/v, the rotation entries, the norm gains
+    float kj[FAST_MAXCB][EPL], vj[FAST_MAXCB][EPL];
 #pragma unroll
-        for (int u = 0; u < MAXV; ++u) {
-            const int i = tid + 256 * u;
-            if (i < nvec) {
-                const int kvh = i / vecs, o = (i % vecs) << 3;
-                const size_t g = (size_t)kvh * ncb * hd + o;
-                if constexpr (sizeof(WT) == 2) {
-                    Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(kc) + g, kv[u]);
-                    Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(vc) + g, vv[u]);
-                } else {
-                    const float* kf = reinterpret_cast<const float*>(kc) + g;
-                    const float* vf = reinterpret_cast<const float*>(vc) + g;
+    for (int j = 0; j < FAST_MAXCB; ++j)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { kv[u][e] = kf[e]; vv[u][e] = vf[e]; }
-                }
-            }
+        for (int e = 0; e < EPL; ++e) {
+            const int d = lane + 64 * e;
+            const bool on = j < c && d < hd;
+            kj[j][e] = on ? ld_elem(kc, (size_t)j * hd + d) : 0.f;
+            vj[j][e] = on ? ld_elem(vc, (size_t)j * hd + d) : 0.f;
         }
+    float q[EPL], kx[EPL], vx[EPL], cs[EPL], sn[EPL], gq[EPL], gk[EPL];
 #pragma unroll
-        for (int u = 0; u < MAXP; ++u) {
-            const int pi = tid + 256 * u;
-            if (pi < npair) {
-                const int item = pi / hp, i = pi % hp;
-                px0[u] = qkv[(size_t)item * hd + 2 * i];
-                px1[u] = qkv[(size_t)item * hd + 2 * i + 1];
-                pcs[u] = a.rope[((size_t)c * hp + i) * 2];
-                psn[u] = a.rope[((size_t)c * hp + i) * 2 + 1];
-            }
-            const int e = tid + 256 * u;
-            if (e < nv) pv[u] = qkv[(size_t)(H + Hkv) * hd + e];
-        }
+    for (int e = 0; e < EPL; ++e) {
+        const int d = lane + 64 * e;
+        const bool on = d < hd;
+        q[e] = on ? qkv[(size_t)h * hd + d] : 0.f;
+        kx[e] = on ? qkv[(size_t)(H + kvh) * hd + d] : 0.f;
+        vx[e] = on ? qkv[(size_t)(H + Hkv + kvh) * hd + d] : 0.f;
+        cs[e] = on ? a.rope[((size_t)c * hp + (d >> 1)) * 2] : 1.f;
+        sn[e] = on ? a.rope[((size_t)c * hp + (d >> 1)) * 2 + 1] : 0.f;
+        gq[e] = (on && qn) ? ld_elem(qn, d) : 1.f;
+        gk[e] = (on && kn) ? ld_elem(kn, d) : 1.f;
+    }
+    if (qn) {  // per-head nn.RMSNorm, one rounding (llama.py:207-209)
+        const float ss = wave_sum(q[0] * q[0] + q[1] * q[1]);
+        const float inv = rsqrt_exact(ss / (float)hd + a.eps);
 #pragma unroll
-        for (int u = 0; u < MAXV; ++u) {
-            const int i = tid + 256 * u;
-            if (i < nvec) {
-                const int kvh = i / vecs, o = (i % vecs) << 3;
-                const size_t g = (size_t)kvh * ncb * hd + o;
+        for (int e = 0; e < EPL; ++e) q[e] = rb<ROUND>((q[e] * inv) * gq[e]);
+    }
+    if (kn) {
+        const float ss = wave_sum(kx[0] * kx[0] + kx[1] * kx[1]);
+        const float inv = rsqrt_exact(ss / (float)hd + a.eps);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { kL[g + e] = kv[u][e]; vL[g + e] = vv[u][e]; }
-            }
-        }
+        for (int e = 0; e < EPL; ++e) kx[e] = rb<ROUND>((kx[e] * inv) * gk[e]);
+    }
+    // interleaved-pair rotation: the partner element sits in the neighbouring lane
 #pragma unroll
-        for (int u = 0; u < MAXP; ++u) {
-            const int pi = tid + 256 * u;
-            if (pi < npair) {
-                const int item = pi / hp, i = pi % hp;
-                float* dst = item < H ? q_s + item * hd : kL + ((size_t)(item - H) * ncb + c) * hd;
-                dst[2 * i] = rb<ROUND>(px0[u] * pcs[u] - px1[u] * psn[u]);
-                dst[2 * i + 1] = rb<ROUND>(px1[u] * pcs[u] + px0[u] * psn[u]);
-            }
-            const int e = tid + 256 * u;
-            if (e < nv) vL[((size_t)(e / hd) * ncb + c) * hd + (e % hd)] = pv[u];
-        }
-    } else {
-    {
-        for (int i = tid; i < Hkv * vecs; i += 256) {
-            const int kvh = i / vecs, o = (i % vecs) << 3;
-            float kv[8], vv[8];
-            const size_t g = (size_t)kvh * ncb * hd + o;
-            if constexpr (sizeof(WT) == 2) {
-                Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(kc) + g, kv);
-                Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(vc) + g, vv);
-            } else {
-                const float* kf = reinterpret_cast<const float*>(kc) + g;
-                const float* vf = reinterpret_cast<const float*>(vc) + g;
+    for (int e = 0; e < EPL; ++e) {
+        const float qo = dpp_f<DPP_XOR1>(q[e]), ko = dpp_f<DPP_XOR1>(kx[e]);
+        const bool even = (lane & 1) == 0;
+        // even lane holds x0: x0*c - x1*s ; odd lane holds x1: x1*c + x0*s
+        q[e] = rb<ROUND>(even ? q[e] * cs[e] - qo * sn[e] : q[e] * cs[e] + qo * sn[e]);
+        kx[e] = rb<ROUND>(even ? kx[e] * cs[e] - ko * sn[e] : kx[e] * cs[e] + ko * sn[e]);
+    }
+    if (h % G == 0) {  // one head of the group appends to the KV cache (llama.py:142-149)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { kv[e] = kf[e]; vv[e] = vf[e]; }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { kL[g + e] = kv[e]; vL[g + e] = vv[e]; }
+        for (int e = 0; e < EPL; ++e) {
+            const int d = lane + 64 * e;
+            if (d < hd) { st_elem(kc, (size_t)c * hd + d, kx[e]); st_elem(vc, (size_t)c * hd + d, vx[e]); }
         }
     }
-    // new q (all heads), new k -> slot c of kL, new v -> slot c of vL
-    if (!qn && !kn) {
-        for (int pi = tid; pi < (H + Hkv) * hp; pi += 256) {
-            const int item = pi / hp, i = pi % hp;
-            const float x0 = qkv[(size_t)item * hd + 2 * i], x1 = qkv[(size_t)item * hd + 2 * i + 1];
-            const float cs = a.rope[((size_t)c * hp + i) * 2], sn = a.rope[((size_t)c * hp + i) * 2 + 1];
-            float* dst = item < H ? q_s + item * hd : kL + ((size_t)(item - H) * ncb + c) * hd;
-            dst[2 * i] = rb<ROUND>(x0 * cs - x1 * sn);
-            dst[2 * i + 1] = rb<ROUND>(x1 * cs + x0 * sn);
-        }
-    } else
-    for (int item = wave; item < H + Hkv; item += 4) {
-        const float* src = qkv + (size_t)item * hd;
-        const WT* gain = item < H ? qn : kn;
-        float* dst = item < H ? q_s + item * hd : kL + ((size_t)(item - H) * ncb + c) * hd;
-        float x0 = 0.f, x1 = 0.f;
-        if (lane < hp) { x0 = src[2 * lane]; x1 = src[2 * lane + 1]; }
-        if (gain) {
-            const float ss = wave_sum(x0 * x0 + x1 * x1);
-            const float inv = rsqrt_exact(ss / (float)hd + a.eps);
-            if (lane < hp) {
-                x0 = rb<ROUND>((x0 * inv) * ld_elem(gain, 2 * lane));
-                x1 = rb<ROUND>((x1 * inv) * ld_elem(gain, 2 * lane + 1));
-            }
-        }
-        if (lane < hp) {
-            const float cs = a.rope[((size_t)c * hp + lane) * 2];
-            const float sn = a.rope[((size_t)c * hp + lane) * 2 + 1];
-            dst[2 * lane] = rb<ROUND>(x0 * cs - x1 * sn);
-            dst[2 * lane + 1] = rb<ROUND>(x1 * cs + x0 * sn);
+    // scores with the three roundings of the explicit path (llama.py:304-309)
+    float s[FAST_MAXCB];
+#pragma unroll
+    for (int j = 0; j < FAST_MAXCB; ++j) {
+        if (j <= c) {  // c is uniform: a scalar branch
+            const float k0 = j == c ? kx[0] : kj[j][0], k1 = j == c ? kx[1] : kj[j][1];
+            const float d = wave_sum(fmaf(q[1], k1, q[0] * k0));
+            s[j] = rb<ROUND>(rb<ROUND>(d) * a.scale);
+        } else {
+            s[j] = -INFINITY;
         }
     }
-    for (int e = tid; e < Hkv * hd; e += 256) {
-        const int kvh = e / hd, d = e % hd;
-        vL[((size_t)kvh * ncb + c) * hd + d] = qkv[(size_t)(H + Hkv) * hd + e];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < FAST_MAXCB; ++j) mx = fmaxf(mx, s[j]);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < FAST_MAXCB; ++j) {
+        if (j <= c) { s[j] = expf(s[j] - mx); sum += s[j]; } else s[j] = 0.f;
     }
-    }
-    __syncthreads();
-    if (blockIdx.x == 0) {  // KV-cache append (llama.py:142-149) by one block
-        for (int e = tid; e < Hkv * hd; e += 256) {
-            const int kvh = e / hd, d = e % hd;
-            const size_t g = ((size_t)kvh * ncb + c) * hd + d;
-            st_elem(kc, g, kL[g]);
-            st_elem(vc, g, vL[g]);
-        }
-    }
-    // 16 lanes per head, EPT = hd/16 dims per lane; everything below reads LDS only
-    const int EPT = hd >> 4;
-    const int sub = tid & 15;
-    for (int h0 = 0; h0 < H; h0 += 16) {
-        const int h = h0 + (tid >> 4);
-        const bool hv = h < H;
-        const int kvh = hv ? h / G : 0;
-        const float* kh = kL + (size_t)kvh * ncb * hd;
-        const float* vh = vL + (size_t)kvh * ncb * hd;
-        float s[FAST_MAXCB];
+    float o[EPL] = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < FAST_MAXCB; ++j) {
-            float d = 0.f;
-            if (hv && j <= c)
-                for (int e = 0; e < EPT; ++e) {
-                    const int dd = sub * EPT + e;
-                    d = fmaf(q_s[h * hd + dd], kh[j * hd + dd], d);
-                }
-            s[j] = d;
-        }
-#pragma unroll
-        for (int j = 0; j < FAST_MAXCB; ++j) {
-            const float d = row16_sum(s[j]);
-            s[j] = (j <= c) ? rb<ROUND>(rb<ROUND>(d) * a.scale) : -INFINITY;
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < FAST_MAXCB; ++j) mx = fmaxf(mx, s[j]);
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < FAST_MAXCB; ++j) {
-            if (j <= c) { s[j] = expf(s[j] - mx); sum += s[j]; } else s[j] = 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < FAST_MAXCB; ++j) if (j <= c) s[j] = rb<ROUND>(s[j] / sum);
-        if (hv) {
-            for (int e = 0; e < EPT; ++e) {
-                const int dd = sub * EPT + e;
-                float o = 0.f;
-#pragma unroll
-                for (int j = 0; j < FAST_MAXCB; ++j)
-                    if (j <= c) o = fmaf(s[j], vh[j * hd + dd], o);
-                y_s[h * hd + dd] = rb<ROUND>(o);
-            }
+    for (int j = 0; j < FAST_MAXCB; ++j) {
+        if (j <= c) {
+            const float pj = rb<ROUND>(s[j] / sum);
+            o[0] = fmaf(pj, j == c ? vx[0] : vj[j][0], o[0]);
+            o[1] = fmaf(pj, j == c ? vx[1] : vj[j][1], o[1]);
         }
     }
-    __syncthreads();
-}
-
-template <typename WT, int NT, int R, bool ROUND>
-__global__ __launch_bounds__(256) void fast_attn_wo_kernel(GemvP p, FastAttnP a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int m = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
-    U4 raw[R][NT];
-    gemv_issue<WT, NT, R>(p, row0, lane, raw);  // Wo rows are in flight while the attention is rebuilt
-    fast_attention_to_lds<WT, ROUND>(a, m, smem);
-    if (row0 >= p.N) return;
-    constexpr int VEC = Vec<WT>::N;
-    const float* y_s = smem;
-    gemv_finish<WT, NT, R, ROUND>(p, m, row0, lane, raw, [&](int k, float(&v)[VEC]) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) v[j] = y_s[k + j];
-    });
+    for (int e = 0; e < EPL; ++e) {
+        const int d = lane + 64 * e;
+        if (d < hd) y[(size_t)m * ldy + (size_t)h * hd + d] = rb<ROUND>(o[e]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

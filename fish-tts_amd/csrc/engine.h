@@ -58,7 +58,7 @@ struct ft_ctx {
     float *x = nullptr, *qkv = nullptr, *y = nullptr, *g = nullptr, *logits = nullptr, *hid = nullptr,
           *femb = nullptr, *xf = nullptr, *qkvf = nullptr, *gf = nullptr, *flog = nullptr, *part_o = nullptr,
           *part_ml = nullptr;
-    int n_slots = 0, nsplit = 1, cap = 0, fastV = 0;
+    int n_slots = 0, nsplit = 1, cap = 0, fastV = 0, y_ld = 0;
     size_t cache_m_stride = 0, fcache_m_stride = 0;
 
     // per-slot state

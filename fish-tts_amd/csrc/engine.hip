@@ -4,6 +4,8 @@
 #include "ar_kernels.h"
 
 #include <math.h>
+
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -134,7 +136,8 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     const size_t fqkvN = (size_t)(c.fast_n_head + 2 * c.fast_n_local_heads) * c.fast_head_dim;
     FT_TRY(dmalloc(ctx, &ctx->x, M * c.dim));
     FT_TRY(dmalloc(ctx, &ctx->qkv, M * qkvN));
-    FT_TRY(dmalloc(ctx, &ctx->y, M * c.n_head * c.head_dim));
+    ctx->y_ld = std::max(c.n_head * c.head_dim, c.fast_n_head * c.fast_head_dim);
+    FT_TRY(dmalloc(ctx, &ctx->y, M * (size_t)ctx->y_ld));
     FT_TRY(dmalloc(ctx, &ctx->g, M * c.intermediate_size));
     FT_TRY(dmalloc(ctx, &ctx->logits, M * c.vocab_size));
     if (c.fast_dim != c.dim) FT_TRY(dmalloc(ctx, &ctx->hid, M * c.fast_dim));
@@ -420,14 +423,6 @@ static int rows_per_wave(int N, int M) {
     return 1;
 }
 
-template <typename WT, bool ROUND, int R>
-static void fast_attn_wo_nt(Launch& L, const GemvP& p, const FastAttnP& a, int nt, size_t lds) {
-    const dim3 grid((p.N + 4 * R - 1) / (4 * R), L.M), block(256);
-#define FT_NT(n) case n: fast_attn_wo_kernel<WT, n, R, ROUND><<<grid, block, lds, L.s>>>(p, a); break;
-    switch (nt) { FT_NT(1) FT_NT(2) FT_NT(3) FT_NT(4) FT_NT(6) FT_NT(8) FT_NT(12) default: L.err = hipErrorInvalidValue; }
-#undef FT_NT
-}
-
 template <typename WT, bool ROUND>
 static void attn_decode(Launch& L, const AttnP& p) {
     ft_ctx* ctx = L.ctx;
@@ -472,7 +467,7 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
     const size_t qkvN = (size_t)(c.n_head + 2 * c.n_local_heads) * c.head_dim;
     float* x = ctx->x + (size_t)m0 * c.dim;
     float* qkv = ctx->qkv + (size_t)m0 * qkvN;
-    float* y = ctx->y + (size_t)m0 * c.n_head * c.head_dim;
+    float* y = ctx->y + (size_t)m0 * ctx->y_ld;
     float* g = ctx->g + (size_t)m0 * c.intermediate_size;
 
     EmbedP e{};
@@ -498,13 +493,13 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
         a.cache_m_stride = ctx->cache_m_stride; a.pos = ctx->d_pos + m0; a.pos_off = L.pos_off;
         a.H = c.n_head; a.Hkv = c.n_local_heads; a.hd = c.head_dim; a.n_slots = ctx->n_slots;
         a.nsplit = ctx->nsplit; a.eps = c.norm_eps; a.scale = 1.0f / sqrtf((float)c.head_dim);
-        a.y = y; a.ldy = c.n_head * c.head_dim;
+        a.y = y; a.ldy = ctx->y_ld;
         a.part_o = ctx->part_o + (size_t)m0 * c.n_head * ctx->nsplit * c.head_dim;
         a.part_ml = ctx->part_ml + (size_t)m0 * c.n_head * ctx->nsplit * 2;
         attn_decode<WT, ROUND>(L, a);
 
         GemvP o{};
-        o.W = l.wo; o.bias = l.bo; o.x = y; o.ldx = c.n_head * c.head_dim; o.out = x; o.ldo = c.dim;
+        o.W = l.wo; o.bias = l.bo; o.x = y; o.ldx = ctx->y_ld; o.out = x; o.ldo = c.dim;
         o.resid = x; o.ldr = c.dim; o.N = c.dim; o.K = c.n_head * c.head_dim; o.pro = PRO_NONE; o.epi = EPI_RESID; o.nt = ctx->nt_weights;
         if (ctx->nsplit > 1) {  // split-KV partials are merged inside the Wo kernel
             const int nt = pick_nt(o.K, Vec<WT>::N);
@@ -610,7 +605,6 @@ static void enqueue_fast_step(Launch& L, const int cb) {
     float* xf = ctx->xf + (size_t)m0 * Df;
     float* qkvf = ctx->qkvf + (size_t)m0 * qkvN;
     float* gf = ctx->gf + (size_t)m0 * c.fast_intermediate_size;
-    const size_t lds = fast_attn_lds_floats(Hf, Hkvf, hdf, c.num_codebooks) * sizeof(float);
     {
         const float* xin = cb == 0 ? ctx->hid + (size_t)m0 * Df : ctx->femb + (size_t)m0 * Df;
         for (int li = 0; li < c.n_fast_layer; ++li) {
@@ -621,29 +615,19 @@ static void enqueue_fast_step(Launch& L, const int cb) {
             p.out = qkvf; p.ldo = (int)qkvN; p.N = (int)qkvN; p.K = Df; p.pro = PRO_RMSNORM; p.epi = EPI_STORE;
             gemv<WT, ROUND>(L, p, rows_per_wave(p.N, L.M));
 
-            GemvP o{};
-            o.W = l.wo; o.bias = l.bo; o.out = xf; o.ldo = Df; o.resid = xl; o.ldr = Df; o.N = Df; o.K = Hf * hdf;
-            o.pro = PRO_NONE; o.epi = EPI_RESID;
             FastAttnP a{};
             a.qkv = qkvf; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->frope;
             a.kc = (char*)l.kc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
             a.vc = (char*)l.vc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
             a.cache_m_stride = ctx->fcache_m_stride; a.c = cb; a.H = Hf; a.Hkv = Hkvf; a.hd = hdf;
             a.ncb = c.num_codebooks; a.eps = c.norm_eps; a.scale = (float)(1.0 / sqrt((double)hdf));
-            {
-                const int nt = pick_nt(o.K, Vec<WT>::N);
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (ctx->prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, L.s); }
-                if (rows_per_wave(o.N, L.M) >= 2) fast_attn_wo_nt<WT, ROUND, 2>(L, o, a, nt, lds);
-                else fast_attn_wo_nt<WT, ROUND, 1>(L, o, a, nt, lds);
-                if (ctx->prof) {
-                    hipEventRecord(e1, L.s);
-                    ctx->prof_ev.push_back(e0); ctx->prof_ev.push_back(e1);
-                    ctx->prof_bytes += (int64_t)o.N * o.K * sizeof(WT);
-                    ctx->prof_launches += 1;
-                }
-                L.chk();
-            }
+            float* yf = ctx->y + (size_t)m0 * ctx->y_ld;  // the slow attention's y buffer is free here
+            fast_attn_kernel<WT, ROUND><<<dim3(Hf, L.M), 64, 0, L.s>>>(a, yf, ctx->y_ld);
+            L.chk();
+            GemvP o{};
+            o.W = l.wo; o.bias = l.bo; o.x = yf; o.ldx = ctx->y_ld; o.out = xf; o.ldo = Df; o.resid = xl;
+            o.ldr = Df; o.N = Df; o.K = Hf * hdf; o.pro = PRO_NONE; o.epi = EPI_RESID;
+            gemv<WT, ROUND>(L, o, rows_per_wave(o.N, L.M));
 
             GemvP f{};
             f.W = l.w13; f.x = xf; f.ldx = Df; f.gain = l.ffn_norm; f.eps = c.norm_eps; f.out = gf;
