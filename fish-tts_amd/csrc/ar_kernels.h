@@ -253,6 +253,32 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     const float* qkv = p.qkv + (size_t)m * p.ldq;
     const WT* qn = reinterpret_cast<const WT*>(p.qn);
     const WT* kn = reinterpret_cast<const WT*>(p.kn);
+    const int chunk = (pos + p.nsplit) / p.nsplit;  // ceil((pos+1)/nsplit)
+    const int lo = split * chunk;
+    const int hi = min(lo + chunk, pos + 1);
+    WT* kc = reinterpret_cast<WT*>(p.kc) + (size_t)m * p.cache_m_stride + (size_t)kvh * p.n_slots * hd;
+    WT* vc = reinterpret_cast<WT*>(p.vc) + (size_t)m * p.cache_m_stride + (size_t)kvh * p.n_slots * hd;
+    const int grp = lane / LPP, gl = lane % LPP;
+    const int slot = wave * PPW + grp;
+    auto load_kv = [&](int j, float(&kv)[8], float(&vv)[8]) {
+        if constexpr (sizeof(WT) == 2) {
+            Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(kc) + (size_t)j * hd + gl * 8, kv);
+            Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(vc) + (size_t)j * hd + gl * 8, vv);
+        } else {
+            const float* kf = reinterpret_cast<const float*>(kc) + (size_t)j * hd + gl * 8;
+            const float* vf = reinterpret_cast<const float*>(vc) + (size_t)j * hd + gl * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kv[e] = kf[e]; vv[e] = vf[e]; }
+        }
+    };
+    // the first K/V rows of this lane group are requested now, so they travel while q/k/v are built
+    float kpre[8], vpre[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { kpre[e] = 0.f; vpre[e] = 0.f; }
+    {
+        const int j = lo + wave * PPW + grp;
+        if (j < hi && j != pos) load_kv(j, kpre, vpre);
+    }
 
     // phase 1: q heads of this group, new k, new v
     for (int item = wave; item < G + 2; item += 4) {
@@ -285,11 +311,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     }
     __syncthreads();
 
-    const int chunk = (pos + p.nsplit) / p.nsplit;  // ceil((pos+1)/nsplit)
-    const int lo = split * chunk;
-    const int hi = min(lo + chunk, pos + 1);
-    WT* kc = reinterpret_cast<WT*>(p.kc) + (size_t)m * p.cache_m_stride + (size_t)kvh * p.n_slots * hd;
-    WT* vc = reinterpret_cast<WT*>(p.vc) + (size_t)m * p.cache_m_stride + (size_t)kvh * p.n_slots * hd;
     if (pos >= lo && pos < hi) {
         for (int e = tid; e < hd; e += 256) {
             st_elem(kc, (size_t)pos * hd + e, k_new[e]);
@@ -298,8 +319,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     }
 
     // phase 2: this block's share of the cached positions
-    const int grp = lane / LPP, gl = lane % LPP;
-    const int slot = wave * PPW + grp;
     float qr[G][8];
 #pragma unroll
     for (int g = 0; g < G; ++g)
@@ -312,28 +331,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
     }
+    bool first = true;
     for (int base = lo + wave * PPW; base < hi; base += NSLOT) {
         const int j = base + grp;
         const bool valid = j < hi;
         float kv[8], vv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { kv[e] = 0.f; vv[e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { kv[e] = kpre[e]; vv[e] = vpre[e]; }
         if (valid) {
             if (j == pos) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { kv[e] = k_new[gl * 8 + e]; vv[e] = v_new[gl * 8 + e]; }
-            } else {
-                if constexpr (sizeof(WT) == 2) {
-                    Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(kc) + (size_t)j * hd + gl * 8, kv);
-                    Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(vc) + (size_t)j * hd + gl * 8, vv);
-                } else {
-                    const float* kf = reinterpret_cast<const float*>(kc) + (size_t)j * hd + gl * 8;
-                    const float* vf = reinterpret_cast<const float*>(vc) + (size_t)j * hd + gl * 8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { kv[e] = kf[e]; vv[e] = vf[e]; }
-                }
+            } else if (!first) {
+                load_kv(j, kv, vv);
             }
         }
+        first = false;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float d = 0.f;
