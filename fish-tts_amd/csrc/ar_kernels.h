@@ -167,6 +167,24 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p) {
     });
 }
 
+// RMSNorm of S rows for the MFMA prefill (llama.py:172-177): f32 normalise, round, * gain, round -> bf16
+template <typename WT, bool ROUND>
+__global__ __launch_bounds__(256) void rmsnorm_llama_rows_kernel(const float* x, const void* gain_, float eps, int D,
+                                                                 bf16_t* out) {
+    __shared__ float red[4];
+    const WT* gain = reinterpret_cast<const WT*>(gain_);
+    const size_t row = blockIdx.x;
+    const float* xr = x + row * D;
+    float ss = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) ss = fmaf(xr[d], xr[d], ss);
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float inv = rsqrt_exact((((red[0] + red[1]) + red[2]) + red[3]) / (float)D + eps);
+    for (int d = threadIdx.x; d < D; d += 256)
+        out[row * D + d] = f32_to_bf16_bits(rb<ROUND>(xr[d] * inv) * ld_elem(gain, d));
+}
+
 // ------------------------------------------------------------------------------------------
 // Embedding of one input column (llama.py:409-429): token row + masked sum of the codebook
 // rows, optional 1/sqrt(ncb+1) at VQ positions.  toks[r*tstride + col], r = 0..ncb.
@@ -233,6 +251,10 @@ struct AttnP {
     int ldy;
     float* part_o;   // [M][H][nsplit][hd]
     float* part_ml;  // [M][H][nsplit][2]
+    // prefill: grid.z indexes prompt positions (pos = pos_off + z, one shared cache); pass 1 appends K/V
+    // for every position (kv_only), pass 2 attends reading every key from the cache (no_append)
+    int row_is_pos, kv_only, no_append;
+    bf16_t* y_bf;    // optional bf16 copy of y
 };
 
 template <typename WT, int G, bool ROUND>
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     const int kvh = blockIdx.x, split = blockIdx.y, m = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hd = p.hd, hp = hd >> 1;
-    const int pos = p.pos[m] + p.pos_off;
+    const int pos = p.row_is_pos ? p.pos_off + m : p.pos[m] + p.pos_off;
     const int LPP = hd >> 3;       // lanes per cached position
     const int PPW = 64 / LPP;      // positions per wave step
     const int NSLOT = 4 * PPW;
@@ -256,8 +278,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     const int chunk = (pos + p.nsplit) / p.nsplit;  // ceil((pos+1)/nsplit)
     const int lo = split * chunk;
     const int hi = min(lo + chunk, pos + 1);
-    WT* kc = reinterpret_cast<WT*>(p.kc) + (size_t)m * p.cache_m_stride + (size_t)kvh * p.n_slots * hd;
-    WT* vc = reinterpret_cast<WT*>(p.vc) + (size_t)m * p.cache_m_stride + (size_t)kvh * p.n_slots * hd;
+    const size_t crow = p.row_is_pos ? 0 : (size_t)m * p.cache_m_stride;
+    WT* kc = reinterpret_cast<WT*>(p.kc) + crow + (size_t)kvh * p.n_slots * hd;
+    WT* vc = reinterpret_cast<WT*>(p.vc) + crow + (size_t)kvh * p.n_slots * hd;
     const int grp = lane / LPP, gl = lane % LPP;
     const int slot = wave * PPW + grp;
     auto load_kv = [&](int j, float(&kv)[8], float(&vv)[8]) {
@@ -277,7 +300,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     for (int e = 0; e < 8; ++e) { kpre[e] = 0.f; vpre[e] = 0.f; }
     {
         const int j = lo + wave * PPW + grp;
-        if (j < hi && j != pos) load_kv(j, kpre, vpre);
+        if (j < hi && (j != pos || p.no_append)) load_kv(j, kpre, vpre);
     }
 
     // phase 1: q heads of this group, new k, new v
@@ -311,12 +334,13 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     }
     __syncthreads();
 
-    if (pos >= lo && pos < hi) {
+    if (pos >= lo && pos < hi && !p.no_append) {
         for (int e = tid; e < hd; e += 256) {
             st_elem(kc, (size_t)pos * hd + e, k_new[e]);
             st_elem(vc, (size_t)pos * hd + e, v_new[e]);
         }
     }
+    if (p.kv_only) return;
 
     // phase 2: this block's share of the cached positions
     float qr[G][8];
@@ -339,7 +363,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { kv[e] = kpre[e]; vv[e] = vpre[e]; }
         if (valid) {
-            if (j == pos) {
+            if (j == pos && !p.no_append) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { kv[e] = k_new[gl * 8 + e]; vv[e] = v_new[gl * 8 + e]; }
             } else if (!first) {
@@ -386,7 +410,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
         }
         const int head = kvh * G + g;
         if (p.nsplit == 1) {
-            p.y[(size_t)m * p.ldy + head * hd + e] = rb<ROUND>(O / L);
+            const float yo = rb<ROUND>(O / L);
+            p.y[(size_t)m * p.ldy + head * hd + e] = yo;
+            if (p.y_bf) p.y_bf[(size_t)m * p.ldy + head * hd + e] = f32_to_bf16_bits(yo);
         } else {
             const size_t pi = ((size_t)m * p.H + head) * p.nsplit + split;
             p.part_o[pi * hd + e] = O;
@@ -1282,7 +1308,7 @@ __device__ __forceinline__ float key16_value(unsigned k16) {
     return __uint_as_float(u);
 }
 
-__global__ __launch_bounds__(256) void samp_hist_kernel(SampBigP b) {
+static __global__ __launch_bounds__(256) void samp_hist_kernel(SampBigP b) {
     __shared__ int pen_id[32];
     __shared__ float pen_val[32];
     __shared__ unsigned grp_s[1024];
@@ -1353,7 +1379,7 @@ constexpr int SAMP_TH_ROW = 33;
 constexpr int SAMP_TH_OVF = 8;
 constexpr size_t SAMP_TH_LDS = (size_t)SAMP_TH_THREADS * SAMP_TH_ROW * 4;
 
-__global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
+static __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cimg[];
     __shared__ float red[16];
     __shared__ int redi[16];
@@ -1512,7 +1538,7 @@ __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
     }
 }
 
-__global__ __launch_bounds__(256) void samp_count_kernel(SampBigP b) {
+static __global__ __launch_bounds__(256) void samp_count_kernel(SampBigP b) {
     __shared__ float red[4];
     const SampP& p = b.s;
     const int m = blockIdx.y, tid = threadIdx.x;
@@ -1531,7 +1557,7 @@ __global__ __launch_bounds__(256) void samp_count_kernel(SampBigP b) {
     if (tid == 0) b.chunk_cnt[(size_t)m * b.nchunk + blockIdx.x] = (int)(red[0] + red[1] + red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void samp_race_kernel(SampBigP b) {
+static __global__ __launch_bounds__(256) void samp_race_kernel(SampBigP b) {
     __shared__ float red[4];
     __shared__ int redi[4];
     __shared__ int wcnt[4];

@@ -37,6 +37,8 @@ struct TapGemmP {
     bf16_t* out_act;      // snake(v, alpha) or null
     const float* alpha;
     long ldo, o_bstride;
+    int round_lin;      // round acc+bias to bf16 first (an nn.Linear output of a bf16 model; also the SwiGLU steps)
+    int round_f32_out;  // out_f32 receives bf16-rounded values
 };
 
 __device__ __forceinline__ float snake_f(float v, float a) {
@@ -113,15 +115,18 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmP p) {
             for (int r = 0; r < 4; ++r) {
                 const int t = m0 + wm * WM + i * 16 + fq * 4 + r;
                 float v = acc[i][j][r] + bias;
+                if (p.round_lin) v = round_bf16(v);
                 if (p.act == ACT_SWIGLU) {
                     // columns (2i, 2i+1) = (gate, up): partner value sits in the neighbouring lane
                     const float other = dpp_f<DPP_XOR1>(v);
                     if ((fr & 1) == 0 && nv && t < p.M) {
                         const float gate = v, up = other;
-                        const float o = (gate / (1.0f + expf(-gate))) * up;
+                        float sg = gate / (1.0f + expf(-gate));
+                        if (p.round_lin) sg = round_bf16(sg);
+                        const float o = sg * up;
                         const size_t oi = (size_t)b * p.o_bstride + (size_t)t * p.ldo + (n >> 1);
                         if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(o);
-                        if (p.out_f32) p.out_f32[oi] = o;
+                        if (p.out_f32) p.out_f32[oi] = p.round_f32_out ? round_bf16(o) : o;
                     }
                     continue;
                 }
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmP p) {
                 if (p.resid_f32) v += p.resid_f32[ri];
                 if (p.resid_bf) v += bf16_bits_to_f32(p.resid_bf[ri]);
                 const size_t oi = (size_t)b * p.o_bstride + (size_t)t * p.ldo + n;
-                if (p.out_f32) p.out_f32[oi] = v;
+                if (p.out_f32) p.out_f32[oi] = p.round_f32_out ? round_bf16(v) : v;
                 if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(v);
                 if (p.out_act) p.out_act[oi] = f32_to_bf16_bits(snake_f(v, p.alpha[nm]));
             }
@@ -149,7 +154,7 @@ struct RvqP {
     int ncb, S0, S, D, T;
     float* x;                // [B][T][D] f32
 };
-__global__ __launch_bounds__(256) void rvq_gather_kernel(RvqP p) {
+static __global__ __launch_bounds__(256) void rvq_gather_kernel(RvqP p) {
     const int t = blockIdx.x, b = blockIdx.y;
     const int* cd = p.codes + (size_t)b * (p.ncb + 1) * p.T;
     for (int d = threadIdx.x; d < p.D; d += 256) {
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256) void rvq_gather_kernel(RvqP p) {
         p.x[((size_t)b * p.T + t) * p.D + d] = zs + zr;
     }
 }
-__global__ void rvq_table_kernel(const float* cb, const float* w, const float* bias, float* table, int S, int D, int cd) {
+static __global__ void rvq_table_kernel(const float* cb, const float* w, const float* bias, float* table, int S, int D, int cd) {
     // table[s][d] = sum_j w[d][j] * cb[s][j] + bias[d]
     const long n = (long)S * D;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -185,7 +190,7 @@ struct RowNormP {
     bf16_t* out_bf;
     float* out_f32;
 };
-__global__ __launch_bounds__(256) void rmsnorm_rows_kernel(RowNormP p) {
+static __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(RowNormP p) {
     __shared__ float red[4];
     const size_t row = blockIdx.x;
     const float* x = p.x + row * p.D;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(RowNormP p) {
 }
 
 // ---- RoPE on the q and k thirds of a [T][3*H*hd] bf16 buffer, in place (vocoder.py:145-156)
-__global__ void rope_qk_kernel(bf16_t* qkv, const float* tab, int T, int H, int hd) {
+static __global__ void rope_qk_kernel(bf16_t* qkv, const float* tab, int T, int H, int hd) {
     const int hp = hd >> 1;
     const long n = (long)T * 2 * H * hp;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -226,7 +231,7 @@ struct WinAttnP {
     int T, H, hd, window;
     float scale;
 };
-__global__ __launch_bounds__(256) void window_attn_kernel(WinAttnP p) {
+static __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnP p) {
     __shared__ float q_s[4][128];
     __shared__ float p_s[4][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -280,7 +285,7 @@ struct DwLnP {
     int T, C;
     bf16_t* out;       // [T][C]
 };
-__global__ __launch_bounds__(256) void dwconv_ln_kernel(DwLnP p) {
+static __global__ __launch_bounds__(256) void dwconv_ln_kernel(DwLnP p) {
     __shared__ float red[8];
     extern __shared__ float ybuf[];  // [C]
     const int t = blockIdx.x;
@@ -318,7 +323,7 @@ struct FinalConvP {
     int T, C;
     float* audio;      // [T]
 };
-__global__ __launch_bounds__(256) void final_conv_tanh_kernel(FinalConvP p) {
+static __global__ __launch_bounds__(256) void final_conv_tanh_kernel(FinalConvP p) {
     // 16 lanes per output sample, 16 samples per block step
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
     for (long t = (long)blockIdx.x * 16 + grp; t < p.T; t += (long)gridDim.x * 16) {
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256) void final_conv_tanh_kernel(FinalConvP p) {
 }
 
 // ---- weight repacks
-__global__ void pack_conv_kernel(const float* w, bf16_t* o, int Cout, int Cin, int k) {
+static __global__ void pack_conv_kernel(const float* w, bf16_t* o, int Cout, int Cin, int k) {
     // [Cout][Cin][k] -> [k][Cout][Cin]
     const long n = (long)Cout * Cin * k;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -342,7 +347,7 @@ __global__ void pack_conv_kernel(const float* w, bf16_t* o, int Cout, int Cin, i
         o[((size_t)kk * Cout + co) * Cin + ci] = f32_to_bf16_bits(w[i]);
     }
 }
-__global__ void pack_convT_kernel(const float* w, bf16_t* o, int Cin, int Cout, int k, int s) {
+static __global__ void pack_convT_kernel(const float* w, bf16_t* o, int Cin, int Cout, int k, int s) {
     // [Cin][Cout][k] -> [k/s taps][s*Cout][Cin]; tap j, column (r, co) <- w[ci][co][r + j*s]
     const long n = (long)Cin * Cout * k;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -351,11 +356,11 @@ __global__ void pack_convT_kernel(const float* w, bf16_t* o, int Cin, int Cout, 
         o[((size_t)j * s * Cout + (size_t)r * Cout + co) * Cin + ci] = f32_to_bf16_bits(w[i]);
     }
 }
-__global__ void pack_rows_kernel(const float* w, bf16_t* o, long n) {
+static __global__ void pack_rows_kernel(const float* w, bf16_t* o, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         o[i] = f32_to_bf16_bits(w[i]);
 }
-__global__ void pack_interleave_kernel(const float* a, const float* b, bf16_t* o, long rows, long K) {
+static __global__ void pack_interleave_kernel(const float* a, const float* b, bf16_t* o, long rows, long K) {
     const long n = rows * K;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const long r = i / K, k = i % K;
@@ -363,7 +368,7 @@ __global__ void pack_interleave_kernel(const float* a, const float* b, bf16_t* o
         o[(2 * r + 1) * K + k] = f32_to_bf16_bits(b[i]);
     }
 }
-__global__ void snake_rows_kernel(const float* x, const float* alpha, bf16_t* out, long T, int C) {
+static __global__ void snake_rows_kernel(const float* x, const float* alpha, bf16_t* out, long T, int C) {
     const long n = T * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         out[i] = f32_to_bf16_bits(snake_f(x[i], alpha[i % C]));

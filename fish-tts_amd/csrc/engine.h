@@ -29,6 +29,7 @@ struct FtLayer {
     void *attn_norm = nullptr, *wqkv = nullptr, *bqkv = nullptr, *qn = nullptr, *kn = nullptr, *wo = nullptr,
          *bo = nullptr, *ffn_norm = nullptr, *w13 = nullptr, *w2 = nullptr;
     void *kc = nullptr, *vc = nullptr;
+    float *bqkv_f32 = nullptr, *bo_f32 = nullptr;  // f32 copies of the biases for the MFMA prefill epilogues
 };
 
 struct CodecState;  // codec.hip
@@ -59,6 +60,10 @@ struct ft_ctx {
           *femb = nullptr, *xf = nullptr, *qkvf = nullptr, *gf = nullptr, *flog = nullptr, *part_o = nullptr,
           *part_ml = nullptr;
     int n_slots = 0, nsplit = 1, cap = 0, fastV = 0, y_ld = 0;
+    // MFMA prefill workspace (bf16 precision): S = max_seq_len rows
+    float *pf_x = nullptr, *pf_qkv = nullptr, *pf_y = nullptr;
+    ft::bf16_t *pf_xn = nullptr, *pf_ybf = nullptr, *pf_g = nullptr;
+    bool prefill_v0 = false;
     size_t cache_m_stride = 0, fcache_m_stride = 0;
 
     // per-slot state

@@ -2,6 +2,7 @@
 // frame step) and the C ABI declared in include/fishtts_hip.h.
 #include "engine.h"
 #include "ar_kernels.h"
+#include "codec_kernels.h"
 
 #include <math.h>
 
@@ -170,6 +171,17 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     FT_TRY(dmalloc(ctx, &ctx->d_done, M));
     FT_TRY(dmalloc(ctx, &ctx->d_prompt, R * (size_t)c.max_seq_len));
     FT_TRY(dmalloc(ctx, &ctx->d_ctl, M));
+    ctx->prefill_v0 = getenv("FT_PREFILL_V0") != nullptr || c.dtype != FT_BF16 || c.dim % 32 || (c.n_head * c.head_dim) % 32 ||
+                      c.intermediate_size % 32;
+    if (!ctx->prefill_v0) {
+        const size_t S = c.max_seq_len;
+        FT_TRY(dmalloc(ctx, &ctx->pf_x, S * c.dim));
+        FT_TRY(dmalloc(ctx, &ctx->pf_qkv, S * qkvN));
+        FT_TRY(dmalloc(ctx, &ctx->pf_y, S * c.n_head * c.head_dim));
+        FT_TRY(dmalloc(ctx, &ctx->pf_xn, S * c.dim));
+        FT_TRY(dmalloc(ctx, &ctx->pf_ybf, S * c.n_head * c.head_dim));
+        FT_TRY(dmalloc(ctx, &ctx->pf_g, S * c.intermediate_size));
+    }
     const size_t nchunk = ((size_t)c.vocab_size + 1023) / 1024;
     FT_TRY(dmalloc(ctx, &ctx->samp_hist, M * SAMP_HIST_STRIDE));
     FT_TRY(dmalloc(ctx, &ctx->samp_cut, M));
@@ -238,6 +250,8 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     int* ibufs[] = {ctx->d_pos, ctx->d_tok, ctx->d_tokn, ctx->d_seq, ctx->d_nf, ctx->d_done, ctx->d_prompt};
     for (int* b : ibufs) if (b) hipFree(b);
     if (ctx->d_ctl) hipFree(ctx->d_ctl);
+    { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g}; for (void* q : pf) if (q) hipFree(q); }
+    for (auto& l : ctx->layers) { if (l.bqkv_f32) hipFree(l.bqkv_f32); if (l.bo_f32) hipFree(l.bo_f32); }
     if (ctx->samp_hist) hipFree(ctx->samp_hist);
     if (ctx->samp_cut) hipFree(ctx->samp_cut);
     if (ctx->samp_chunk_cnt) hipFree(ctx->samp_chunk_cnt);
@@ -351,6 +365,20 @@ static ft_status ar_finalize(ft_ctx* ctx) {
         return FT_OK;
     };
     FT_TRY(fill(ctx->layers, "layers.", c.intermediate_size, c.dim));
+    if (!ctx->prefill_v0) {
+        const int qkvN = (c.n_head + 2 * c.n_local_heads) * c.head_dim;
+        for (auto& l : ctx->layers) {
+            if (l.bqkv) {
+                FT_HIP(ctx, hipMalloc((void**)&l.bqkv_f32, qkvN * sizeof(float)));
+                convert_kernel<bf16_t, float><<<(qkvN + 255) / 256, 256, 0, ctx->stream>>>((const bf16_t*)l.bqkv, l.bqkv_f32, qkvN);
+            }
+            if (l.bo) {
+                FT_HIP(ctx, hipMalloc((void**)&l.bo_f32, c.dim * sizeof(float)));
+                convert_kernel<bf16_t, float><<<(c.dim + 255) / 256, 256, 0, ctx->stream>>>((const bf16_t*)l.bo, l.bo_f32, c.dim);
+            }
+        }
+        FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     FT_TRY(fill(ctx->flayers, "fast_layers.", c.fast_intermediate_size, c.fast_dim));
     return FT_OK;
 }
@@ -458,6 +486,19 @@ static void gemv_combine_nt(Launch& L, const GemvP& p, const AttnP& a, int nt) {
 #undef FT_NT
 }
 
+// fast_project_in on the pre-norm hidden state (llama.py:453,590); identity when fast_dim == dim
+template <typename WT, bool ROUND>
+static void enqueue_fproj(Launch& L) {
+    ft_ctx* ctx = L.ctx;
+    const ft_ar_config& c = ctx->c;
+    if (c.fast_dim == c.dim) return;
+    GemvP q{};
+    q.W = ctx->fproj_w; q.bias = ctx->fproj_b; q.x = ctx->x + (size_t)L.m0 * c.dim; q.ldx = c.dim;
+    q.out = ctx->hid + (size_t)L.m0 * c.fast_dim; q.ldo = c.fast_dim; q.N = c.fast_dim; q.K = c.dim;
+    q.pro = PRO_NONE; q.epi = EPI_STORE;
+    gemv<WT, ROUND>(L, q, rows_per_wave(q.N, L.M));
+}
+
 // One slow-transformer pass over the current input column of rows [m0, m0+M) (llama.py:400-453).
 template <typename WT, bool ROUND>
 static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long tok_m_stride, int col, bool with_head) {
@@ -528,13 +569,7 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
         d.N = c.dim; d.K = c.intermediate_size; d.pro = PRO_NONE; d.epi = EPI_RESID; d.nt = ctx->nt_weights;
         gemv<WT, ROUND>(L, d, rows_per_wave(d.N, L.M));
     }
-    if (c.fast_dim != c.dim) {  // fast_project_in on the pre-norm hidden state (llama.py:453,590)
-        GemvP q{};
-        q.W = ctx->fproj_w; q.bias = ctx->fproj_b; q.x = x; q.ldx = c.dim;
-        q.out = ctx->hid + (size_t)m0 * c.fast_dim; q.ldo = c.fast_dim; q.N = c.fast_dim; q.K = c.dim;
-        q.pro = PRO_NONE; q.epi = EPI_STORE;
-        if (with_head) gemv<WT, ROUND>(L, q, rows_per_wave(q.N, L.M));
-    }
+    if (with_head) enqueue_fproj<WT, ROUND>(L);
 }
 
 // final norm + vocabulary head (llama.py:446-451)
@@ -652,10 +687,19 @@ static void enqueue_fast_step(Launch& L, const int cb) {
 
 // One full frame: slow pass on the current column, semantic sample, fast codebooks (inference.py:83-155).
 template <typename WT, bool ROUND>
+static void enqueue_frame_tail(Launch& L);
+
+template <typename WT, bool ROUND>
 static void enqueue_frame_t(Launch& L, const int* toks, long trs, long tms, int col) {
+    enqueue_slow<WT, ROUND>(L, toks, trs, tms, col, true);
+    enqueue_frame_tail<WT, ROUND>(L);
+}
+
+// everything after the slow layers: vocabulary head, semantic draw, the fast codebooks
+template <typename WT, bool ROUND>
+static void enqueue_frame_tail(Launch& L) {
     ft_ctx* ctx = L.ctx;
     const int ncb = ctx->c.num_codebooks;
-    enqueue_slow<WT, ROUND>(L, toks, trs, tms, col, true);
     // The fast pass at codebook position 0 needs only the hidden state, not the sampled token
     // (inference.py:121-122): it runs beside the vocabulary head + semantic draw on a second stream
     // (a forked branch of the captured graph) and joins before position 1.
@@ -717,6 +761,73 @@ static ft_status upload_ctl(ft_ctx* ctx, int m0, int n, const ft_sampling* sp) {
     return FT_OK;
 }
 
+// MFMA prefill (bf16 precision): the whole prompt goes through every slow layer as S = Lp rows on the
+// tap-GEMM kernel (v_mfma_f32_16x16x32_bf16), with the reference's rounding points in the epilogues
+// (Linear output rounded, residual add rounded, SwiGLU steps rounded; llama.py:172-190,229-283,322-331).
+// K/V of all positions are appended first, then every position attends over the cache.
+static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, const float* bias, int N, int K,
+                    int act, const float* resid, float* out_f32, bf16_t* out_bf, long ldo, int round_out) {
+    TapGemmP p{};
+    p.X = X; p.ldx = ldx; p.T_in = S; p.W = (const bf16_t*)W; p.ntap = 1; p.offs[0] = 0; p.M = S; p.N = N; p.K = K;
+    p.bias = bias; p.n_mod = N; p.act = act; p.resid_f32 = resid; p.ldr = ldo; p.out_f32 = out_f32; p.out_bf = out_bf;
+    p.ldo = ldo; p.round_lin = 1; p.round_f32_out = round_out;
+    if (N >= 128) tapgemm_kernel<128, 128, 2, 2><<<dim3((S + 127) / 128, (N + 127) / 128, 1), 256, 0, L.s>>>(p);
+    else tapgemm_kernel<128, 64, 4, 1><<<dim3((S + 127) / 128, (N + 63) / 64, 1), 256, 0, L.s>>>(p);
+    L.chk();
+}
+
+static void prefill_gemm(Launch& L, int slot, int Lp) {
+    ft_ctx* ctx = L.ctx;
+    const ft_ar_config& c = ctx->c;
+    const int D = c.dim, HD = c.n_head * c.head_dim, F = c.intermediate_size;
+    const int qkvN = (c.n_head + 2 * c.n_local_heads) * c.head_dim;
+    EmbedP e{};
+    e.emb = ctx->emb; e.cb_emb = ctx->cb_emb; e.toks = ctx->d_prompt; e.tok_row_stride = Lp; e.tok_m_stride = 1;
+    e.col = 0; e.x = ctx->pf_x; e.ldx = D; e.D = D; e.ncb = c.num_codebooks; e.cbsize = c.codebook_size;
+    e.vocab = c.vocab_size; e.sem_begin = c.semantic_begin_id; e.sem_end = c.semantic_end_id;
+    e.scale = c.scale_codebook_embeddings; e.inv_div = (float)sqrt((double)(c.num_codebooks + 1));
+    embed_kernel<bf16_t, true><<<dim3((D + 255) / 256, Lp), 256, 0, L.s>>>(e);
+    L.chk();
+    const int G = c.n_head / c.n_local_heads;
+    const int nslot = 2048 / c.head_dim;
+    const size_t lds = ((size_t)G * c.head_dim + 2 * c.head_dim + (size_t)nslot * G * 2 + (size_t)nslot * G * c.head_dim) * sizeof(float);
+    for (int li = 0; li < c.n_layer; ++li) {
+        const FtLayer& l = ctx->layers[li];
+        rmsnorm_llama_rows_kernel<bf16_t, true><<<Lp, 256, 0, L.s>>>(ctx->pf_x, l.attn_norm, c.norm_eps, D, ctx->pf_xn);
+        pf_gemm(L, ctx->pf_xn, D, Lp, l.wqkv, l.bqkv_f32, qkvN, D, ACT_NONE, nullptr, ctx->pf_qkv, nullptr, qkvN, 0);
+        AttnP a{};
+        a.qkv = ctx->pf_qkv; a.ldq = qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->rope;
+        a.kc = (char*)l.kc + (size_t)slot * ctx->cache_m_stride * ctx->esz;
+        a.vc = (char*)l.vc + (size_t)slot * ctx->cache_m_stride * ctx->esz;
+        a.cache_m_stride = 0; a.pos = nullptr; a.pos_off = 0; a.row_is_pos = 1;
+        a.H = c.n_head; a.Hkv = c.n_local_heads; a.hd = c.head_dim; a.n_slots = ctx->n_slots; a.nsplit = 1;
+        a.eps = c.norm_eps; a.scale = 1.0f / sqrtf((float)c.head_dim); a.y = ctx->pf_y; a.ldy = HD; a.y_bf = ctx->pf_ybf;
+        Launch LA = L;
+        LA.M = Lp;
+        for (int pass = 0; pass < 2; ++pass) {
+            a.kv_only = pass == 0; a.no_append = pass == 1;
+            const dim3 grid(c.n_local_heads, 1, Lp);
+            switch (G) {
+                case 1: attn_decode_kernel<bf16_t, 1, true><<<grid, 256, lds, L.s>>>(a); break;
+                case 2: attn_decode_kernel<bf16_t, 2, true><<<grid, 256, lds, L.s>>>(a); break;
+                case 4: attn_decode_kernel<bf16_t, 4, true><<<grid, 256, lds, L.s>>>(a); break;
+                default:
+                    hipFuncSetAttribute((const void*)attn_decode_kernel<bf16_t, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    attn_decode_kernel<bf16_t, 8, true><<<grid, 256, lds, L.s>>>(a);
+            }
+            L.chk();
+        }
+        pf_gemm(L, ctx->pf_ybf, HD, Lp, l.wo, l.bo_f32, D, HD, ACT_NONE, ctx->pf_x, ctx->pf_x, nullptr, D, 1);
+        rmsnorm_llama_rows_kernel<bf16_t, true><<<Lp, 256, 0, L.s>>>(ctx->pf_x, l.ffn_norm, c.norm_eps, D, ctx->pf_xn);
+        pf_gemm(L, ctx->pf_xn, D, Lp, l.w13, nullptr, 2 * F, D, ACT_SWIGLU, nullptr, nullptr, ctx->pf_g, F, 0);
+        pf_gemm(L, ctx->pf_g, F, Lp, l.w2, nullptr, D, F, ACT_NONE, ctx->pf_x, ctx->pf_x, nullptr, D, 1);
+    }
+    // the last position feeds the head and the fast stack through the decode kernels
+    hipMemcpyAsync(ctx->x + (size_t)slot * D, ctx->pf_x + (size_t)(Lp - 1) * D, D * sizeof(float), hipMemcpyDeviceToDevice, L.s);
+    enqueue_fproj<bf16_t, true>(L);
+    enqueue_frame_tail<bf16_t, true>(L);
+}
+
 extern "C" ft_status ft_ar_prefill(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_t Lp,
                                    const ft_sampling* sp, int32_t* out_frame) {
     FT_TRY(ar_ready(ctx));
@@ -734,14 +845,18 @@ extern "C" ft_status ft_ar_prefill(ft_ctx* ctx, int32_t slot, const int32_t* pro
     FT_TRY(upload_ctl(ctx, slot, 1, sp));
     FT_HIP(ctx, hipMemcpyAsync(ctx->d_prompt, prompt, (size_t)R * Lp * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     Launch L{ctx, ctx->stream, slot, 1, 0};
-    // v0 prefill: the prompt is fed through the S=1 decode kernels position by position (same causal
-    // arithmetic as the reference's S=Lp pass); only the last position runs the head and the fast stack.
-    for (int t = 0; t < Lp - 1; ++t) {
-        L.pos_off = t;
-        enqueue_slow_only(L, ctx->d_prompt, Lp, 0, t);
+    if (!ctx->prefill_v0) {
+        prefill_gemm(L, slot, Lp);
+    } else {
+        // f32 precision (and shapes the MFMA tiles do not cover): the prompt is fed through the S=1 decode
+        // kernels position by position (same causal arithmetic); only the last position runs the head
+        for (int t = 0; t < Lp - 1; ++t) {
+            L.pos_off = t;
+            enqueue_slow_only(L, ctx->d_prompt, Lp, 0, t);
+        }
+        L.pos_off = Lp - 1;
+        enqueue_frame(L, ctx->d_prompt, Lp, 0, Lp - 1);
     }
-    L.pos_off = Lp - 1;
-    enqueue_frame(L, ctx->d_prompt, Lp, 0, Lp - 1);
     if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("prefill launch: ") + hipGetErrorString(L.err));
     // finalize() advanced pos 0 -> 1; the next input position is Lp
     ctx->h_pin[0] = Lp;
