@@ -990,21 +990,61 @@ extern "C" ft_status ft_ar_profile_gemv(ft_ctx* ctx, int32_t frames, const ft_sa
     for (auto e : ctx->prof_ev) hipEventDestroy(e);
     ctx->prof_ev.clear();
     ctx->prof_bytes = ctx->prof_launches = 0;
-    ctx->prof = true;
-    for (int f = 0; f < frames; ++f) {
-        Launch L{ctx, ctx->stream, 0, 1, 0};
-        enqueue_frame(L, ctx->d_tok, 1, R, 0);
-        if (L.err != hipSuccess) { ctx->prof = false; return ft_fail(ctx, FT_ERR_HIP, "profile launch failed"); }
-    }
-    ctx->prof = false;
-    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // One frame is captured WITH an event pair around every launch of the GEMV family, so the durations are
+    // taken in situ (same stream, same graph replay as the timed region); falls back to eager launches if
+    // the runtime cannot time captured events.
     double tot = 0.0;
-    for (size_t i = 0; i + 1 < ctx->prof_ev.size(); i += 2) {
-        float t = 0.f;
-        hipEventElapsedTime(&t, ctx->prof_ev[i], ctx->prof_ev[i + 1]);
-        tot += t;
+    int64_t n_launch = 0, n_bytes = 0;
+    bool graph_ok = getenv("FT_PROFILE_EAGER") == nullptr;
+    if (graph_ok) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        ctx->prof = true;
+        hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+        Launch L{ctx, ctx->stream, 0, 1, 0};
+        if (e == hipSuccess) {
+            enqueue_frame(L, ctx->d_tok, 1, R, 0);
+            e = hipStreamEndCapture(ctx->stream, &graph);
+        }
+        ctx->prof = false;
+        if (e == hipSuccess && L.err == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) hipGraphDestroy(graph);
+        graph_ok = e == hipSuccess && L.err == hipSuccess && exec != nullptr;
+        for (int f = 0; graph_ok && f < frames; ++f) {
+            if (hipGraphLaunch(exec, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { graph_ok = false; break; }
+            for (size_t i = 0; i + 1 < ctx->prof_ev.size(); i += 2) {
+                float t = 0.f;
+                if (hipEventElapsedTime(&t, ctx->prof_ev[i], ctx->prof_ev[i + 1]) != hipSuccess) { graph_ok = false; break; }
+                tot += t;
+            }
+            n_launch += ctx->prof_launches;
+            n_bytes += ctx->prof_bytes;
+        }
+        if (exec) hipGraphExecDestroy(exec);
+        (void)hipGetLastError();
     }
-    *ms = tot; *launches = ctx->prof_launches; *bytes = ctx->prof_bytes;
+    if (!graph_ok) {
+        for (auto e : ctx->prof_ev) hipEventDestroy(e);
+        ctx->prof_ev.clear();
+        ctx->prof_bytes = ctx->prof_launches = 0;
+        tot = 0.0;
+        ctx->prof = true;
+        for (int f = 0; f < frames; ++f) {
+            Launch L{ctx, ctx->stream, 0, 1, 0};
+            enqueue_frame(L, ctx->d_tok, 1, R, 0);
+            if (L.err != hipSuccess) { ctx->prof = false; return ft_fail(ctx, FT_ERR_HIP, "profile launch failed"); }
+        }
+        ctx->prof = false;
+        FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i + 1 < ctx->prof_ev.size(); i += 2) {
+            float t = 0.f;
+            hipEventElapsedTime(&t, ctx->prof_ev[i], ctx->prof_ev[i + 1]);
+            tot += t;
+        }
+        n_launch = ctx->prof_launches;
+        n_bytes = ctx->prof_bytes;
+    }
+    *ms = tot; *launches = n_launch; *bytes = n_bytes;
     for (auto e : ctx->prof_ev) hipEventDestroy(e);
     ctx->prof_ev.clear();
     return FT_OK;
