@@ -86,7 +86,7 @@ struct ft_ctx {
     std::map<int, hipGraphExec_t> graphs;
 
     // measurement hook
-    bool prof = false;
+    bool prof = false, prof_count_only = false;
     std::vector<hipEvent_t> prof_ev;
     int64_t prof_bytes = 0, prof_launches = 0;
 

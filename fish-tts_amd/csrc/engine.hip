@@ -402,6 +402,7 @@ struct Launch {
     int m0, M;       // batch rows [m0, m0+M)
     int pos_off;     // added to the device position (token-by-token prefill)
     hipError_t err = hipSuccess;
+    bool gemv_only = false;  // measurement: enqueue only the weight-streaming GEMV launches of the frame
     void chk() { hipError_t e = hipGetLastError(); if (e != hipSuccess && err == hipSuccess) err = e; }
 };
 
@@ -426,7 +427,7 @@ static void gemv(Launch& L, GemvP p, int R) {
     if (nt < 0) { L.err = hipErrorInvalidValue; return; }
     ft_ctx* ctx = L.ctx;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->prof) {
+    if (ctx->prof && !ctx->prof_count_only) {
         hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, L.s);
     }
@@ -435,8 +436,10 @@ static void gemv(Launch& L, GemvP p, int R) {
     else if (R == 2) gemv_nt<WT, ROUND, 2>(L, p, nt);
     else gemv_nt<WT, ROUND, 4>(L, p, nt);
     if (ctx->prof) {
-        hipEventRecord(e1, L.s);
-        ctx->prof_ev.push_back(e0); ctx->prof_ev.push_back(e1);
+        if (!ctx->prof_count_only) {
+            hipEventRecord(e1, L.s);
+            ctx->prof_ev.push_back(e0); ctx->prof_ev.push_back(e1);
+        }
         ctx->prof_bytes += (int64_t)p.N * p.K * sizeof(WT);
         ctx->prof_launches += 1;
     }
@@ -517,7 +520,7 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
     e.cbsize = c.codebook_size; e.vocab = c.vocab_size; e.sem_begin = c.semantic_begin_id;
     e.sem_end = c.semantic_end_id; e.scale = c.scale_codebook_embeddings;
     e.inv_div = (float)sqrt((double)(c.num_codebooks + 1));
-    embed_kernel<WT, ROUND><<<dim3((c.dim + 255) / 256, L.M), 256, 0, L.s>>>(e);
+    if (!L.gemv_only) embed_kernel<WT, ROUND><<<dim3((c.dim + 255) / 256, L.M), 256, 0, L.s>>>(e);
     L.chk();
 
     for (int li = 0; li < c.n_layer; ++li) {
@@ -537,7 +540,7 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
         a.y = y; a.ldy = ctx->y_ld;
         a.part_o = ctx->part_o + (size_t)m0 * c.n_head * ctx->nsplit * c.head_dim;
         a.part_ml = ctx->part_ml + (size_t)m0 * c.n_head * ctx->nsplit * 2;
-        attn_decode<WT, ROUND>(L, a);
+        if (!L.gemv_only) attn_decode<WT, ROUND>(L, a);
 
         GemvP o{};
         o.W = l.wo; o.bias = l.bo; o.x = y; o.ldx = ctx->y_ld; o.out = x; o.ldo = c.dim;
@@ -545,12 +548,14 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
         if (ctx->nsplit > 1) {  // split-KV partials are merged inside the Wo kernel
             const int nt = pick_nt(o.K, Vec<WT>::N);
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (ctx->prof) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, L.s); }
+            if (ctx->prof && !ctx->prof_count_only) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, L.s); }
             if (rows_per_wave(o.N, L.M) >= 2) gemv_combine_nt<WT, ROUND, 2>(L, o, a, nt);
             else gemv_combine_nt<WT, ROUND, 1>(L, o, a, nt);
             if (ctx->prof) {
-                hipEventRecord(e1, L.s);
-                ctx->prof_ev.push_back(e0); ctx->prof_ev.push_back(e1);
+                if (!ctx->prof_count_only) {
+                    hipEventRecord(e1, L.s);
+                    ctx->prof_ev.push_back(e0); ctx->prof_ev.push_back(e1);
+                }
                 ctx->prof_bytes += (int64_t)o.N * o.K * sizeof(WT);
                 ctx->prof_launches += 1;
             }
@@ -586,6 +591,7 @@ static void enqueue_head(Launch& L) {
 
 template <typename WT, bool ROUND>
 static void enqueue_sample(Launch& L, int cb, bool last) {
+    if (L.gemv_only) return;
     ft_ctx* ctx = L.ctx;
     const ft_ar_config& c = ctx->c;
     const int m0 = L.m0, R = c.num_codebooks + 1;
@@ -657,7 +663,7 @@ static void enqueue_fast_step(Launch& L, const int cb) {
             a.cache_m_stride = ctx->fcache_m_stride; a.c = cb; a.H = Hf; a.Hkv = Hkvf; a.hd = hdf;
             a.ncb = c.num_codebooks; a.eps = c.norm_eps; a.scale = (float)(1.0 / sqrt((double)hdf));
             float* yf = ctx->y + (size_t)m0 * ctx->y_ld;  // the slow attention's y buffer is free here
-            fast_attn_kernel<WT, ROUND><<<dim3(Hf, L.M), 64, 0, L.s>>>(a, yf, ctx->y_ld);
+            if (!L.gemv_only) fast_attn_kernel<WT, ROUND><<<dim3(Hf, L.M), 64, 0, L.s>>>(a, yf, ctx->y_ld);
             L.chk();
             GemvP o{};
             o.W = l.wo; o.bias = l.bo; o.x = yf; o.ldx = ctx->y_ld; o.out = xf; o.ldo = Df; o.resid = xl;
@@ -990,35 +996,44 @@ extern "C" ft_status ft_ar_profile_gemv(ft_ctx* ctx, int32_t frames, const ft_sa
     for (auto e : ctx->prof_ev) hipEventDestroy(e);
     ctx->prof_ev.clear();
     ctx->prof_bytes = ctx->prof_launches = 0;
-    // One frame is captured WITH an event pair around every launch of the GEMV family, so the durations are
-    // taken in situ (same stream, same graph replay as the timed region); falls back to eager launches if
-    // the runtime cannot time captured events.
+    // The GEMV launches of one frame (weights of every layer in order, nothing else) are captured into a graph
+    // and replayed `frames` times between two HIP events on the engine's stream: the average includes the
+    // dependent-launch boundary exactly as rocprofv3's serialized kernel durations do.  The launch and byte
+    // counters come from the same enqueue code as the real frame.
     double tot = 0.0;
     int64_t n_launch = 0, n_bytes = 0;
     bool graph_ok = getenv("FT_PROFILE_EAGER") == nullptr;
     if (graph_ok) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-        ctx->prof = true;
         hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
         Launch L{ctx, ctx->stream, 0, 1, 0};
+        L.gemv_only = true;
+        ctx->prof_count_only = true;
+        ctx->prof = true;
         if (e == hipSuccess) {
             enqueue_frame(L, ctx->d_tok, 1, R, 0);
             e = hipStreamEndCapture(ctx->stream, &graph);
         }
         ctx->prof = false;
+        ctx->prof_count_only = false;
         if (e == hipSuccess && L.err == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (graph) hipGraphDestroy(graph);
         graph_ok = e == hipSuccess && L.err == hipSuccess && exec != nullptr;
-        for (int f = 0; graph_ok && f < frames; ++f) {
-            if (hipGraphLaunch(exec, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { graph_ok = false; break; }
-            for (size_t i = 0; i + 1 < ctx->prof_ev.size(); i += 2) {
-                float t = 0.f;
-                if (hipEventElapsedTime(&t, ctx->prof_ev[i], ctx->prof_ev[i + 1]) != hipSuccess) { graph_ok = false; break; }
-                tot += t;
-            }
-            n_launch += ctx->prof_launches;
-            n_bytes += ctx->prof_bytes;
+        if (graph_ok) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipGraphLaunch(exec, ctx->stream);  // warm
+            hipEventRecord(e0, ctx->stream);
+            for (int f = 0; f < frames; ++f) hipGraphLaunch(exec, ctx->stream);
+            hipEventRecord(e1, ctx->stream);
+            graph_ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+            float t = 0.f;
+            if (graph_ok) graph_ok = hipEventElapsedTime(&t, e0, e1) == hipSuccess;
+            tot = t;
+            n_launch = ctx->prof_launches * frames;
+            n_bytes = ctx->prof_bytes * frames;
+            hipEventDestroy(e0); hipEventDestroy(e1);
         }
         if (exec) hipGraphExecDestroy(exec);
         (void)hipGetLastError();
