@@ -126,30 +126,22 @@ int main() {
         }, 40);
         printf("fast layer (4 gemv, 25 MB, cache-resident): %.2f us/layer\n", us);
     }
-    // 5. fused fast attention + Wo, by codebook position
+    // 5. fast-stack attention kernel (one wave per head), by codebook position
     {
         bf16_t *kc, *vc; float* rope;
         CK(hipMalloc(&kc, 8 * 10 * 64 * 2)); CK(hipMalloc(&vc, 8 * 10 * 64 * 2)); CK(hipMalloc(&rope, 10 * 32 * 2 * 4));
         CK(hipMemset(kc, 0x11, 8 * 10 * 64 * 2)); CK(hipMemset(vc, 0x11, 8 * 10 * 64 * 2)); CK(hipMemset(rope, 0, 10 * 32 * 2 * 4));
-        const size_t lds = fast_attn_lds_floats(16, 8, 64, 10) * sizeof(float);
         for (int c : {0, 4, 9}) {
             float us = time_graph([&] {
-                for (int rep = 0; rep < 10; ++rep)
-                    for (int l = 0; l < 4; ++l) {
-                        GemvP p = mk(wo[l], y, 1024, x, D, D, 1024, PRO_NONE, EPI_RESID, 0);
-                        FastAttnP a{};
-                        a.qkv = qkv; a.ldq = 2048; a.rope = rope; a.kc = kc; a.vc = vc; a.cache_m_stride = 8 * 10 * 64; a.c = c;
-                        a.H = 16; a.Hkv = 8; a.hd = 64; a.ncb = 10; a.eps = 1e-6f; a.scale = 0.125f;
-                        fast_attn_wo_kernel<bf16_t, 2, 1, true><<<dim3(256, 1), 256, lds, s>>>(p, a);
-                    }
+                for (int rep = 0; rep < 40; ++rep) {
+                    FastAttnP a{};
+                    a.qkv = qkv; a.ldq = 2048; a.rope = rope; a.kc = kc; a.vc = vc; a.cache_m_stride = 8 * 10 * 64; a.c = c;
+                    a.H = 16; a.Hkv = 8; a.hd = 64; a.ncb = 10; a.eps = 1e-6f; a.scale = 0.125f;
+                    fast_attn_kernel<bf16_t, true><<<dim3(16, 1), 64, 0, s>>>(a, y, 2048);
+                }
             }, 40);
-            printf("fast_attn_wo c=%d: %.2f us\n", c, us);
+            printf("fast_attn c=%d: %.2f us\n", c, us);
         }
-        float us = time_graph([&] {
-            for (int rep = 0; rep < 10; ++rep)
-                for (int l = 0; l < 4; ++l) launch_gemv<2, 1>(mk(wo[l], y, 1024, x, D, D, 1024, PRO_NONE, EPI_RESID, 0), 1);
-        }, 40);
-        printf("plain wo N=1024 K=1024: %.2f us\n", us);
     }
     return 0;
 }
