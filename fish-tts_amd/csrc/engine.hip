@@ -706,6 +706,10 @@ template <typename WT, bool ROUND>
 static void enqueue_frame_tail(Launch& L) {
     ft_ctx* ctx = L.ctx;
     const int ncb = ctx->c.num_codebooks;
+    if (L.gemv_only) {  // measurement graph: the HBM-streamed launches only (slow layers above + the head)
+        enqueue_head<WT, ROUND>(L);
+        return;
+    }
     // The fast pass at codebook position 0 needs only the hidden state, not the sampled token
     // (inference.py:121-122): it runs beside the vocabulary head + semantic draw on a second stream
     // (a forked branch of the captured graph) and joins before position 1.

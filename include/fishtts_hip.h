@@ -109,10 +109,11 @@ ft_status ft_codec_decode(ft_ctx* ctx, const int32_t* codes, int32_t B, int32_t 
                           float* audio);
 int32_t ft_codec_frame_len(const ft_ctx* ctx); /* samples per code frame (2048) */
 
-/* Measurement hooks used by bench.py (never by the product path).  Runs `frames` decode frames
- * eagerly (not graph-replayed) on slot 0 with HIP events around every launch of the
- * weight-streaming GEMV kernel family on the engine's own stream; returns summed device ms,
- * launch count and the algorithmic bytes those launches stream. */
+/* Measurement hook used by bench.py (never by the product path).  The weight-streaming GEMV launches of
+ * one decode frame whose weights come from HBM (4 per slow layer + the vocabulary head; the fast stack's
+ * 100 MB stay cache-resident and are excluded) are captured into a hipGraph and replayed `frames` times
+ * between two HIP events on the engine's own stream.  Returns the elapsed device ms, the number of kernel
+ * launches timed and the algorithmic bytes those launches stream. */
 ft_status ft_ar_profile_gemv(ft_ctx* ctx, int32_t frames, const ft_sampling* sp, double* ms,
                              int64_t* launches, int64_t* bytes);
 ft_status ft_sync(ft_ctx* ctx);
