@@ -1,5 +1,8 @@
 // DAC codec decode (DAC.decode, vocoder.py:906-912) on the tap-GEMM kernels of codec_kernels.h.
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
 
 #include <mutex>
 
@@ -291,7 +294,22 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
     p.M = io.M; p.N = w.N; p.K = w.K; p.bias = w.bias; p.n_mod = w.n_mod; p.act = io.act; p.gamma = io.gamma;
     p.resid_f32 = io.resid_f32; p.resid_bf = io.resid_bf; p.ldr = io.ldr; p.out_f32 = io.out_f32; p.out_bf = io.out_bf;
     p.out_act = io.out_act; p.alpha = io.alpha; p.ldo = io.ldo;
-    if (w.N >= 128) {
+    int halo = 0;
+    for (int i = 0; i < w.ntap; ++i) halo = std::max(halo, -w.offs[i]);
+    static const bool legacy = getenv("FT_CODEC_GEMM_V0") != nullptr;
+    if (w.K % 64 == 0 && halo <= 56 && !legacy) {  // pipelined kernel: A stripe shared by the taps, B double-buffered
+        const size_t a_bytes = (size_t)(128 + 56) * 72 * 2;
+        if (w.N % 128 == 0 || (w.N % 96 != 0 && w.N > 96)) {
+            const dim3 grid((io.M + 127) / 128, (w.N + 127) / 128, 1);
+            tapgemm64_kernel<128><<<grid, 256, a_bytes + 2 * 128 * 72 * 2, st>>>(p);
+        } else if (w.N % 96 == 0) {
+            const dim3 grid((io.M + 127) / 128, w.N / 96, 1);
+            tapgemm64_kernel<96><<<grid, 256, a_bytes + 2 * 96 * 72 * 2, st>>>(p);
+        } else {
+            const dim3 grid((io.M + 127) / 128, (w.N + 63) / 64, 1);
+            tapgemm64_kernel<64><<<grid, 256, a_bytes + 2 * 64 * 72 * 2, st>>>(p);
+        }
+    } else if (w.N >= 128) {
         const dim3 grid((io.M + 127) / 128, (w.N + 127) / 128, 1);
         tapgemm_kernel<128, 128, 2, 2><<<grid, 256, 0, st>>>(p);
     } else {

@@ -41,11 +41,66 @@ struct TapGemmP {
     int round_f32_out;  // out_f32 receives bf16-rounded values
 };
 
+// offs[] lives in the kernel arguments: a runtime index would force the whole struct into scratch
+__device__ __forceinline__ int tap_off(const TapGemmP& p, int tap) {
+    int o = p.offs[0];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) o = (t == tap) ? p.offs[t] : o;
+    return o;
+}
+
 __device__ __forceinline__ float snake_f(float v, float a) {
     const float s = sinf(a * v);
     return v + (1.0f / (a + 1e-9f)) * (s * s);
 }
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+
+template <int TM, int TN>
+__device__ __forceinline__ void tapgemm_epilogue(const TapGemmP& p, f32x4 (&acc)[TM][TN], const int mw, const int nw,
+                                                 const int b, const int fr, const int fq) {
+    // epilogue: lane holds C[row = 4*fq + r][col = fr] of each 16x16 tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nw + j * 16 + fr;
+            const bool nv = n < p.N;
+            const int nm = nv ? n % p.n_mod : 0;
+            const float bias = (p.bias && nv) ? p.bias[nm] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = mw + i * 16 + fq * 4 + r;
+                float v = acc[i][j][r] + bias;
+                if (p.round_lin) v = round_bf16(v);
+                if (p.act == ACT_SWIGLU) {
+                    // columns (2i, 2i+1) = (gate, up): partner value sits in the neighbouring lane
+                    const float other = dpp_f<DPP_XOR1>(v);
+                    if ((fr & 1) == 0 && nv && t < p.M) {
+                        const float gate = v, up = other;
+                        float sg = gate / (1.0f + expf(-gate));
+                        if (p.round_lin) sg = round_bf16(sg);
+                        const float o = sg * up;
+                        const size_t oi = (size_t)b * p.o_bstride + (size_t)t * p.ldo + (n >> 1);
+                        if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(o);
+                        if (p.out_f32) p.out_f32[oi] = p.round_f32_out ? round_bf16(o) : o;
+                    }
+                    continue;
+                }
+                if (!nv || t >= p.M) continue;
+                if (p.act == ACT_GELU) v = gelu_f(v);
+                else if (p.act == ACT_TANH) v = tanhf(v);
+                if (p.gamma) v *= p.gamma[nm];
+                const size_t ri = (size_t)b * p.r_bstride + (size_t)t * p.ldr + n;
+                if (p.resid_f32) v += p.resid_f32[ri];
+                if (p.resid_bf) v += bf16_bits_to_f32(p.resid_bf[ri]);
+                const size_t oi = (size_t)b * p.o_bstride + (size_t)t * p.ldo + n;
+                if (p.out_f32) p.out_f32[oi] = p.round_f32_out ? round_bf16(v) : v;
+                if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(v);
+                if (p.out_act) p.out_act[oi] = f32_to_bf16_bits(snake_f(v, p.alpha[nm]));
+            }
+        }
+    }
+}
 
 // Block tile BM x BN, BK = 32, 256 threads = 4 waves arranged WGM x WGN; each wave owns
 // (BM/WGM) x (BN/WGN) as 16x16 MFMA tiles.  LDS rows are padded to 40 bf16 (80 B) so the 16-byte
@@ -68,7 +123,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmP p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
     for (int tap = 0; tap < p.ntap; ++tap) {
-        const int off = p.offs[tap];
+        const int off = tap_off(p, tap);
         const bf16_t* Wt = p.W + (size_t)tap * p.N * p.K;
         for (int k0 = 0; k0 < p.K; k0 += BK) {
             // stage A (BM x 32) and B (BN x 32): 16-byte chunks, 4 per row
@@ -102,48 +157,93 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmP p) {
             __syncthreads();
         }
     }
-    // epilogue: lane holds C[row = 4*fq + r][col = fr] of each 16x16 tile
+    tapgemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, b, fr, fq);
+}
+
+// Pipelined variant for K % 64 == 0 (every layer of the real codec).  Per 64-channel chunk the A rows of the
+// block *and its tap halo* (BM + max|off| rows) are staged once and shared by all taps; the B (weight) tile of
+// the next tap is fetched into registers while the current one feeds the MFMAs and is written to the other LDS
+// buffer afterwards: one barrier per (tap, chunk) step, 32 (BN=128) MFMAs per wave between barriers.
+template <int BN>
+__global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
+    constexpr int BM = 128, BK = 64, LD = 72;       // LDS row stride (bf16): 144 B keeps 16-byte alignment, spreads banks
+    constexpr int WM = 64, WN = BN / 2;             // 2 x 2 waves
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int MAXH = 56;                        // largest tap halo (k=7, dilation 9 -> 54)
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    bf16_t* As = lds;                               // [(BM + MAXH)][LD]
+    bf16_t* Bs0 = As + (BM + MAXH) * LD;            // [BN][LD] x 2
+    bf16_t* Bs1 = Bs0 + BN * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
+    const bf16_t* X = p.X + (size_t)b * p.x_bstride;
+    int offmin = 0;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int t = 0; t < 8; ++t) offmin = (t < p.ntap) ? min(offmin, p.offs[t]) : offmin;
+    const int srows = BM - offmin;                  // stripe rows: t in [m0 + offmin, m0 + BM)
+    f32x4 acc[TM][TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + j * 16 + fr;
-            const bool nv = n < p.N;
-            const int nm = nv ? n % p.n_mod : 0;
-            const float bias = (p.bias && nv) ? p.bias[nm] : 0.f;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = m0 + wm * WM + i * 16 + fq * 4 + r;
-                float v = acc[i][j][r] + bias;
-                if (p.round_lin) v = round_bf16(v);
-                if (p.act == ACT_SWIGLU) {
-                    // columns (2i, 2i+1) = (gate, up): partner value sits in the neighbouring lane
-                    const float other = dpp_f<DPP_XOR1>(v);
-                    if ((fr & 1) == 0 && nv && t < p.M) {
-                        const float gate = v, up = other;
-                        float sg = gate / (1.0f + expf(-gate));
-                        if (p.round_lin) sg = round_bf16(sg);
-                        const float o = sg * up;
-                        const size_t oi = (size_t)b * p.o_bstride + (size_t)t * p.ldo + (n >> 1);
-                        if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(o);
-                        if (p.out_f32) p.out_f32[oi] = p.round_f32_out ? round_bf16(o) : o;
-                    }
-                    continue;
-                }
-                if (!nv || t >= p.M) continue;
-                if (p.act == ACT_GELU) v = gelu_f(v);
-                else if (p.act == ACT_TANH) v = tanhf(v);
-                if (p.gamma) v *= p.gamma[nm];
-                const size_t ri = (size_t)b * p.r_bstride + (size_t)t * p.ldr + n;
-                if (p.resid_f32) v += p.resid_f32[ri];
-                if (p.resid_bf) v += bf16_bits_to_f32(p.resid_bf[ri]);
-                const size_t oi = (size_t)b * p.o_bstride + (size_t)t * p.ldo + n;
-                if (p.out_f32) p.out_f32[oi] = p.round_f32_out ? round_bf16(v) : v;
-                if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(v);
-                if (p.out_act) p.out_act[oi] = f32_to_bf16_bits(snake_f(v, p.alpha[nm]));
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr int BCH = BN * 8 / 256;               // 16-byte chunks of a B tile per thread (BN rows x 8 chunks)
+    U4 breg[BCH];
+    auto load_b = [&](int tap, int k0) {
+        const bf16_t* Wt = p.W + (size_t)tap * p.N * p.K;
+#pragma unroll
+        for (int u = 0; u < BCH; ++u) {
+            const int c = tid + 256 * u, r = c >> 3, q = c & 7;
+            breg[u] = (n0 + r < p.N) ? *reinterpret_cast<const U4*>(Wt + (size_t)(n0 + r) * p.K + k0 + q * 8) : U4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_b = [&](bf16_t* Bs) {
+#pragma unroll
+        for (int u = 0; u < BCH; ++u) {
+            const int c = tid + 256 * u, r = c >> 3, q = c & 7;
+            *reinterpret_cast<U4*>(&Bs[r * LD + q * 8]) = breg[u];
+        }
+    };
+    const int nsteps = p.ntap * (p.K / BK);
+    load_b(0, 0);
+    for (int step = 0; step < nsteps; ++step) {
+        const int kc = step / p.ntap, tap = step % p.ntap;
+        bf16_t* Bcur = (step & 1) ? Bs1 : Bs0;
+        if (tap == 0) {
+            // previous chunk's MFMAs are done (barrier at the end of the last step): restage the A stripe
+            for (int c = tid; c < srows * 8; c += 256) {
+                const int r = c >> 3, q = c & 7;
+                const int t = m0 + offmin + r;
+                U4 v = U4{0u, 0u, 0u, 0u};
+                if (t >= 0 && t < p.T_in) v = *reinterpret_cast<const U4*>(X + (size_t)t * p.ldx + kc * BK + q * 8);
+                *reinterpret_cast<U4*>(&As[r * LD + q * 8]) = v;
             }
         }
+        store_b(Bcur);
+        __syncthreads();
+        if (step + 1 < nsteps) load_b((step + 1) % p.ntap, ((step + 1) / p.ntap) * BK);  // in flight during the MFMAs
+        const int arow = tap_off(p, tap) - offmin;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(&As[(arow + wm * WM + i * 16 + fr) * LD + kk * 32 + fq * 8]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(&Bcur[(wn * WN + j * 16 + fr) * LD + kk * 32 + fq * 8]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        // the next step writes the OTHER B buffer; the A stripe is rewritten only at tap == 0 of the next chunk,
+        // which must wait for every wave's reads of this chunk: barrier only then
+        if (tap == p.ntap - 1) __syncthreads();
     }
+    tapgemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, b, fr, fq);
 }
 
 // ---- residual vector quantiser decode (vocoder.py:800-811): x[t][:] = sum_i table_i[code_i[t]][:]
