@@ -297,18 +297,21 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
     int halo = 0;
     for (int i = 0; i < w.ntap; ++i) halo = std::max(halo, -w.offs[i]);
     static const bool legacy = getenv("FT_CODEC_GEMM_V0") != nullptr;
-    if (w.K % 64 == 0 && halo <= 56 && !legacy) {  // pipelined kernel: A stripe shared by the taps, B double-buffered
-        const size_t a_bytes = (size_t)(128 + 56) * 72 * 2;
+    if (w.K % 32 == 0 && halo <= 56 && !legacy) {  // pipelined kernel: A stripe shared by the taps, B double-buffered
+#define FT_TG(BM_, BN_, BK_)                                                                                   \
+    tapgemm64_kernel<BM_, BN_, BK_><<<dim3((io.M + BM_ - 1) / BM_, (w.N + BN_ - 1) / BN_, 1), 256,              \
+                                      (size_t)((BM_ + 56) + 2 * BN_) * (BK_ + 8) * 2, st>>>(p)
+        const bool small_m = io.M <= 1024;          // few row blocks: smaller tiles put more CUs to work
+        const bool k64 = w.K % 64 == 0;
         if (w.N % 128 == 0 || (w.N % 96 != 0 && w.N > 96)) {
-            const dim3 grid((io.M + 127) / 128, (w.N + 127) / 128, 1);
-            tapgemm64_kernel<128><<<grid, 256, a_bytes + 2 * 128 * 72 * 2, st>>>(p);
+            if (small_m) { if (k64) FT_TG(64, 64, 64); else FT_TG(64, 64, 32); }
+            else { if (k64) FT_TG(128, 128, 64); else FT_TG(128, 128, 32); }
         } else if (w.N % 96 == 0) {
-            const dim3 grid((io.M + 127) / 128, w.N / 96, 1);
-            tapgemm64_kernel<96><<<grid, 256, a_bytes + 2 * 96 * 72 * 2, st>>>(p);
+            if (k64) FT_TG(128, 96, 64); else FT_TG(128, 96, 32);
         } else {
-            const dim3 grid((io.M + 127) / 128, (w.N + 63) / 64, 1);
-            tapgemm64_kernel<64><<<grid, 256, a_bytes + 2 * 64 * 72 * 2, st>>>(p);
+            if (k64) FT_TG(128, 64, 64); else FT_TG(128, 64, 32);
         }
+#undef FT_TG
     } else if (w.N >= 128) {
         const dim3 grid((io.M + 127) / 128, (w.N + 127) / 128, 1);
         tapgemm_kernel<128, 128, 2, 2><<<grid, 256, 0, st>>>(p);

@@ -164,12 +164,13 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmP p) {
 // block *and its tap halo* (BM + max|off| rows) are staged once and shared by all taps; the B (weight) tile of
 // the next tap is fetched into registers while the current one feeds the MFMAs and is written to the other LDS
 // buffer afterwards: one barrier per (tap, chunk) step, 32 (BN=128) MFMAs per wave between barriers.
-template <int BN>
+template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
-    constexpr int BM = 128, BK = 64, LD = 72;       // LDS row stride (bf16): 144 B keeps 16-byte alignment, spreads banks
-    constexpr int WM = 64, WN = BN / 2;             // 2 x 2 waves
+    constexpr int LD = BK + 8;                      // LDS row stride (bf16): keeps 16-byte alignment, spreads banks
+    constexpr int WM = BM / 2, WN = BN / 2;         // 2 x 2 waves
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int MAXH = 56;                        // largest tap halo (k=7, dilation 9 -> 54)
+    constexpr int QPR = BK / 8;                     // 16-byte chunks per tile row
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     bf16_t* As = lds;                               // [(BM + MAXH)][LD]
     bf16_t* Bs0 = As + (BM + MAXH) * LD;            // [BN][LD] x 2
@@ -188,21 +189,21 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
-    constexpr int BCH = BN * 8 / 256;               // 16-byte chunks of a B tile per thread (BN rows x 8 chunks)
+    constexpr int BCH = (BN * QPR + 255) / 256;     // 16-byte chunks of a B tile per thread
     U4 breg[BCH];
     auto load_b = [&](int tap, int k0) {
         const bf16_t* Wt = p.W + (size_t)tap * p.N * p.K;
 #pragma unroll
         for (int u = 0; u < BCH; ++u) {
-            const int c = tid + 256 * u, r = c >> 3, q = c & 7;
-            breg[u] = (n0 + r < p.N) ? *reinterpret_cast<const U4*>(Wt + (size_t)(n0 + r) * p.K + k0 + q * 8) : U4{0u, 0u, 0u, 0u};
+            const int c = tid + 256 * u, r = c / QPR, q = c % QPR;
+            breg[u] = (r < BN && n0 + r < p.N) ? *reinterpret_cast<const U4*>(Wt + (size_t)(n0 + r) * p.K + k0 + q * 8) : U4{0u, 0u, 0u, 0u};
         }
     };
     auto store_b = [&](bf16_t* Bs) {
 #pragma unroll
         for (int u = 0; u < BCH; ++u) {
-            const int c = tid + 256 * u, r = c >> 3, q = c & 7;
-            *reinterpret_cast<U4*>(&Bs[r * LD + q * 8]) = breg[u];
+            const int c = tid + 256 * u, r = c / QPR, q = c % QPR;
+            if (r < BN) *reinterpret_cast<U4*>(&Bs[r * LD + q * 8]) = breg[u];
         }
     };
     const int nsteps = p.ntap * (p.K / BK);
@@ -212,8 +213,8 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
         bf16_t* Bcur = (step & 1) ? Bs1 : Bs0;
         if (tap == 0) {
             // previous chunk's MFMAs are done (barrier at the end of the last step): restage the A stripe
-            for (int c = tid; c < srows * 8; c += 256) {
-                const int r = c >> 3, q = c & 7;
+            for (int c = tid; c < srows * QPR; c += 256) {
+                const int r = c / QPR, q = c % QPR;
                 const int t = m0 + offmin + r;
                 U4 v = U4{0u, 0u, 0u, 0u};
                 if (t >= 0 && t < p.T_in) v = *reinterpret_cast<const U4*>(X + (size_t)t * p.ldx + kc * BK + q * 8);
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
         if (step + 1 < nsteps) load_b((step + 1) % p.ntap, ((step + 1) / p.ntap) * BK);  // in flight during the MFMAs
         const int arow = tap_off(p, tap) - offmin;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
