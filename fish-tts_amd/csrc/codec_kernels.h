@@ -190,8 +190,11 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
     constexpr int BCH = (BN * QPR + 255) / 256;     // 16-byte chunks of a B tile per thread
-    U4 breg[BCH];
-    auto load_b = [&](int tap, int k0) {
+    // weight tiles are fetched TWO steps ahead into two named register sets (the MFMA work of one step is far
+    // shorter than an L2 round trip)
+    U4 bregA[BCH], bregB[BCH];
+    auto load_b = [&](U4 (&breg)[BCH], int step) {
+        const int tap = step % p.ntap, k0 = (step / p.ntap) * BK;
         const bf16_t* Wt = p.W + (size_t)tap * p.N * p.K;
 #pragma unroll
         for (int u = 0; u < BCH; ++u) {
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
             breg[u] = (r < BN && n0 + r < p.N) ? *reinterpret_cast<const U4*>(Wt + (size_t)(n0 + r) * p.K + k0 + q * 8) : U4{0u, 0u, 0u, 0u};
         }
     };
-    auto store_b = [&](bf16_t* Bs) {
+    auto store_b = [&](const U4 (&breg)[BCH], bf16_t* Bs) {
 #pragma unroll
         for (int u = 0; u < BCH; ++u) {
             const int c = tid + 256 * u, r = c / QPR, q = c % QPR;
@@ -207,12 +210,10 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
         }
     };
     const int nsteps = p.ntap * (p.K / BK);
-    load_b(0, 0);
-    for (int step = 0; step < nsteps; ++step) {
+    auto do_step = [&](int step, U4 (&breg)[BCH], bf16_t* Bcur) {
         const int kc = step / p.ntap, tap = step % p.ntap;
-        bf16_t* Bcur = (step & 1) ? Bs1 : Bs0;
         if (tap == 0) {
-            // previous chunk's MFMAs are done (barrier at the end of the last step): restage the A stripe
+            // previous chunk's MFMAs are done (barrier at the end of its last step): restage the A stripe
             for (int c = tid; c < srows * QPR; c += 256) {
                 const int r = c / QPR, q = c % QPR;
                 const int t = m0 + offmin + r;
@@ -221,9 +222,9 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
                 *reinterpret_cast<U4*>(&As[r * LD + q * 8]) = v;
             }
         }
-        store_b(Bcur);
+        store_b(breg, Bcur);
         __syncthreads();
-        if (step + 1 < nsteps) load_b((step + 1) % p.ntap, ((step + 1) / p.ntap) * BK);  // in flight during the MFMAs
+        if (step + 2 < nsteps) load_b(breg, step + 2);  // in flight during two steps of MFMAs
         const int arow = tap_off(p, tap) - offmin;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
@@ -243,6 +244,12 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
         // the next step writes the OTHER B buffer; the A stripe is rewritten only at tap == 0 of the next chunk,
         // which must wait for every wave's reads of this chunk: barrier only then
         if (tap == p.ntap - 1) __syncthreads();
+    };
+    load_b(bregA, 0);
+    if (nsteps > 1) load_b(bregB, 1);
+    for (int step = 0; step < nsteps; step += 2) {
+        do_step(step, bregA, Bs0);
+        if (step + 1 < nsteps) do_step(step + 1, bregB, Bs1);
     }
     tapgemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, b, fr, fq);
 }
