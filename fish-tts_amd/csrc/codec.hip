@@ -300,7 +300,8 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
     if (w.K % 32 == 0 && halo <= 56 && !legacy) {  // pipelined kernel: A stripe shared by the taps, B double-buffered
 #define FT_TG(BM_, BN_, BK_)                                                                                   \
     tapgemm64_kernel<BM_, BN_, BK_><<<dim3((io.M + BM_ - 1) / BM_, (w.N + BN_ - 1) / BN_, 1), 256,              \
-                                      (size_t)((BM_ + 56) + 2 * BN_) * (BK_ + 8) * 2, st>>>(p)
+                                      std::max((size_t)((BM_ + 56) + 2 * BN_) * (BK_ + 8) * 2,                  \
+                                               (size_t)(BM_ / 2) * (BN_ + 4) * 4), st>>>(p)
         const bool small_m = io.M <= 1024;          // few row blocks: smaller tiles put more CUs to work
         const bool k64 = w.K % 64 == 0;
         if (w.N % 128 == 0 || (w.N % 96 != 0 && w.N > 96)) {

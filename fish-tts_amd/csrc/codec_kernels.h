@@ -50,7 +50,9 @@ __device__ __forceinline__ int tap_off(const TapGemmP& p, int tap) {
 }
 
 __device__ __forceinline__ float snake_f(float v, float a) {
-    const float s = sinf(a * v);
+    // hardware sine (v_sin_f32 after the 1/2pi scaling): ~1e-6 absolute error, far below the bf16 step of the
+    // value it is stored in; the argument is O(10) here
+    const float s = __sinf(a * v);
     return v + (1.0f / (a + 1e-9f)) * (s * s);
 }
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
@@ -160,6 +162,96 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmP p) {
     tapgemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, b, fr, fq);
 }
 
+// Epilogue through LDS: the accumulators (column-per-lane) are transposed so that each lane finishes 8 consecutive
+// columns of one row: 16-byte loads of the residual, 16-byte stores of every output (the late decoder stages are
+// bandwidth-bound: 2-byte scattered stores were the bottleneck).  Two passes of BM/2 rows.
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void tapgemm_epilogue_lds(const TapGemmP& p, f32x4 (&acc)[TM][TN], float* Cs, const int m0,
+                                                     const int n0, const int b, const int wm, const int wn,
+                                                     const int fr, const int fq) {
+    constexpr int LDC = BN + 4;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+        if (wm == pass) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Cs[(i * 16 + fq * 4 + r) * LDC + wn * WN + j * 16 + fr] = acc[i][j][r];
+        }
+        __syncthreads();
+        for (int v = tid; v < WM * (BN / 8); v += 256) {
+            const int row = v / (BN / 8), c8 = (v % (BN / 8)) * 8;
+            const int t = m0 + pass * WM + row, n = n0 + c8;
+            if (t >= p.M || n >= p.N) continue;
+            const int nm = n % p.n_mod;
+            float x[8];
+            const float4 c0 = *reinterpret_cast<const float4*>(&Cs[row * LDC + c8]);
+            const float4 c1 = *reinterpret_cast<const float4*>(&Cs[row * LDC + c8 + 4]);
+            x[0] = c0.x; x[1] = c0.y; x[2] = c0.z; x[3] = c0.w; x[4] = c1.x; x[5] = c1.y; x[6] = c1.z; x[7] = c1.w;
+            if (p.bias) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] += p.bias[nm + j];
+            }
+            if (p.round_lin) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = round_bf16(x[j]);
+            }
+            if (p.act == ACT_GELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = gelu_f(x[j]);
+            } else if (p.act == ACT_TANH) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = tanhf(x[j]);
+            }
+            if (p.gamma) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] *= p.gamma[nm + j];
+            }
+            const size_t ri = (size_t)b * p.r_bstride + (size_t)t * p.ldr + n;
+            if (p.resid_f32) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] += p.resid_f32[ri + j];
+            }
+            if (p.resid_bf) {
+                float rv[8];
+                Vec<bf16_t>::load(p.resid_bf + ri, rv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] += rv[j];
+            }
+            const size_t oi = (size_t)b * p.o_bstride + (size_t)t * p.ldo + n;
+            if (p.out_f32) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p.out_f32[oi + j] = p.round_f32_out ? round_bf16(x[j]) : x[j];
+            }
+            if (p.out_bf) {
+                U4 o;
+                o.x = f32_to_bf16_bits(x[0]) | ((uint32_t)f32_to_bf16_bits(x[1]) << 16);
+                o.y = f32_to_bf16_bits(x[2]) | ((uint32_t)f32_to_bf16_bits(x[3]) << 16);
+                o.z = f32_to_bf16_bits(x[4]) | ((uint32_t)f32_to_bf16_bits(x[5]) << 16);
+                o.w = f32_to_bf16_bits(x[6]) | ((uint32_t)f32_to_bf16_bits(x[7]) << 16);
+                *reinterpret_cast<U4*>(p.out_bf + oi) = o;
+            }
+            if (p.out_act) {
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = snake_f(x[j], p.alpha[nm + j]);
+                U4 o;
+                o.x = f32_to_bf16_bits(y[0]) | ((uint32_t)f32_to_bf16_bits(y[1]) << 16);
+                o.y = f32_to_bf16_bits(y[2]) | ((uint32_t)f32_to_bf16_bits(y[3]) << 16);
+                o.z = f32_to_bf16_bits(y[4]) | ((uint32_t)f32_to_bf16_bits(y[5]) << 16);
+                o.w = f32_to_bf16_bits(y[6]) | ((uint32_t)f32_to_bf16_bits(y[7]) << 16);
+                *reinterpret_cast<U4*>(p.out_act + oi) = o;
+            }
+        }
+    }
+}
+
 // Pipelined variant for K % 64 == 0 (every layer of the real codec).  Per 64-channel chunk the A rows of the
 // block *and its tap halo* (BM + max|off| rows) are staged once and shared by all taps; the B (weight) tile of
 // the next tap is fetched into registers while the current one feeds the MFMAs and is written to the other LDS
@@ -251,7 +343,10 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
         do_step(step, bregA, Bs0);
         if (step + 1 < nsteps) do_step(step + 1, bregB, Bs1);
     }
-    tapgemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, b, fr, fq);
+    // vector epilogue whenever rows are 16-byte addressable (every real layer); SwiGLU pairs keep the lane epilogue
+    const bool vec_ok = p.act != ACT_SWIGLU && (p.N % 8) == 0 && (p.n_mod % 8) == 0 && (p.ldo % 8) == 0 && (p.ldr % 8) == 0;
+    if (vec_ok) tapgemm_epilogue_lds<BM, BN, TM, TN>(p, acc, reinterpret_cast<float*>(lds), m0, n0, b, wm, wn, fr, fq);
+    else tapgemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, b, fr, fq);
 }
 
 // ---- residual vector quantiser decode (vocoder.py:800-811): x[t][:] = sum_i table_i[code_i[t]][:]
