@@ -167,6 +167,114 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p) {
     });
 }
 
+// Lock-step batches: MB utterance rows share one pass over the weights (each wave keeps MB activation vectors in
+// registers).  Per row the arithmetic (order of the fma chain, wave reduction, roundings) is exactly that of
+// gemv_kernel, so a batched run reproduces the single-utterance run bit for bit.
+template <typename WT, int NT, int R, int MB, bool ROUND>
+__global__ __launch_bounds__(256) void gemv_mb_kernel(GemvP p, int Mrows) {
+    constexpr int VEC = Vec<WT>::N;
+    constexpr int TILE = 64 * VEC;
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= p.N) return;
+    const int m0 = blockIdx.y * MB;
+    const int K = p.K, N = p.N;
+    U4 raw[R][NT];
+    gemv_issue<WT, NT, R>(p, row0, lane, raw);
+    float xv[MB][NT][VEC];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = min(m0 + mb, Mrows - 1);
+        const float* x = p.x + (size_t)m * p.ldx;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int k = t * TILE + lane * VEC;
+            if (k < K) {
+#pragma unroll
+                for (int j = 0; j < VEC; j += 4) {
+                    const float4 f = *reinterpret_cast<const float4*>(x + k + j);
+                    xv[mb][t][j] = f.x; xv[mb][t][j + 1] = f.y; xv[mb][t][j + 2] = f.z; xv[mb][t][j + 3] = f.w;
+                }
+            } else {
+                Vec<WT>::zero(xv[mb][t]);
+            }
+        }
+    }
+    if (p.pro == PRO_RMSNORM) {
+        const WT* gain = reinterpret_cast<const WT*>(p.gain);
+        U4 graw[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int k = t * TILE + lane * VEC;
+            graw[t] = k < K ? *reinterpret_cast<const U4*>(gain + k) : U4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            float ss = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) ss = fmaf(xv[mb][t][j], xv[mb][t][j], ss);
+            ss = wave_sum(ss);
+            const float inv = rsqrt_exact(ss / (float)K + p.eps);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float gv[VEC];
+                Vec<WT>::unpack(graw[t], gv);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) xv[mb][t][j] = rb<ROUND>(rb<ROUND>(xv[mb][t][j] * inv) * gv[j]);
+            }
+        }
+    }
+    float acc[R][MB];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[r][mb] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float wv[VEC];
+            Vec<WT>::unpack(raw[r][t], wv);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[r][mb] = fmaf(wv[j], xv[mb][t][j], acc[r][mb]);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[r][mb] = wave_sum(acc[r][mb]);
+    }
+    const WT* bias = reinterpret_cast<const WT*>(p.bias);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int m = m0 + mb;
+        if (m >= Mrows) continue;
+        if (p.epi == EPI_SWIGLU) {
+#pragma unroll
+            for (int r = 0; r + 1 < R; r += 2) {
+                const int row = row0 + r;
+                if (lane == (r >> 1) * MB + mb && row + 1 < N) {
+                    const float a = rb<ROUND>(acc[r][mb]);
+                    const float b = rb<ROUND>(acc[r + 1][mb]);
+                    const float s = rb<ROUND>(a / (1.0f + expf(-a)));
+                    p.out[(size_t)m * p.ldo + (row >> 1)] = rb<ROUND>(s * b);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int row = row0 + r;
+                if (lane == r * MB + mb && row < N) {
+                    float v = acc[r][mb];
+                    if (bias) v += ld_elem(bias, row);
+                    v = rb<ROUND>(v);
+                    if (p.epi == EPI_RESID) v = rb<ROUND>(p.resid[(size_t)m * p.ldr + row] + v);
+                    p.out[(size_t)m * p.ldo + row] = v;
+                }
+            }
+        }
+    }
+}
+
 // RMSNorm of S rows for the MFMA prefill (llama.py:172-177): f32 normalise, round, * gain, round -> bf16
 template <typename WT, bool ROUND>
 __global__ __launch_bounds__(256) void rmsnorm_llama_rows_kernel(const float* x, const void* gain_, float eps, int D,

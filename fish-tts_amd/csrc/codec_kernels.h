@@ -349,6 +349,112 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
     else tapgemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, b, fr, fq);
 }
 
+// ---- skinny GEMM: few rows (prompt positions / lock-step utterances), weights streamed once ----------------------
+// out[t][n] = sum_k X[t][k] W[n][k] for M <= 16*TS rows per block column.  The problem is weight-bandwidth bound,
+// so the grid is cut along N only (16 weight rows per block => N/16 blocks) and the four waves of a block split K;
+// fragments go straight from global memory into the MFMA operand registers (each lane's 16 bytes are one operand),
+// the four partial tiles meet in LDS and are summed in wave order (deterministic).  Epilogue = the nn.Linear
+// rounding points of the prefill (bias, rounded; residual add, rounded; SwiGLU on interleaved (gate, up) rows).
+// Requires K % 128 == 0; act in {ACT_NONE, ACT_SWIGLU}; ntap == 1.
+template <int TS>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(TapGemmP p) {
+    constexpr int CH = 4;                          // k-steps (of 32) per register chunk
+    __shared__ float Cs[4][TS * 16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * TS);
+    const int kw = wave * (p.K >> 2);              // this wave's K quarter
+    const int nch = (p.K >> 2) / (32 * CH);
+    const int rem = ((p.K >> 2) / 32) % CH;        // k-steps of a last partial chunk
+    const bool nv = n0 + fr < p.N;
+    const bf16_t* wrow = p.W + (size_t)(nv ? n0 + fr : 0) * p.K + kw + fq * 8;
+    const bf16_t* xrow[TS];
+    bool tv[TS];
+#pragma unroll
+    for (int j = 0; j < TS; ++j) {
+        const int t = m0 + j * 16 + fr;
+        tv[j] = t < p.M;
+        xrow[j] = p.X + (size_t)(tv[j] ? t : 0) * p.ldx + kw + fq * 8;
+    }
+    f32x4 acc[TS];
+#pragma unroll
+    for (int j = 0; j < TS; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const U4 zero = U4{0u, 0u, 0u, 0u};
+    auto load = [&](U4 (&w)[CH], U4 (&x)[TS][CH], int k0, int steps) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            if (s < steps) {
+                w[s] = nv ? __builtin_nontemporal_load(reinterpret_cast<const U4*>(wrow + k0 + s * 32)) : zero;
+#pragma unroll
+                for (int j = 0; j < TS; ++j) x[j][s] = tv[j] ? *reinterpret_cast<const U4*>(xrow[j] + k0 + s * 32) : zero;
+            }
+        }
+    };
+    auto compute = [&](const U4 (&w)[CH], const U4 (&x)[TS][CH], int steps) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            if (s < steps) {
+                bf16x8 b;
+                __builtin_memcpy(&b, &w[s], 16);
+#pragma unroll
+                for (int j = 0; j < TS; ++j) {
+                    bf16x8 a;
+                    __builtin_memcpy(&a, &x[j][s], 16);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    };
+    U4 wa[CH], wb[CH], xa[TS][CH], xb[TS][CH];
+    if (nch > 0) load(wa, xa, 0, CH);
+    for (int c = 0; c < nch; c += 2) {
+        if (c + 1 < nch) load(wb, xb, (c + 1) * 32 * CH, CH);
+        compute(wa, xa, CH);
+        if (c + 2 < nch) load(wa, xa, (c + 2) * 32 * CH, CH);
+        if (c + 1 < nch) compute(wb, xb, CH);
+    }
+    if (rem) {
+        load(wa, xa, nch * 32 * CH, rem);
+        compute(wa, xa, rem);
+    }
+    // lane holds C[token = j*16 + 4*fq + r][n = fr]
+#pragma unroll
+    for (int j = 0; j < TS; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[wave][j * 16 + fq * 4 + r][fr] = acc[j][r];
+    __syncthreads();
+    if (p.act == ACT_SWIGLU) {
+        for (int e = tid; e < TS * 16 * 8; e += 256) {
+            const int row = e >> 3, c2 = (e & 7) * 2;
+            const int t = m0 + row, n = n0 + c2;
+            if (t >= p.M || n + 1 >= p.N) continue;
+            float g = ((Cs[0][row][c2] + Cs[1][row][c2]) + Cs[2][row][c2]) + Cs[3][row][c2];
+            float u = ((Cs[0][row][c2 + 1] + Cs[1][row][c2 + 1]) + Cs[2][row][c2 + 1]) + Cs[3][row][c2 + 1];
+            if (p.bias) { g += p.bias[n % p.n_mod]; u += p.bias[(n + 1) % p.n_mod]; }
+            if (p.round_lin) { g = round_bf16(g); u = round_bf16(u); }
+            float sg = g / (1.0f + expf(-g));
+            if (p.round_lin) sg = round_bf16(sg);
+            const float o = sg * u;
+            const size_t oi = (size_t)t * p.ldo + (n >> 1);
+            if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(o);
+            if (p.out_f32) p.out_f32[oi] = p.round_f32_out ? round_bf16(o) : o;
+        }
+    } else {
+        for (int e = tid; e < TS * 16 * 16; e += 256) {
+            const int row = e >> 4, c = e & 15;
+            const int t = m0 + row, n = n0 + c;
+            if (t >= p.M || n >= p.N) continue;
+            float v = ((Cs[0][row][c] + Cs[1][row][c]) + Cs[2][row][c]) + Cs[3][row][c];
+            if (p.bias) v += p.bias[n % p.n_mod];
+            if (p.round_lin) v = round_bf16(v);
+            if (p.resid_f32) v += p.resid_f32[(size_t)t * p.ldr + n];
+            const size_t oi = (size_t)t * p.ldo + n;
+            if (p.out_f32) p.out_f32[oi] = p.round_f32_out ? round_bf16(v) : v;
+            if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(v);
+        }
+    }
+}
+
 // ---- residual vector quantiser decode (vocoder.py:800-811): x[t][:] = sum_i table_i[code_i[t]][:]
 // table_i = out_proj_i(codebook_i) + bias_i, precomputed in f32 at load time.
 struct RvqP {

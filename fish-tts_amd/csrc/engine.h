@@ -64,6 +64,7 @@ struct ft_ctx {
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_y = nullptr;
     ft::bf16_t *pf_xn = nullptr, *pf_ybf = nullptr, *pf_g = nullptr;
     bool prefill_v0 = false;
+    int prefill_gemm_mode = 2;
     size_t cache_m_stride = 0, fcache_m_stride = 0;
 
     // per-slot state
@@ -82,6 +83,7 @@ struct ft_ctx {
     int* samp_part_idx = nullptr;
     bool force_block_sampler = false, wave_sampler = false;
     int nt_weights = 1;
+    int batch_rows = 4;  // utterance rows per weight pass in lock-step batches (1 disables)
 
     std::map<int, hipGraphExec_t> graphs;
 

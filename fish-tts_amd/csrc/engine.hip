@@ -129,6 +129,7 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     const char* ns = getenv("FT_ATTN_NSPLIT");
     ctx->nsplit = ns ? atoi(ns) : (ctx->n_slots > 512 ? 8 : 1);
     ctx->nt_weights = getenv("FT_NO_NT") ? 0 : 1;
+    { const char* br = getenv("FT_BATCH_ROWS"); ctx->batch_rows = br ? atoi(br) : 4; }
     if (ctx->nsplit < 1) ctx->nsplit = 1;
     if (ctx->nsplit > 8) ctx->nsplit = 8;
     ctx->cap = c.max_new_tokens + 24;
@@ -171,6 +172,7 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     FT_TRY(dmalloc(ctx, &ctx->d_done, M));
     FT_TRY(dmalloc(ctx, &ctx->d_prompt, R * (size_t)c.max_seq_len));
     FT_TRY(dmalloc(ctx, &ctx->d_ctl, M));
+    ctx->prefill_gemm_mode = getenv("FT_PREFILL_GEMM") ? atoi(getenv("FT_PREFILL_GEMM")) : 2;
     ctx->prefill_v0 = getenv("FT_PREFILL_V0") != nullptr || c.dtype != FT_BF16 || c.dim % 32 || (c.n_head * c.head_dim) % 32 ||
                       c.intermediate_size % 32;
     if (!ctx->prefill_v0) {
@@ -421,6 +423,14 @@ static int pick_nt(int K, int vec) {
     return -1;
 }
 
+template <typename WT, bool ROUND, int R, int MB>
+static void gemv_mb_nt(Launch& L, const GemvP& p, int nt) {
+    const dim3 grid((p.N + 4 * R - 1) / (4 * R), (L.M + MB - 1) / MB), block(256);
+#define FT_NT(n) case n: gemv_mb_kernel<WT, n, R, MB, ROUND><<<grid, block, 0, L.s>>>(p, L.M); break;
+    switch (nt) { FT_NT(1) FT_NT(2) FT_NT(4) FT_NT(6) default: L.err = hipErrorInvalidValue; }
+#undef FT_NT
+}
+
 template <typename WT, bool ROUND>
 static void gemv(Launch& L, GemvP p, int R) {
     const int nt = pick_nt(p.K, Vec<WT>::N);
@@ -432,7 +442,16 @@ static void gemv(Launch& L, GemvP p, int R) {
         hipEventRecord(e0, L.s);
     }
     if (p.epi == EPI_SWIGLU && R < 2) R = 2;
-    if (R == 1) gemv_nt<WT, ROUND, 1>(L, p, nt);
+    // lock-step batches (bf16): several utterance rows per pass over the weights
+    const bool mb_ok = sizeof(WT) == 2 && L.M >= 2 && ctx->batch_rows > 1 && (nt == 1 || nt == 2 || nt == 4 || nt == 6);
+    if (mb_ok) {
+        if constexpr (sizeof(WT) == 2) {
+            const bool four = L.M >= 3 && nt <= 2 && R <= 2 && ctx->batch_rows >= 4;  // register budget: 4 x NT x 8 activations
+            if (R >= 4) { if (nt <= 2) gemv_mb_nt<WT, ROUND, 4, 2>(L, p, nt); else gemv_nt<WT, ROUND, 4>(L, p, nt); }
+            else if (R == 2) { if (four) gemv_mb_nt<WT, ROUND, 2, 4>(L, p, nt); else gemv_mb_nt<WT, ROUND, 2, 2>(L, p, nt); }
+            else { if (four) gemv_mb_nt<WT, ROUND, 1, 4>(L, p, nt); else gemv_mb_nt<WT, ROUND, 1, 2>(L, p, nt); }
+        }
+    } else if (R == 1) gemv_nt<WT, ROUND, 1>(L, p, nt);
     else if (R == 2) gemv_nt<WT, ROUND, 2>(L, p, nt);
     else gemv_nt<WT, ROUND, 4>(L, p, nt);
     if (ctx->prof) {
@@ -781,7 +800,23 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
     p.X = X; p.ldx = ldx; p.T_in = S; p.W = (const bf16_t*)W; p.ntap = 1; p.offs[0] = 0; p.M = S; p.N = N; p.K = K;
     p.bias = bias; p.n_mod = N; p.act = act; p.resid_f32 = resid; p.ldr = ldo; p.out_f32 = out_f32; p.out_bf = out_bf;
     p.ldo = ldo; p.round_lin = 1; p.round_f32_out = round_out;
-    if (N >= 128) tapgemm_kernel<128, 128, 2, 2><<<dim3((S + 127) / 128, (N + 127) / 128, 1), 256, 0, L.s>>>(p);
+    const int mode = L.ctx->prefill_gemm_mode;  // FT_PREFILL_GEMM: 0 = first tile kernel only, 1 = no skinny kernel
+    if (mode >= 2 && S <= 128 && K % 128 == 0 && N % 2 == 0) {
+        // short prompts are weight-bandwidth bound: 16 weight rows per block, K split over the waves
+        const int nb = (N + 15) / 16;
+        if (S <= 16) skinny_gemm_kernel<1><<<dim3(nb, 1), 256, 0, L.s>>>(p);
+        else if (S <= 32) skinny_gemm_kernel<2><<<dim3(nb, 1), 256, 0, L.s>>>(p);
+        else skinny_gemm_kernel<4><<<dim3(nb, (S + 63) / 64), 256, 0, L.s>>>(p);
+    } else if (mode >= 1 && K % 64 == 0 && N % 128 == 0) {
+        // long prompts (reference audio): the pipelined tile kernel of the codec
+        if (S <= 1024) {
+            const size_t lds = std::max((size_t)((64 + 56) + 2 * 64) * (64 + 8) * 2, (size_t)(64 / 2) * (64 + 4) * 4);
+            tapgemm64_kernel<64, 64, 64><<<dim3((S + 63) / 64, N / 64, 1), 256, lds, L.s>>>(p);
+        } else {
+            const size_t lds = std::max((size_t)((128 + 56) + 2 * 128) * (64 + 8) * 2, (size_t)(128 / 2) * (128 + 4) * 4);
+            tapgemm64_kernel<128, 128, 64><<<dim3((S + 127) / 128, N / 128, 1), 256, lds, L.s>>>(p);
+        }
+    } else if (N >= 128) tapgemm_kernel<128, 128, 2, 2><<<dim3((S + 127) / 128, (N + 127) / 128, 1), 256, 0, L.s>>>(p);
     else tapgemm_kernel<128, 64, 4, 1><<<dim3((S + 127) / 128, (N + 63) / 64, 1), 256, 0, L.s>>>(p);
     L.chk();
 }

@@ -150,6 +150,42 @@ def test_medium_shapes_greedy_vs_oracle(precision):
     eng.close()
 
 
+@pytest.mark.parametrize("Lp", [12, 40, 100, 200])
+def test_prefill_gemm_paths_vs_oracle(monkeypatch, Lp):
+    """The S = Lp prompt pass (skinny split-K MFMA kernel for Lp <= 128, pipelined tile kernel above, first tile
+    kernel with FT_PREFILL_GEMM=0, position-by-position decode kernels with FT_PREFILL_V0) all reproduce the oracle's
+    frame-0 logits within the bf16 evaluation-order tolerance, and pick the oracle's first frame unless the oracle's
+    own top-2 margin is inside that tolerance."""
+    shape = medium_shape()
+    prompt = make_prompt(shape, Lp, seed=20 + Lp, n_vq=3)
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.0)
+    taps = []
+    orc = None
+    results = {}
+    for mode, env in [("default", {}), ("tile64", {"FT_PREFILL_GEMM": "1"}), ("tile_v0", {"FT_PREFILL_GEMM": "0"}),
+                      ("per_position", {"FT_PREFILL_V0": "1"})]:
+        for k in ("FT_PREFILL_GEMM", "FT_PREFILL_V0"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng, o = make_pair(shape, "bf16", std=0.05)
+        if orc is None:
+            orc = o
+            want = orc.generate(prompt.clone(), 1, frame_taps=taps, **kw).numpy()
+        first = eng.prefill(prompt.numpy(), eng._sampling(0.7, 1e-6, 1.0))
+        logits, _ = eng.debug_state()
+        results[mode] = (first.copy(), logits.copy())
+        eng.close()
+    ref_logits = taps[0][0].float().reshape(-1).numpy()
+    scale = max(1.0, float(np.max(np.abs(ref_logits))))
+    for mode, (first, logits) in results.items():
+        assert np.max(np.abs(logits - ref_logits)) <= 0.05 * scale, mode
+        got = np.concatenate([prompt.numpy(), first[:, None]], axis=1)
+        div = first_divergence(got, want[:, : Lp + 1])
+        if div is not None:
+            assert _margin_ok(taps, 0, div[1], 0.03 * scale), (mode, div)
+
+
 def test_split_kv_attention_matches_single_block(monkeypatch):
     shape = tiny_shape()
     prompt = make_prompt(shape, 40, seed=4, n_vq=4).numpy()
