@@ -150,13 +150,13 @@ def test_medium_shapes_greedy_vs_oracle(precision):
     eng.close()
 
 
-@pytest.mark.parametrize("Lp", [12, 40, 100, 200])
+@pytest.mark.parametrize("Lp", [12, 40, 100, 200, 700, 1100])
 def test_prefill_gemm_paths_vs_oracle(monkeypatch, Lp):
     """The S = Lp prompt pass (skinny split-K MFMA kernel for Lp <= 128, pipelined tile kernel above, first tile
     kernel with FT_PREFILL_GEMM=0, position-by-position decode kernels with FT_PREFILL_V0) all reproduce the oracle's
     frame-0 logits within the bf16 evaluation-order tolerance, and pick the oracle's first frame unless the oracle's
     own top-2 margin is inside that tolerance."""
-    shape = medium_shape()
+    shape = medium_shape(max_seq_len=2048)   # 700 = a 30 s voice-cloning reference; 1100 reaches the 128x128 tiles
     prompt = make_prompt(shape, Lp, seed=20 + Lp, n_vq=3)
     kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.0)
     taps = []
@@ -216,6 +216,24 @@ def test_lockstep_batch_equals_single(monkeypatch):
     for i, p in enumerate(prompts):
         got = np.concatenate([p, firsts[i][:, None], frames[i, : n[i]].T], axis=1)
         assert np.array_equal(got, singles[i]), i
+    eng.close()
+
+
+def test_batch32_mixed_lengths_equals_single():
+    """BASELINE configs[2]: 32 utterances of mixed prompt lengths and mixed frame budgets in one captured lock-step
+    graph; every utterance reproduces its own single-slot run (EOS allowed, so lengths differ)."""
+    shape = tiny_shape()
+    B = 32
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    prompts = [make_prompt(shape, 5 + (7 * i) % 23, seed=100 + i, n_vq=i % 4).numpy() for i in range(B)]
+    eng, _ = make_pair(shape, "bf16", max_batch=B)
+    singles = [eng.generate(p, 12, **kw) for p in prompts]
+    sp = eng._sampling(0.7, 1e-6, 1.1)
+    firsts = [eng.prefill(p, sp, slot=i) for i, p in enumerate(prompts)]
+    frames, n = eng.decode(11, [sp] * B, poll=4)
+    for i, p in enumerate(prompts):
+        got = np.concatenate([p, firsts[i][:, None], frames[i, : n[i]].T], axis=1)
+        assert np.array_equal(got[:, : singles[i].shape[1]], singles[i]), i
     eng.close()
 
 
