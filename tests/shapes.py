@@ -42,3 +42,15 @@ def make_prompt(shape, T, seed, n_vq=0):
         p[1, col] = code0
         p[2:, col] = torch.randint(0, min(1024, shape.codebook_size), (shape.num_codebooks - 1,), generator=g)
     return p
+
+
+def s1mini_shape(max_seq_len=128):
+    """openaudio-s1-mini widths and depths (SURVEY.md §8 'Shapes'), ids laid out as tokenizer.py:83-101."""
+    n_sem = 4096
+    n_text = 155776 - 15 - n_sem
+    return ARShape(vocab_size=155776, n_layer=28, n_head=16, dim=1024, intermediate_size=3072, n_local_heads=8,
+                   head_dim=128, rope_base=1e6, norm_eps=1e-6, max_seq_len=max_seq_len, tie_word_embeddings=True,
+                   attention_qk_norm=True, codebook_size=4096, num_codebooks=10, scale_codebook_embeddings=True,
+                   n_fast_layer=4, fast_dim=1024, fast_n_head=16, fast_n_local_heads=8, fast_head_dim=64,
+                   fast_intermediate_size=3072, fast_attention_qk_norm=False, initializer_range=0.02,
+                   semantic_begin_id=n_text + 15, semantic_end_id=n_text + 15 + n_sem - 1, im_end_id=n_text + 4)

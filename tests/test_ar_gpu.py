@@ -150,6 +150,36 @@ def test_medium_shapes_greedy_vs_oracle(precision):
     eng.close()
 
 
+def test_s1mini_shapes_greedy_vs_reference_golden():
+    """G6: the real model shapes (28+4 layers, V = 155 776, 700 M seeded parameters) in bf16 against frames the
+    REFERENCE produced (tests/golden/make_golden_s1mini.py).  Indices must be equal; a difference is accepted only
+    at a decision whose top-1/top-2 logit margin in the reference run was within the bf16 evaluation-order tolerance
+    (recorded in the fixture; V = 155 776 bf16 logits do produce exact ties)."""
+    from fish_tts_amd.ar_engine import ARHipEngine
+    from tests.hip_util import args_from_shape
+    from tests.shapes import s1mini_shape
+    g = np.load(os.path.join(G, "ar_s1mini.npz"))
+    shape = s1mini_shape()
+    w = O.random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]), dtype=torch.bfloat16)
+    eng = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,
+                      precision="bf16", device=0, max_batch=1, max_new_tokens=16)
+    eng.load_state_dict(w)
+    del w
+    prompt, want = g["prompt"], g["bf16.seq"]
+    T, n_new = prompt.shape[1], int(g["n_new"])
+    got = eng.generate(prompt, n_new, temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    tol = 0.03 * max(1.0, float(g["bf16.logit_absmax"]))
+    div = first_divergence(got, want)
+    if div is not None:
+        col, row = div
+        cb = 0 if row <= 1 else row - 1
+        assert float(g["bf16.margins"][col - T, cb]) <= tol, f"diverged at column {col}, row {row}\n{got[:, T:]}\n{want[:, T:]}"
+    else:
+        blocks = list(eng.generate_streaming(prompt, n_new, temperature=0.7, top_p=1e-6, repetition_penalty=1.1))
+        assert np.array_equal(np.concatenate(blocks, axis=1), g["bf16.stream"])
+    eng.close()
+
+
 @pytest.mark.parametrize("Lp", [12, 40, 100, 200, 700, 1100])
 def test_prefill_gemm_paths_vs_oracle(monkeypatch, Lp):
     """The S = Lp prompt pass (skinny split-K MFMA kernel for Lp <= 128, pipelined tile kernel above, first tile

@@ -70,3 +70,18 @@ def test_batch_drops_last_column_stream_keeps_it():
     seq, stream = gold["greedy_rep1.1.seq"], gold["greedy_rep1.1.stream"]
     assert seq.shape[1] - T == stream.shape[1]
     assert np.array_equal(seq[1:, T:], stream)
+
+
+def test_ar_oracle_matches_reference_at_s1mini_shapes():
+    """G6: the real model shapes (28+4 layers, V = 155 776), bf16, seeded weights regenerated here (~40 s, 6 GB)."""
+    from tests.shapes import s1mini_shape
+    g = np.load(os.path.join(G, "ar_s1mini.npz"))
+    shape = s1mini_shape()
+    w = O.random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]))
+    orc = O.AROracle(shape, w, torch.bfloat16)
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    prompt = torch.from_numpy(g["prompt"])
+    got = orc.generate(prompt.clone(), int(g["n_new"]), **kw).numpy()
+    assert np.array_equal(got, g["bf16.seq"])
+    cols = list(orc.generate_stream(prompt.clone(), int(g["n_new"]), **kw))
+    assert np.array_equal(torch.cat(cols, dim=1).numpy(), g["bf16.stream"])
