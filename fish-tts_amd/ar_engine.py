@@ -82,6 +82,8 @@ class ARHipEngine:
     # ------------------------------------------------------------------ lifecycle
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
+            for pf in list(getattr(self, "_prefixes", [])):
+                pf.free()
             self.lib.ft_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -134,13 +136,38 @@ class ARHipEngine:
         s.seed, s.ban_eos = int(seed) & (2 ** 64 - 1), 1 if ban_eos else 0
         return s
 
-    def prefill(self, prompt: np.ndarray, sampling: L.ft_sampling, slot: int = 0) -> np.ndarray:
+    def prefill(self, prompt: np.ndarray, sampling: L.ft_sampling, slot: int = 0, pos0: int = 0) -> np.ndarray:
+        """Feeds the (R, Lp) prompt at cache positions [pos0, pos0 + Lp); returns the first generated frame.
+        pos0 > 0 continues a restored prefix (kv_restore)."""
         prompt = np.ascontiguousarray(prompt, dtype=np.int32)
         assert prompt.ndim == 2 and prompt.shape[0] == self.R, prompt.shape
         out = np.zeros(self.R, dtype=np.int32)
-        self._check(self.lib.ft_ar_prefill(self._h, slot, prompt.ctypes.data_as(C.c_void_p), prompt.shape[1],
-                                           C.byref(sampling), out.ctypes.data_as(C.c_void_p)), "ft_ar_prefill")
+        self._check(self.lib.ft_ar_prefill_at(self._h, slot, prompt.ctypes.data_as(C.c_void_p), prompt.shape[1], pos0,
+                                              C.byref(sampling), out.ctypes.data_as(C.c_void_p)), "ft_ar_prefill")
         return out
+
+    # ---- reference-prefix K/V reuse (SURVEY.md §8-f F1)
+    def kv_save(self, n_pos: int, slot: int = 0) -> "KVPrefix":
+        h = C.c_void_p()
+        self._check(self.lib.ft_ar_kv_save(self._h, slot, n_pos, C.byref(h)), "ft_ar_kv_save")
+        return KVPrefix(self, h, n_pos)
+
+    def kv_restore(self, prefix: "KVPrefix", slot: int = 0) -> None:
+        if prefix.engine is not self or not prefix.handle:
+            raise ValueError("KV prefix belongs to another engine or was freed")
+        self._check(self.lib.ft_ar_kv_restore(self._h, prefix.handle, slot), "ft_ar_kv_restore")
+
+    def build_prefix(self, prefix_cols: np.ndarray, slot: int = 0) -> "KVPrefix":
+        """K/V of a prompt prefix (its own prefill; the sampled frame is discarded)."""
+        self.prefill(prefix_cols, self._sampling(0.7, 0.7, 1.0), slot)
+        return self.kv_save(prefix_cols.shape[1], slot)
+
+    def _start(self, prompt: np.ndarray, sp, prefix: Optional["KVPrefix"], slot: int = 0) -> np.ndarray:
+        if prefix is None:
+            return self.prefill(prompt, sp, slot)
+        assert 0 < prefix.n_pos < prompt.shape[1], (prefix.n_pos, prompt.shape)
+        self.kv_restore(prefix, slot)
+        return self.prefill(prompt[:, prefix.n_pos:], sp, slot, pos0=prefix.n_pos)
 
     def decode(self, n_frames: int, samplings: Sequence[L.ft_sampling], poll: int = 8):
         ns = len(samplings)
@@ -199,25 +226,28 @@ class ARHipEngine:
         return min(max_new_tokens, self.max_new_tokens)
 
     def generate(self, prompt: np.ndarray, max_new_tokens: int, temperature: float = 0.7, top_p: float = 0.7,
-                 repetition_penalty: float = 1.5, seed: int = 0, ban_eos: bool = False, poll: int = 8) -> np.ndarray:
-        """(R, T) int32 prompt -> (R, T + n) int32, n <= max_new_tokens, stopping after <|im_end|>."""
+                 repetition_penalty: float = 1.5, seed: int = 0, ban_eos: bool = False, poll: int = 8,
+                 prefix: Optional["KVPrefix"] = None) -> np.ndarray:
+        """(R, T) int32 prompt -> (R, T + n) int32, n <= max_new_tokens, stopping after <|im_end|>.
+        `prefix`: saved K/V of the first prefix.n_pos prompt columns (only the rest is prefilled)."""
         prompt = np.ascontiguousarray(prompt, dtype=np.int32)
         T = prompt.shape[1]
         n_new = self._clamp_new(T, max_new_tokens)
         sp = self._sampling(temperature, top_p, repetition_penalty, seed, ban_eos)
-        first = self.prefill(prompt, sp, 0)
+        first = self._start(prompt, sp, prefix)
         frames, n = self.decode(n_new - 1, [sp], poll)
         return np.concatenate([prompt, first[:, None], frames[0, : n[0]].T], axis=1)
 
     def generate_streaming(self, prompt: np.ndarray, max_new_tokens: int, temperature: float = 0.7,
                            top_p: float = 0.7, repetition_penalty: float = 1.5, seed: int = 0,
-                           ban_eos: bool = False, chunk: int = 8) -> Iterator[np.ndarray]:
+                           ban_eos: bool = False, chunk: int = 8,
+                           prefix: Optional["KVPrefix"] = None) -> Iterator[np.ndarray]:
         """Yields (num_codebooks, k) code blocks as they are produced, <|im_end|> frame included
         (inference.py:645-738, 218-276); `chunk` frames per graph burst."""
         prompt = np.ascontiguousarray(prompt, dtype=np.int32)
         n_new = self._clamp_new(prompt.shape[1], max_new_tokens)
         sp = self._sampling(temperature, top_p, repetition_penalty, seed, ban_eos)
-        first = self.prefill(prompt, sp, 0)
+        first = self._start(prompt, sp, prefix)
         yield first[1:, None]
         left = n_new - 1
         while left > 0:
@@ -228,3 +258,20 @@ class ARHipEngine:
             left -= k
             if n[0] < k or (n[0] > 0 and frames[0, n[0] - 1, 0] == self.im_end_id):
                 break
+
+
+class KVPrefix:
+    """Device-resident K/V of the first n_pos prompt positions (one per voice); freed with the engine."""
+
+    def __init__(self, engine: ARHipEngine, handle, n_pos: int):
+        self.engine, self.handle, self.n_pos = engine, handle, n_pos
+        if not hasattr(engine, "_prefixes"):
+            engine._prefixes = []
+        engine._prefixes.append(self)
+
+    def free(self) -> None:
+        if self.handle:
+            self.engine.lib.ft_ar_kv_free(self.engine._h, self.handle)
+            self.handle = None
+        if self in getattr(self.engine, "_prefixes", []):
+            self.engine._prefixes.remove(self)

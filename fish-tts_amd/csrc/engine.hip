@@ -821,7 +821,7 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
     L.chk();
 }
 
-static void prefill_gemm(Launch& L, int slot, int Lp) {
+static void prefill_gemm(Launch& L, int slot, int Lp, int pos0) {
     ft_ctx* ctx = L.ctx;
     const ft_ar_config& c = ctx->c;
     const int D = c.dim, HD = c.n_head * c.head_dim, F = c.intermediate_size;
@@ -844,7 +844,7 @@ static void prefill_gemm(Launch& L, int slot, int Lp) {
         a.qkv = ctx->pf_qkv; a.ldq = qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->rope;
         a.kc = (char*)l.kc + (size_t)slot * ctx->cache_m_stride * ctx->esz;
         a.vc = (char*)l.vc + (size_t)slot * ctx->cache_m_stride * ctx->esz;
-        a.cache_m_stride = 0; a.pos = nullptr; a.pos_off = 0; a.row_is_pos = 1;
+        a.cache_m_stride = 0; a.pos = nullptr; a.pos_off = pos0; a.row_is_pos = 1;
         a.H = c.n_head; a.Hkv = c.n_local_heads; a.hd = c.head_dim; a.n_slots = ctx->n_slots; a.nsplit = 1;
         a.eps = c.norm_eps; a.scale = 1.0f / sqrtf((float)c.head_dim); a.y = ctx->pf_y; a.ldy = HD; a.y_bf = ctx->pf_ybf;
         Launch LA = L;
@@ -873,16 +873,17 @@ static void prefill_gemm(Launch& L, int slot, int Lp) {
     enqueue_frame_tail<bf16_t, true>(L);
 }
 
-extern "C" ft_status ft_ar_prefill(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_t Lp,
-                                   const ft_sampling* sp, int32_t* out_frame) {
+extern "C" ft_status ft_ar_prefill_at(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_t Lp, int32_t pos0,
+                                      const ft_sampling* sp, int32_t* out_frame) {
     FT_TRY(ar_ready(ctx));
     const ft_ar_config& c = ctx->c;
     if (!prompt || !sp || !out_frame) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill: null argument");
     if (slot < 0 || slot >= c.max_batch) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill: bad slot");
     if (Lp < 1) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill: empty prompt");
-    if (Lp >= c.max_seq_len) {  // inference.py:296-299
+    if (pos0 < 0) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill_at: pos0 < 0");
+    if (pos0 + Lp >= c.max_seq_len) {  // inference.py:296-299
         char buf[128];
-        snprintf(buf, sizeof buf, "Input sequence length %d exceeds max_seq_len %d", Lp, c.max_seq_len);
+        snprintf(buf, sizeof buf, "Input sequence length %d exceeds max_seq_len %d", pos0 + Lp, c.max_seq_len);
         return ft_fail(ctx, FT_ERR_TOO_LONG, buf);
     }
     const int R = c.num_codebooks + 1;
@@ -891,24 +892,89 @@ extern "C" ft_status ft_ar_prefill(ft_ctx* ctx, int32_t slot, const int32_t* pro
     FT_HIP(ctx, hipMemcpyAsync(ctx->d_prompt, prompt, (size_t)R * Lp * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     Launch L{ctx, ctx->stream, slot, 1, 0};
     if (!ctx->prefill_v0) {
-        prefill_gemm(L, slot, Lp);
+        prefill_gemm(L, slot, Lp, pos0);
     } else {
         // f32 precision (and shapes the MFMA tiles do not cover): the prompt is fed through the S=1 decode
         // kernels position by position (same causal arithmetic); only the last position runs the head
         for (int t = 0; t < Lp - 1; ++t) {
-            L.pos_off = t;
+            L.pos_off = pos0 + t;
             enqueue_slow_only(L, ctx->d_prompt, Lp, 0, t);
         }
-        L.pos_off = Lp - 1;
+        L.pos_off = pos0 + Lp - 1;
         enqueue_frame(L, ctx->d_prompt, Lp, 0, Lp - 1);
     }
     if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("prefill launch: ") + hipGetErrorString(L.err));
-    // finalize() advanced pos 0 -> 1; the next input position is Lp
-    ctx->h_pin[0] = Lp;
+    // finalize() advanced pos 0 -> 1; the next input position is pos0 + Lp
+    ctx->h_pin[0] = pos0 + Lp;
     FT_HIP(ctx, hipMemcpyAsync(ctx->d_pos + slot, ctx->h_pin, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     FT_HIP(ctx, hipMemcpyAsync(out_frame, ctx->d_tok + (size_t)slot * R, R * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FT_OK;
+}
+
+extern "C" ft_status ft_ar_prefill(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_t Lp,
+                                   const ft_sampling* sp, int32_t* out_frame) {
+    return ft_ar_prefill_at(ctx, slot, prompt, Lp, 0, sp, out_frame);
+}
+
+// ---- reference-prefix K/V snapshots: [layer][K|V][Hkv][n_pos][hd] packed, in the cache's element type
+struct ft_kv_snapshot {
+    char* data = nullptr;
+    int n_pos = 0;
+    size_t bytes = 0;
+};
+
+static ft_status kv_copy(ft_ctx* ctx, char* snap, int n_pos, int slot, bool save) {
+    const ft_ar_config& c = ctx->c;
+    const size_t row = (size_t)n_pos * c.head_dim * ctx->esz;            // one head's positions [0, n_pos)
+    const size_t pitch = (size_t)ctx->n_slots * c.head_dim * ctx->esz;   // head stride inside the cache
+    for (int li = 0; li < c.n_layer; ++li) {
+        const FtLayer& l = ctx->layers[li];
+        for (int kv = 0; kv < 2; ++kv) {
+            char* cache = (char*)(kv ? l.vc : l.kc) + (size_t)slot * ctx->cache_m_stride * ctx->esz;
+            char* packed = snap + ((size_t)li * 2 + kv) * c.n_local_heads * row;
+            if (save) FT_HIP(ctx, hipMemcpy2DAsync(packed, row, cache, pitch, row, c.n_local_heads, hipMemcpyDeviceToDevice, ctx->stream));
+            else FT_HIP(ctx, hipMemcpy2DAsync(cache, pitch, packed, row, row, c.n_local_heads, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    }
+    return FT_OK;
+}
+
+extern "C" ft_status ft_ar_kv_save(ft_ctx* ctx, int32_t slot, int32_t n_pos, ft_kv_snapshot** out) {
+    FT_TRY(ar_ready(ctx));
+    const ft_ar_config& c = ctx->c;
+    if (!out) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_kv_save: null argument");
+    if (slot < 0 || slot >= c.max_batch) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_kv_save: bad slot");
+    if (n_pos < 1 || n_pos > ctx->n_slots) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_kv_save: bad n_pos");
+    ft_kv_snapshot* s = new ft_kv_snapshot();
+    s->n_pos = n_pos;
+    s->bytes = (size_t)c.n_layer * 2 * c.n_local_heads * n_pos * c.head_dim * ctx->esz;
+    if (hipMalloc((void**)&s->data, s->bytes) != hipSuccess) {
+        delete s;
+        return ft_fail(ctx, FT_ERR_HIP, "ft_ar_kv_save: out of device memory");
+    }
+    ft_status st = kv_copy(ctx, s->data, n_pos, slot, true);
+    if (st == FT_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = ft_fail(ctx, FT_ERR_HIP, "ft_ar_kv_save: copy failed");
+    if (st != FT_OK) { hipFree(s->data); delete s; return st; }
+    *out = s;
+    return FT_OK;
+}
+
+extern "C" ft_status ft_ar_kv_restore(ft_ctx* ctx, const ft_kv_snapshot* snap, int32_t slot) {
+    FT_TRY(ar_ready(ctx));
+    if (!snap || !snap->data) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_kv_restore: null snapshot");
+    if (slot < 0 || slot >= ctx->c.max_batch) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_kv_restore: bad slot");
+    if (snap->n_pos > ctx->n_slots) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_kv_restore: snapshot longer than the cache");
+    return kv_copy(ctx, snap->data, snap->n_pos, slot, false);  // stream-ordered before the next prefill
+}
+
+extern "C" int32_t ft_ar_kv_positions(const ft_kv_snapshot* snap) { return snap ? snap->n_pos : 0; }
+
+extern "C" void ft_ar_kv_free(ft_ctx* ctx, ft_kv_snapshot* snap) {
+    if (!snap) return;
+    if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+    if (snap->data) hipFree(snap->data);
+    delete snap;
 }
 
 static ft_status get_graph(ft_ctx* ctx, int M, hipGraphExec_t* out) {

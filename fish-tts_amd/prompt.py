@@ -69,10 +69,11 @@ class ContentSequence:
         return np.concatenate(cols, axis=1) if cols else np.zeros((num_codebooks + 1, 0), dtype=np.int32)
 
 
-def build_prompt(tokenizer, text: str, prompt_text: Optional[Sequence[str]], prompt_tokens: Optional[Sequence],
-                 num_codebooks: int) -> np.ndarray:
-    """[<|interleave|>, (<|speaker:0|>, ref text, ref codes, <|im_end|>)*, <|speaker:0|>, text]
-    (inference.py:767-793)."""
+def build_prompt_split(tokenizer, text: str, prompt_text: Optional[Sequence[str]], prompt_tokens: Optional[Sequence],
+                       num_codebooks: int):
+    """-> (matrix, n_prefix): the prompt of build_prompt and the number of leading columns that do not depend on
+    `text` -- [<|interleave|>, (<|speaker:0|>, ref text, ref codes, <|im_end|>)*] -- i.e. the part whose K/V a
+    voice can keep (0 without references)."""
     use_prompt = prompt_text is not None and prompt_tokens is not None
     if use_prompt and isinstance(prompt_text, str):
         prompt_text, prompt_tokens = [prompt_text], [prompt_tokens]
@@ -83,5 +84,19 @@ def build_prompt(tokenizer, text: str, prompt_text: Optional[Sequence[str]], pro
         for t, c in zip(prompt_text, prompt_tokens):
             c = c.cpu().numpy() if hasattr(c, "cpu") else np.asarray(c)
             seq.append([TextPart(text=t), VQPart(codes=c)], add_end=True, speaker=0)
+    n_parts = len(seq.parts)
+    has_refs = use_prompt and len(prompt_text) > 0
     seq.append([TextPart(text=text)], add_end=False, speaker=0)
-    return seq.encode_for_inference(tokenizer, num_codebooks)
+    full = seq.encode_for_inference(tokenizer, num_codebooks)
+    n_prefix = 0
+    if has_refs:
+        head = ContentSequence(seq.parts[:n_parts])
+        n_prefix = head.encode_for_inference(tokenizer, num_codebooks).shape[1]
+    return full, n_prefix
+
+
+def build_prompt(tokenizer, text: str, prompt_text: Optional[Sequence[str]], prompt_tokens: Optional[Sequence],
+                 num_codebooks: int) -> np.ndarray:
+    """[<|interleave|>, (<|speaker:0|>, ref text, ref codes, <|im_end|>)*, <|speaker:0|>, text]
+    (inference.py:767-793)."""
+    return build_prompt_split(tokenizer, text, prompt_text, prompt_tokens, num_codebooks)[0]

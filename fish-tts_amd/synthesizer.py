@@ -51,7 +51,12 @@ class FishTTS:
 
     def __init__(self, model_dir=None, device: Literal["cpu", "cuda"] = "cuda",
                  precision: Literal["bf16", "fp16", "fp32"] = "bf16", warmup: bool = True, *,
-                 _synthetic: Optional[dict] = None, gpu_index: int = 0):
+                 _synthetic: Optional[dict] = None, gpu_index: int = 0, cache_reference_kv: bool = True):
+        """`cache_reference_kv` (extension): keep the K/V of the reference part of the prompt on
+        the device per voice, so a cloned-voice call prefills only the new text (the reference re-prefills ~700
+        prompt positions per call: synthesizer.py:363-377, inference.py:779-793)."""
+        from .generation import PrefixCache
+        self._prefix_cache = PrefixCache() if cache_reference_kv else None
         self.device = device
         self._precision = precision
         self._warmup = warmup
@@ -128,9 +133,10 @@ class FishTTS:
 
     @classmethod
     def synthetic(cls, args, tokenizer, codec_args=None, precision="bf16", seed: int = 0, warmup: bool = False,
-                  with_codec: bool = True, max_new_tokens: int = 2048 + 8, std=None, gpu_index: int = 0) -> "FishTTS":
+                  with_codec: bool = True, max_new_tokens: int = 2048 + 8, std=None, gpu_index: int = 0,
+                  cache_reference_kv: bool = True) -> "FishTTS":
         """Random-init model of the given shapes (no checkpoint on disk): benches, smoke tests."""
-        return cls(None, "cuda", precision, warmup, gpu_index=gpu_index,
+        return cls(None, "cuda", precision, warmup, gpu_index=gpu_index, cache_reference_kv=cache_reference_kv,
                    _synthetic=dict(args=args, tokenizer=tokenizer, codec_args=codec_args, seed=seed,
                                    with_codec=with_codec, max_new_tokens=max_new_tokens, std=std))
 
@@ -199,7 +205,7 @@ class FishTTS:
             for response in generate_long(engine=self._engine, tokenizer=self._tokenizer, text=text,
                                           max_new_tokens=max_tokens, temperature=temperature, top_p=top_p,
                                           repetition_penalty=repetition_penalty, prompt_text=prompt_text,
-                                          prompt_tokens=prompt_tokens):
+                                          prompt_tokens=prompt_tokens, prefix_cache=self._prefix_cache):
                 if response.action == "sample":
                     codes_list.append(response.codes)
                 elif response.action == "next":
@@ -239,7 +245,8 @@ class FishTTS:
                                               max_new_tokens=kwargs.get("max_tokens", 2048),
                                               temperature=kwargs.get("temperature", 0.7), top_p=kwargs.get("top_p", 0.8),
                                               repetition_penalty=kwargs.get("repetition_penalty", 1.1),
-                                              prompt_text=prompt_text, prompt_tokens=prompt_tokens, streaming=True):
+                                              prompt_text=prompt_text, prompt_tokens=prompt_tokens, streaming=True,
+                                              prefix_cache=self._prefix_cache):
                     if response.action == "sample":
                         buffer.append(response.codes)
                         total_tokens += response.codes.shape[1]

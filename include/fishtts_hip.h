@@ -88,6 +88,21 @@ ft_status ft_ar_reset(ft_ctx* ctx, int32_t slot);
  * generated frame (num_codebooks+1 int32) to out_frame (host).  No repetition penalty. */
 ft_status ft_ar_prefill(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_t Lp,
                         const ft_sampling* sp, int32_t* out_frame);
+/* Reference-prefix KV reuse (the reference keeps the reference tensors in
+ * `_prefill_cache` but re-prefills them on every call: synthesizer.py:363-429, inference.py:779-793,
+ * 353-362).  The prompt prefix [<|interleave|>, (<|speaker:0|>, ref text, ref codes, <|im_end|>)*] does
+ * not depend on the text to speak, and the model is causal, so its K/V are computed once:
+ *   ft_ar_prefill(slot, prefix)  ->  ft_ar_kv_save(slot, n_prefix)            (once per voice)
+ *   ft_ar_kv_restore(snap, slot) ->  ft_ar_prefill_at(slot, tail, pos0=n_prefix)  (per utterance)
+ * ft_ar_prefill_at feeds `Lp` prompt columns at cache positions [pos0, pos0+Lp) of a slot whose
+ * positions [0, pos0) already hold K/V; pos0 = 0 is ft_ar_prefill. */
+typedef struct ft_kv_snapshot ft_kv_snapshot;
+ft_status ft_ar_prefill_at(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_t Lp, int32_t pos0,
+                           const ft_sampling* sp, int32_t* out_frame);
+ft_status ft_ar_kv_save(ft_ctx* ctx, int32_t slot, int32_t n_pos, ft_kv_snapshot** out);
+ft_status ft_ar_kv_restore(ft_ctx* ctx, const ft_kv_snapshot* snap, int32_t slot);
+int32_t ft_ar_kv_positions(const ft_kv_snapshot* snap);
+void ft_ar_kv_free(ft_ctx* ctx, ft_kv_snapshot* snap);
 /* Decode loop = decode_n_tokens[_streaming] (inference.py:158-276) driving decode_one_token_ar
  * (inference.py:83-155), for slots [0, nslots) in lock step, up to n_frames more frames each.
  * out_frames: nslots x n_frames x (num_codebooks+1) int32 (host), frame-major; out_n[slot] =

@@ -122,3 +122,39 @@ def test_references_enter_the_prompt(tts):
     assert wav_with != wav_without
     with pytest.raises(AssertionError, match="top_p"):
         synth.synthesize("x", top_p=0.0)
+
+
+def test_reference_kv_is_cached_per_voice_and_changes_nothing(tts):
+    """SURVEY §8-f F1 through the public API: the K/V of the reference part of the prompt is computed once per voice;
+    codes equal the oracle's on the full prompt (fp32: exact)."""
+    synth, tok, orc, corc, shape, cshape = tts
+    import fish_tts_amd as ft
+    from fish_tts_amd.generation import generate_long
+    from fish_tts_amd.prompt import build_prompt_split
+    g = np.random.default_rng(9)
+    ref = np.concatenate([g.integers(0, 2048, (1, 40)), g.integers(0, 1024, (9, 40))]).astype(np.int64)
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    cache = synth._prefix_cache
+    cache.clear()
+    for text in ("Yo", "Another sentence"):
+        res = [r for r in generate_long(engine=synth._engine, tokenizer=tok, text=text, max_new_tokens=8,
+                                        prompt_text=["ref text"], prompt_tokens=[ref], prefix_cache=cache, **kw)
+               if r.action == "sample"]
+        prompt, n_prefix = build_prompt_split(tok, text, ["ref text"], [ref], 10)
+        assert n_prefix >= 40 + 2
+        seq = _oracle_codes(orc, prompt, 8, **kw)
+        assert np.array_equal(res[0].codes, seq[1:, prompt.shape[1]:-1]), text
+        assert len(cache) == 1
+    prof = ft.VoiceProfile(codes=ref, text="ref text", name="v")
+    a = synth.synthesize("Yo", references=[prof], max_tokens=8, **kw)
+    saved, synth._prefix_cache = synth._prefix_cache, None
+    try:
+        b = synth.synthesize("Yo", references=[prof], max_tokens=8, **kw)
+    finally:
+        synth._prefix_cache = saved
+    assert a == b
+    other = ft.VoiceProfile(codes=ref[:, ::-1].copy(), text="ref text", name="w")
+    synth.synthesize("Yo", references=[other], max_tokens=4, **kw)
+    assert len(cache) == 2
+    cache.clear()
+    assert len(cache) == 0

@@ -249,6 +249,52 @@ def test_lockstep_batch_equals_single(monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_prefix_kv_reuse_equals_full_prefill(precision):
+    """K/V of a prompt prefix saved once, restored into a (dirtied) slot, only the tail prefilled.
+    At these shapes every prompt GEMM is row-independent, so the result must equal the full prefill exactly."""
+    shape = tiny_shape()
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    prompt = make_prompt(shape, 40, seed=5, n_vq=4).numpy()
+    eng, _ = make_pair(shape, precision)
+    full = eng.generate(prompt, 10, **kw)
+    pf = eng.build_prefix(prompt[:, :29])
+    assert pf.n_pos == 29
+    eng.generate(make_prompt(shape, 33, seed=6, n_vq=1).numpy(), 4, **kw)   # overwrite the slot's cache
+    again = eng.generate(prompt, 10, prefix=pf, **kw)
+    assert np.array_equal(full, again)
+    blocks = list(eng.generate_streaming(prompt, 10, prefix=pf, **kw))
+    assert np.array_equal(np.concatenate(blocks, axis=1)[:, : full.shape[1] - 40], full[1:, 40:])
+    other = prompt.copy()
+    other[0, 35] += 1                                                        # same prefix, different tail
+    assert np.array_equal(eng.generate(other, 6, **kw), eng.generate(other, 6, prefix=pf, **kw))
+    pf.free()
+    with pytest.raises(ValueError):
+        eng.generate(prompt, 4, prefix=pf, **kw)
+    eng.close()
+
+
+def test_prefix_kv_reuse_at_model_widths_vs_oracle():
+    """Same at s1-mini widths in bf16, where the tail (skinny split-K kernel) and a full prompt (tile kernel) sum in
+    different orders: frame-0 logits within the bf16 evaluation-order tolerance of the oracle's."""
+    shape = medium_shape()
+    prompt = make_prompt(shape, 200, seed=31, n_vq=3)
+    eng, orc = make_pair(shape, "bf16", std=0.05)
+    taps = []
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.0)
+    want = orc.generate(prompt.clone(), 1, frame_taps=taps, **kw).numpy()
+    ref_logits = taps[0][0].float().reshape(-1).numpy()
+    scale = max(1.0, float(np.max(np.abs(ref_logits))))
+    pf = eng.build_prefix(prompt.numpy()[:, :150])
+    got = eng.generate(prompt.numpy(), 1, prefix=pf, **kw)
+    logits, _ = eng.debug_state()
+    assert np.max(np.abs(logits - ref_logits)) <= 0.05 * scale
+    div = first_divergence(got, want)
+    if div is not None:
+        assert _margin_ok(taps, 0, div[1], 0.03 * scale), div
+    eng.close()
+
+
 def test_batch32_mixed_lengths_equals_single():
     """BASELINE configs[2]: 32 utterances of mixed prompt lengths and mixed frame budgets in one captured lock-step
     graph; every utterance reproduces its own single-slot run (EOS allowed, so lengths differ)."""

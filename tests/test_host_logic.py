@@ -114,3 +114,23 @@ def test_config_defaults_follow_reference_rules():
     assert a.head_dim == 64 and a.n_local_heads == 8 and a.intermediate_size == 1536 and a.fast_dim == 512
     b = s1_mini_args()
     assert (b.dim, b.n_layer, b.n_head, b.num_codebooks, b.codebook_size, b.vocab_size) == (1024, 28, 16, 10, 4096, 155776)
+
+
+def test_prompt_prefix_split_is_text_independent():
+    """build_prompt_split: the leading n_prefix columns are [interleave, (speaker, ref text, ref codes, im_end)*]
+    and do not change with the text to speak (what the reference-prefix K/V cache keys on)."""
+    from fish_tts_amd.prompt import build_prompt, build_prompt_split
+    from fish_tts_amd.tokenizer import ByteTokenizer
+    tok = ByteTokenizer()
+    rng = np.random.default_rng(0)
+    codes = np.concatenate([rng.integers(0, 4096, (1, 37)), rng.integers(0, 1024, (9, 37))]).astype(np.int32)
+    a, na = build_prompt_split(tok, "Hello world", ["ref transcript"], [codes], 10)
+    b, nb = build_prompt_split(tok, "Something else entirely.", ["ref transcript"], [codes], 10)
+    assert na == nb and na > 37
+    assert np.array_equal(a[:, :na], b[:, :nb])
+    assert a[0, na - 1] == tok.get_token_id("<|im_end|>")
+    assert np.array_equal(a, build_prompt(tok, "Hello world", ["ref transcript"], [codes], 10))
+    c, nc = build_prompt_split(tok, "Hello world", [], [], 10)
+    assert nc == 0 and c.shape[1] < a.shape[1]
+    d, nd = build_prompt_split(tok, "Hello world", None, None, 10)
+    assert nd == 0 and np.array_equal(c, d)
