@@ -146,6 +146,10 @@ class ARHipEngine:
                                               C.byref(sampling), out.ctypes.data_as(C.c_void_p)), "ft_ar_prefill")
         return out
 
+    def park(self, slot: int) -> None:
+        """Marks a slot idle (finished) for lock-step decoding until its next prefill."""
+        self._check(self.lib.ft_ar_park(self._h, slot), "ft_ar_park")
+
     # ---- reference-prefix K/V reuse (SURVEY.md §8-f F1)
     def kv_save(self, n_pos: int, slot: int = 0) -> "KVPrefix":
         h = C.c_void_p()

@@ -826,13 +826,16 @@ __device__ __forceinline__ void finish_draw(const SampP& p, const int m, const i
     const WT* fe = reinterpret_cast<const WT*>(p.fast_emb);
     for (int d = tid; d < p.Df; d += T) p.femb[(size_t)m * p.Df + d] = ld_elem(fe, (size_t)code * p.Df + d);
     if (p.last) {
+        // a slot that has emitted <|im_end|> (or is parked) stays frozen while the rest of the lock-step batch
+        // goes on: its position, frame count and frame store no longer move
+        const int frozen = p.done[m];
         __syncthreads();
         if (tid < R) {
             const int v = tokn[tid];
             p.tok[(size_t)m * R + tid] = v;
-            if (nfv < p.cap) seq[(size_t)tid * p.cap + nfv] = v;
+            if (nfv < p.cap && !frozen) seq[(size_t)tid * p.cap + nfv] = v;
         }
-        if (tid == 0) {
+        if (tid == 0 && !frozen) {
             p.pos[m] += 1;
             p.nf[m] = nfv + 1;
             if (tokn[0] == p.im_end) p.done[m] = 1;
@@ -983,7 +986,7 @@ __global__ __launch_bounds__(1024) void sample_block_kernel(SampP p) {
             float q;
             if (qrow) q = qrow[i];
             else {
-                q = exp1_from_word(philox_word((uint32_t)i, (uint32_t)p.cb, (uint32_t)nfv, (uint32_t)m,
+                q = exp1_from_word(philox_word((uint32_t)i, (uint32_t)p.cb, (uint32_t)nfv, 0u /* not the slot: a draw depends on (seed, frame, codebook, index) only */,
                                                (uint32_t)ctl.seed, (uint32_t)(ctl.seed >> 32)));
             }
             q = rb<ROUND>(q);
@@ -1003,7 +1006,7 @@ __global__ __launch_bounds__(1024) void sample_block_kernel(SampP p) {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float draw_noise(const SampP& p, const RowCtl& ctl, const float* qrow, int i, int nfv, int m) {
     if (qrow) return qrow[i];
-    return exp1_from_word(philox_word((uint32_t)i, (uint32_t)p.cb, (uint32_t)nfv, (uint32_t)m,
+    return exp1_from_word(philox_word((uint32_t)i, (uint32_t)p.cb, (uint32_t)nfv, 0u /* not the slot: a draw depends on (seed, frame, codebook, index) only */,
                                       (uint32_t)ctl.seed, (uint32_t)(ctl.seed >> 32)));
 }
 // the four draws of elements 4g .. 4g+3 from one Philox call
@@ -1014,7 +1017,7 @@ __device__ __forceinline__ void draw_noise4(const SampP& p, const RowCtl& ctl, c
         for (int e = 0; e < 4; ++e) q[e] = (i4 + e) < V ? qrow[i4 + e] : 1.f;
         return;
     }
-    const Philox4 r = philox4((uint32_t)(i4 >> 2), (uint32_t)p.cb, (uint32_t)nfv, (uint32_t)m,
+    const Philox4 r = philox4((uint32_t)(i4 >> 2), (uint32_t)p.cb, (uint32_t)nfv, 0u /* not the slot: a draw depends on (seed, frame, codebook, index) only */,
                               (uint32_t)ctl.seed, (uint32_t)(ctl.seed >> 32));
 #pragma unroll
     for (int e = 0; e < 4; ++e) q[e] = exp1_from_word(r.w[e]);

@@ -196,7 +196,7 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     FT_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     FT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     FT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    FT_HIP(ctx, hipHostMalloc((void**)&ctx->h_pin, (2 * M + 8) * sizeof(int), hipHostMallocDefault));
+    FT_HIP(ctx, hipHostMalloc((void**)&ctx->h_pin, (3 * M + 8) * sizeof(int), hipHostMallocDefault));
     return FT_OK;
 }
 
@@ -1015,10 +1015,13 @@ extern "C" ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames,
     FT_HIP(ctx, hipMemcpyAsync(h, ctx->d_nf, nslots * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     FT_HIP(ctx, hipMemcpyAsync(h + nslots, ctx->d_pos, nslots * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FT_HIP(ctx, hipMemcpyAsync(h + 2 * nslots, ctx->d_done, nslots * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<int> nf0(h, h + nslots);
     int budget = n_frames;
     for (int m = 0; m < nslots; ++m) {
         if (nf0[m] < 1) return ft_fail(ctx, FT_ERR_STATE, "ft_ar_decode: slot has not been prefilled");
+        if (h[2 * nslots + m]) continue;  // finished or parked: frozen on the device, limits nothing
         budget = std::min(budget, ctx->cap - nf0[m]);
         budget = std::min(budget, ctx->n_slots - h[nslots + m]);  // cache positions left
     }
@@ -1060,6 +1063,23 @@ extern "C" ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames,
         if (nf0[m] >= 1 && seq[nf0[m] - 1] == c.im_end_id) n = 0;
         out_n[m] = n;
     }
+    return FT_OK;
+}
+
+extern "C" ft_status ft_ar_park(ft_ctx* ctx, int32_t slot) {
+    FT_TRY(ar_ready(ctx));
+    const ft_ar_config& c = ctx->c;
+    if (slot < 0 || slot >= c.max_batch) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_park: bad slot");
+    const int R = c.num_codebooks + 1;
+    FT_TRY(ft_ar_reset(ctx, slot));
+    // one stored frame = <|im_end|>, done = 1, a harmless input column (token 0, codes 0) at position 0
+    int* h = ctx->h_pin;
+    h[0] = c.im_end_id; h[1] = 1;
+    FT_HIP(ctx, hipMemcpyAsync(ctx->d_seq + (size_t)slot * R * ctx->cap, h, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    FT_HIP(ctx, hipMemcpyAsync(ctx->d_nf + slot, h + 1, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    FT_HIP(ctx, hipMemcpyAsync(ctx->d_done + slot, h + 1, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    FT_HIP(ctx, hipMemsetAsync(ctx->d_tok + (size_t)slot * R, 0, R * sizeof(int), ctx->stream));
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FT_OK;
 }
 

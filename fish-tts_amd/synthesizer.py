@@ -51,12 +51,15 @@ class FishTTS:
 
     def __init__(self, model_dir=None, device: Literal["cpu", "cuda"] = "cuda",
                  precision: Literal["bf16", "fp16", "fp32"] = "bf16", warmup: bool = True, *,
-                 _synthetic: Optional[dict] = None, gpu_index: int = 0, cache_reference_kv: bool = True):
-        """`cache_reference_kv` (extension): keep the K/V of the reference part of the prompt on
+                 _synthetic: Optional[dict] = None, gpu_index: int = 0, cache_reference_kv: bool = True,
+                 max_batch: int = 1):
+        """`max_batch` (extension): utterance slots for synthesize_batch (lock-step batch with refill).
+        `cache_reference_kv` (extension): keep the K/V of the reference part of the prompt on
         the device per voice, so a cloned-voice call prefills only the new text (the reference re-prefills ~700
         prompt positions per call: synthesizer.py:363-377, inference.py:779-793)."""
         from .generation import PrefixCache
         self._prefix_cache = PrefixCache() if cache_reference_kv else None
+        self._max_batch = int(max_batch)
         self.device = device
         self._precision = precision
         self._warmup = warmup
@@ -102,7 +105,8 @@ class FishTTS:
         self._tokenizer = load_tokenizer(self._model_dir)
         tok = self._tokenizer
         self._engine = ARHipEngine(args, tok.semantic_begin_id, tok.semantic_end_id, tok.get_token_id(IM_END_TOKEN),
-                                   precision=self._precision, device=self._gpu_index, max_batch=1, max_new_tokens=2048 + 8)
+                                   precision=self._precision, device=self._gpu_index, max_batch=self._max_batch,
+                                   max_new_tokens=2048 + 8)
         self._engine.load_state_dict(load_checkpoint(self._model_dir))
         logger.info("Transformer loaded in %.1fs", time.perf_counter() - t0)
         codec_path = self._model_dir / "codec.pth"
@@ -125,7 +129,7 @@ class FishTTS:
         dtype = torch.bfloat16 if self._precision == "bf16" else torch.float32
         self._engine = ARHipEngine(args, tokenizer.semantic_begin_id, tokenizer.semantic_end_id,
                                    tokenizer.get_token_id(IM_END_TOKEN), precision=self._precision,
-                                   device=self._gpu_index, max_batch=1, max_new_tokens=max_new_tokens)
+                                   device=self._gpu_index, max_batch=self._max_batch, max_new_tokens=max_new_tokens)
         self._engine.load_state_dict(random_state_dict(args, seed=seed, dtype=dtype, std=std))
         if with_codec:
             self._vocoder = CodecHipEngine.synthetic(device=self._gpu_index, max_frames=max_new_tokens, seed=seed,
@@ -134,9 +138,10 @@ class FishTTS:
     @classmethod
     def synthetic(cls, args, tokenizer, codec_args=None, precision="bf16", seed: int = 0, warmup: bool = False,
                   with_codec: bool = True, max_new_tokens: int = 2048 + 8, std=None, gpu_index: int = 0,
-                  cache_reference_kv: bool = True) -> "FishTTS":
+                  cache_reference_kv: bool = True, max_batch: int = 1) -> "FishTTS":
         """Random-init model of the given shapes (no checkpoint on disk): benches, smoke tests."""
         return cls(None, "cuda", precision, warmup, gpu_index=gpu_index, cache_reference_kv=cache_reference_kv,
+                   max_batch=max_batch,
                    _synthetic=dict(args=args, tokenizer=tokenizer, codec_args=codec_args, seed=seed,
                                    with_codec=with_codec, max_new_tokens=max_new_tokens, std=std))
 
@@ -213,6 +218,37 @@ class FishTTS:
         if not codes_list:
             raise RuntimeError("No audio generated")
         return self._decode_to_wav(np.concatenate(codes_list, axis=1))
+
+    def synthesize_batch(self, texts: List[str], references: Optional[List[VoiceProfile]] = None,
+                         temperature: float = 0.7, top_p: float = 0.8, repetition_penalty: float = 1.1,
+                         max_tokens: int = 2048, seed: int = 0) -> List[bytes]:
+        """Extension (BASELINE configs[2]): many texts -> WAV bytes each, decoded `max_batch` at a time in lock step
+        with refill (fish_tts_amd.batch); utterance i uses seed + i.  Same per-utterance semantics as synthesize()."""
+        from .batch import Utterance, run_batch
+        from .prompt import build_prompt_split
+        assert 0 < top_p <= 1, "top_p must be in (0, 1]"
+        assert 0 < repetition_penalty < 2, "repetition_penalty must be in (0, 2)"
+        assert 0 < temperature < 2, "temperature must be in (0, 2)"
+        prompt_text, prompt_tokens = self._get_prompt_data(references)
+        ncb = self._engine.args.num_codebooks
+        with self._gen_lock:
+            utts = []
+            for i, text in enumerate(texts):
+                enc, n_prefix = build_prompt_split(self._tokenizer, text, prompt_text, prompt_tokens, ncb)
+                if enc.shape[1] > self._engine.args.max_seq_len - 2048:
+                    raise ValueError(f"Prompt is too long: {enc.shape[1]} > {self._engine.args.max_seq_len - 2048}")
+                prefix = None
+                if self._prefix_cache is not None and n_prefix >= self._prefix_cache.min_positions:
+                    prefix = self._prefix_cache.get(self._engine, enc[:, :n_prefix])
+                utts.append(Utterance(enc, max_tokens, temperature, top_p, repetition_penalty, seed + i, prefix=prefix))
+            run_batch(self._engine, utts)
+        out = []
+        for u in utts:
+            codes = u.codes()
+            if codes.shape[1] == 0:
+                raise RuntimeError("No audio generated")
+            out.append(self._decode_to_wav(codes))
+        return out
 
     def synthesize_stream(self, text: str, references: Optional[List[VoiceProfile]] = None, chunk_tokens: int = 20,
                           min_first_chunk: int = 10, **kwargs) -> Iterator[bytes]:

@@ -88,6 +88,11 @@ ft_status ft_ar_reset(ft_ctx* ctx, int32_t slot);
  * generated frame (num_codebooks+1 int32) to out_frame (host).  No repetition penalty. */
 ft_status ft_ar_prefill(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_t Lp,
                         const ft_sampling* sp, int32_t* out_frame);
+/* Marks a slot idle for lock-step decoding: it counts as already finished (ft_ar_decode reports 0 frames for
+ * it and it limits nothing); a later ft_ar_prefill[_at] on the slot re-activates it.  Slots that emit
+ * <|im_end|> freeze the same way on the device, so a host scheduler can refill finished slots between
+ * ft_ar_decode bursts (continuous batching; the reference serves one utterance at a time, synthesizer.py:431). */
+ft_status ft_ar_park(ft_ctx* ctx, int32_t slot);
 /* Reference-prefix KV reuse (the reference keeps the reference tensors in
  * `_prefill_cache` but re-prefills them on every call: synthesizer.py:363-429, inference.py:779-793,
  * 353-362).  The prompt prefix [<|interleave|>, (<|speaker:0|>, ref text, ref codes, <|im_end|>)*] does

@@ -158,3 +158,12 @@ def test_reference_kv_is_cached_per_voice_and_changes_nothing(tts):
     assert len(cache) == 2
     cache.clear()
     assert len(cache) == 0
+
+
+def test_synthesize_batch_equals_synthesize(tts):
+    synth, tok, orc, corc, shape, cshape = tts
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    texts = ["Hi there", "Yo", "A third, longer sentence."]
+    singles = [synth.synthesize(t, max_tokens=10, **kw) for t in texts]
+    assert synth.synthesize_batch(texts, max_tokens=10, **kw) == singles
+    assert synth.synthesize_batch([], max_tokens=10, **kw) == []

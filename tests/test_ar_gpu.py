@@ -313,6 +313,30 @@ def test_batch32_mixed_lengths_equals_single():
     eng.close()
 
 
+def test_continuous_batching_equals_single_runs():
+    """fish_tts_amd.batch.run_batch: 11 utterances (mixed prompt lengths, frame budgets, greedy and seeded top-p,
+    one with a saved K/V prefix) through 4 slots with refill; each equals its single-slot run."""
+    from fish_tts_amd.batch import Utterance, run_batch
+    shape = tiny_shape()
+    eng, _ = make_pair(shape, "bf16", max_batch=4)
+    utts, singles = [], []
+    for i in range(11):
+        prompt = make_prompt(shape, 6 + (5 * i) % 17, seed=200 + i, n_vq=i % 3).numpy()
+        kw = dict(temperature=0.7, top_p=1e-6 if i % 2 == 0 else 0.8, repetition_penalty=1.1, seed=50 + i)
+        budget = 3 + (4 * i) % 13
+        singles.append(eng.generate(prompt, budget, **kw))
+        utts.append(Utterance(prompt, budget, **kw))
+    pf = eng.build_prefix(utts[4].prompt[:, :5])
+    utts[4].prefix = pf
+    seen = {}
+    run_batch(eng, utts, burst=4, on_frames=lambda i, blk: seen.__setitem__(i, seen.get(i, 0) + blk.shape[1]))
+    for i, (u, want) in enumerate(zip(utts, singles)):
+        got = np.concatenate([u.prompt, u.columns()], axis=1)
+        assert np.array_equal(got, want), i
+        assert seen[i] == u.columns().shape[1]
+    eng.close()
+
+
 def test_eager_frame_equals_graph_replay(monkeypatch):
     shape = tiny_shape()
     prompt = make_prompt(shape, 9, seed=1, n_vq=3).numpy()
