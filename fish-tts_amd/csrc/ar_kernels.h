@@ -595,6 +595,7 @@ struct FastAttnP {
     int c;              // codebook position of this step (0..ncb-1)
     int H, Hkv, hd, ncb;
     float eps, scale;
+    bf16_t* y_bf;       // optional bf16 copy of y (operand of the MFMA Wo GEMM in wide batches)
 };
 
 constexpr int FAST_MAXCB = 16;
@@ -696,7 +697,11 @@ __global__ __launch_bounds__(64) void fast_attn_kernel(FastAttnP a, float* y, in
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
         const int d = lane + 64 * e;
-        if (d < hd) y[(size_t)m * ldy + (size_t)h * hd + d] = rb<ROUND>(o[e]);
+        if (d < hd) {
+            const float yo = rb<ROUND>(o[e]);
+            y[(size_t)m * ldy + (size_t)h * hd + d] = yo;
+            if (a.y_bf) a.y_bf[(size_t)m * ldy + (size_t)h * hd + d] = f32_to_bf16_bits(yo);
+        }
     }
 }
 

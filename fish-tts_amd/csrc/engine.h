@@ -63,6 +63,10 @@ struct ft_ctx {
     // MFMA prefill workspace (bf16 precision): S = max_seq_len rows
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_y = nullptr;
     ft::bf16_t *pf_xn = nullptr, *pf_ybf = nullptr, *pf_g = nullptr;
+    // lock-step batches of >= wide_min utterances run every Linear on the MFMA skinny kernel (bf16 operand copies)
+    ft::bf16_t *mb_xn = nullptr, *mb_ybf = nullptr, *mb_g = nullptr;
+    int wide_min = 8;
+    bool wide_ok = false;
     bool prefill_v0 = false;
     int prefill_gemm_mode = 2;
     size_t cache_m_stride = 0, fcache_m_stride = 0;

@@ -183,6 +183,15 @@ static ft_status ar_alloc(ft_ctx* ctx) {
         FT_TRY(dmalloc(ctx, &ctx->pf_xn, S * c.dim));
         FT_TRY(dmalloc(ctx, &ctx->pf_ybf, S * c.n_head * c.head_dim));
         FT_TRY(dmalloc(ctx, &ctx->pf_g, S * c.intermediate_size));
+        // wide lock-step batches: no fast-layer f32 bias copies exist, and the fast widths must fit the MFMA tiles
+        ctx->wide_ok = !getenv("FT_NO_WIDE") && !c.fast_attention_qkv_bias && !c.fast_attention_o_bias &&
+                       c.fast_dim % 32 == 0 && (c.fast_n_head * c.fast_head_dim) % 32 == 0 && c.fast_intermediate_size % 32 == 0;
+        if (getenv("FT_WIDE_MIN")) ctx->wide_min = std::max(1, atoi(getenv("FT_WIDE_MIN")));
+        if (ctx->wide_ok) {
+            FT_TRY(dmalloc(ctx, &ctx->mb_xn, M * (size_t)std::max(c.dim, c.fast_dim)));
+            FT_TRY(dmalloc(ctx, &ctx->mb_ybf, M * (size_t)std::max(c.n_head * c.head_dim, c.fast_n_head * c.fast_head_dim)));
+            FT_TRY(dmalloc(ctx, &ctx->mb_g, M * (size_t)std::max(c.intermediate_size, c.fast_intermediate_size)));
+        }
     }
     const size_t nchunk = ((size_t)c.vocab_size + 1023) / 1024;
     FT_TRY(dmalloc(ctx, &ctx->samp_hist, M * SAMP_HIST_STRIDE));
@@ -252,7 +261,7 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     int* ibufs[] = {ctx->d_pos, ctx->d_tok, ctx->d_tokn, ctx->d_seq, ctx->d_nf, ctx->d_done, ctx->d_prompt};
     for (int* b : ibufs) if (b) hipFree(b);
     if (ctx->d_ctl) hipFree(ctx->d_ctl);
-    { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g}; for (void* q : pf) if (q) hipFree(q); }
+    { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g, ctx->mb_xn, ctx->mb_ybf, ctx->mb_g}; for (void* q : pf) if (q) hipFree(q); }
     for (auto& l : ctx->layers) { if (l.bqkv_f32) hipFree(l.bqkv_f32); if (l.bo_f32) hipFree(l.bo_f32); }
     if (ctx->samp_hist) hipFree(ctx->samp_hist);
     if (ctx->samp_cut) hipFree(ctx->samp_cut);
@@ -408,6 +417,14 @@ struct Launch {
     void chk() { hipError_t e = hipGetLastError(); if (e != hipSuccess && err == hipSuccess) err = e; }
 };
 
+static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, const float* bias, int N, int K,
+                    int act, const float* resid, float* out_f32, bf16_t* out_bf, long ldo, int round_out);
+// A lock-step batch of >= wide_min rows (bf16): every Linear is an M-row GEMM on the MFMA skinny kernel (weights read
+// once for the whole batch), norms run as their own row kernels, attention hands bf16 copies to the Wo GEMM.
+static bool wide_batch(const Launch& L) {
+    return L.ctx->wide_ok && L.ctx->c.dtype == FT_BF16 && L.M >= L.ctx->wide_min && !L.gemv_only && !L.ctx->prof;
+}
+
 template <typename WT, bool ROUND, int R>
 static void gemv_nt(Launch& L, const GemvP& p, int nt) {
     const dim3 grid((p.N + 4 * R - 1) / (4 * R), L.M), block(256);
@@ -542,8 +559,34 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
     if (!L.gemv_only) embed_kernel<WT, ROUND><<<dim3((c.dim + 255) / 256, L.M), 256, 0, L.s>>>(e);
     L.chk();
 
+    const bool wide = wide_batch(L);
     for (int li = 0; li < c.n_layer; ++li) {
         const FtLayer& l = ctx->layers[li];
+        if (wide) {
+            if constexpr (ROUND) {
+                const int D = c.dim, HD = c.n_head * c.head_dim, F = c.intermediate_size, M = L.M;
+                bf16_t* xn = ctx->mb_xn + (size_t)m0 * D;
+                bf16_t* ybf = ctx->mb_ybf + (size_t)m0 * HD;
+                bf16_t* gbf = ctx->mb_g + (size_t)m0 * F;
+                rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.attn_norm, c.norm_eps, D, xn);
+                pf_gemm(L, xn, D, M, l.wqkv, l.bqkv_f32, (int)qkvN, D, ACT_NONE, nullptr, qkv, nullptr, (long)qkvN, 0);
+                AttnP a{};
+                a.qkv = qkv; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->rope;
+                a.kc = (char*)l.kc + (size_t)m0 * ctx->cache_m_stride * ctx->esz;
+                a.vc = (char*)l.vc + (size_t)m0 * ctx->cache_m_stride * ctx->esz;
+                a.cache_m_stride = ctx->cache_m_stride; a.pos = ctx->d_pos + m0; a.pos_off = L.pos_off;
+                a.H = c.n_head; a.Hkv = c.n_local_heads; a.hd = c.head_dim; a.n_slots = ctx->n_slots;
+                a.nsplit = 1;  // M x Hkv blocks already fill the chip
+                a.eps = c.norm_eps; a.scale = 1.0f / sqrtf((float)c.head_dim);
+                a.y = y; a.ldy = HD; a.y_bf = ybf;
+                attn_decode<WT, ROUND>(L, a);
+                pf_gemm(L, ybf, HD, M, l.wo, l.bo_f32, D, HD, ACT_NONE, x, x, nullptr, D, 1);
+                rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.ffn_norm, c.norm_eps, D, xn);
+                pf_gemm(L, xn, D, M, l.w13, nullptr, 2 * F, D, ACT_SWIGLU, nullptr, nullptr, gbf, F, 0);
+                pf_gemm(L, gbf, F, M, l.w2, nullptr, D, F, ACT_NONE, x, x, nullptr, D, 1);
+            }
+            continue;
+        }
         GemvP p{};
         p.W = l.wqkv; p.bias = l.bqkv; p.x = x; p.ldx = c.dim; p.gain = l.attn_norm; p.eps = c.norm_eps;
         p.out = qkv; p.ldo = (int)qkvN; p.N = (int)qkvN; p.K = c.dim; p.pro = PRO_RMSNORM; p.epi = EPI_STORE; p.nt = ctx->nt_weights;
@@ -601,6 +644,15 @@ template <typename WT, bool ROUND>
 static void enqueue_head(Launch& L) {
     ft_ctx* ctx = L.ctx;
     const ft_ar_config& c = ctx->c;
+    if (wide_batch(L)) {
+        if constexpr (ROUND) {
+            bf16_t* xn = ctx->mb_xn + (size_t)L.m0 * c.dim;
+            rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(ctx->x + (size_t)L.m0 * c.dim, ctx->norm, c.norm_eps, c.dim, xn);
+            pf_gemm(L, xn, c.dim, L.M, ctx->head, nullptr, c.vocab_size, c.dim, ACT_NONE, nullptr,
+                    ctx->logits + (size_t)L.m0 * c.vocab_size, nullptr, c.vocab_size, 0);
+        }
+        return;
+    }
     GemvP h{};
     h.W = ctx->head; h.x = ctx->x + (size_t)L.m0 * c.dim; h.ldx = c.dim; h.gain = ctx->norm; h.eps = c.norm_eps;
     h.out = ctx->logits + (size_t)L.m0 * c.vocab_size; h.ldo = c.vocab_size; h.N = c.vocab_size; h.K = c.dim;
@@ -667,9 +719,36 @@ static void enqueue_fast_step(Launch& L, const int cb) {
     float* gf = ctx->gf + (size_t)m0 * c.fast_intermediate_size;
     {
         const float* xin = cb == 0 ? ctx->hid + (size_t)m0 * Df : ctx->femb + (size_t)m0 * Df;
+        const bool wide = wide_batch(L);
         for (int li = 0; li < c.n_fast_layer; ++li) {
             const FtLayer& l = ctx->flayers[li];
             const float* xl = li == 0 ? xin : xf;
+            if (wide) {
+                if constexpr (ROUND) {
+                    const int HDf = Hf * hdf, Ff = c.fast_intermediate_size, M = L.M;
+                    bf16_t* xn = ctx->mb_xn + (size_t)m0 * Df;
+                    bf16_t* ybf = ctx->mb_ybf + (size_t)m0 * HDf;
+                    bf16_t* gbf = ctx->mb_g + (size_t)m0 * Ff;
+                    rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xl, l.attn_norm, c.norm_eps, Df, xn);
+                    pf_gemm(L, xn, Df, M, l.wqkv, nullptr, (int)qkvN, Df, ACT_NONE, nullptr, qkvf, nullptr, (long)qkvN, 0);
+                    FastAttnP a{};
+                    a.qkv = qkvf; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->frope;
+                    a.kc = (char*)l.kc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
+                    a.vc = (char*)l.vc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
+                    a.cache_m_stride = ctx->fcache_m_stride; a.c = cb; a.H = Hf; a.Hkv = Hkvf; a.hd = hdf;
+                    a.ncb = c.num_codebooks; a.eps = c.norm_eps; a.scale = (float)(1.0 / sqrt((double)hdf));
+                    a.y_bf = ybf;
+                    float* yf = ctx->y + (size_t)m0 * ctx->y_ld;
+                    // y (f32) and its bf16 copy share the row stride HDf here
+                    fast_attn_kernel<WT, ROUND><<<dim3(Hf, M), 64, 0, L.s>>>(a, yf, HDf);
+                    L.chk();
+                    pf_gemm(L, ybf, HDf, M, l.wo, nullptr, Df, HDf, ACT_NONE, xl, xf, nullptr, Df, 1);
+                    rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xf, l.ffn_norm, c.norm_eps, Df, xn);
+                    pf_gemm(L, xn, Df, M, l.w13, nullptr, 2 * Ff, Df, ACT_SWIGLU, nullptr, nullptr, gbf, Ff, 0);
+                    pf_gemm(L, gbf, Ff, M, l.w2, nullptr, Df, Ff, ACT_NONE, xf, xf, nullptr, Df, 1);
+                }
+                continue;
+            }
             GemvP p{};
             p.W = l.wqkv; p.bias = l.bqkv; p.x = xl; p.ldx = Df; p.gain = l.attn_norm; p.eps = c.norm_eps;
             p.out = qkvf; p.ldo = (int)qkvN; p.N = (int)qkvN; p.K = Df; p.pro = PRO_RMSNORM; p.epi = EPI_STORE;
@@ -701,6 +780,16 @@ static void enqueue_fast_step(Launch& L, const int cb) {
             gemv<WT, ROUND>(L, d, rows_per_wave(d.N, L.M));
         }
         if (cb == 0) return;  // logits of position 0 are discarded (inference.py:122)
+        if (wide) {
+            if constexpr (ROUND) {
+                bf16_t* xn = ctx->mb_xn + (size_t)m0 * Df;
+                rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(xf, ctx->fast_norm, c.norm_eps, Df, xn);
+                pf_gemm(L, xn, Df, L.M, ctx->fast_out, nullptr, ctx->fastV, Df, ACT_NONE, nullptr,
+                        ctx->flog + (size_t)m0 * ctx->fastV, nullptr, ctx->fastV, 0);
+            }
+            enqueue_sample<WT, ROUND>(L, cb, cb == c.num_codebooks - 1);
+            return;
+        }
         GemvP h{};
         h.W = ctx->fast_out; h.x = xf; h.ldx = Df; h.gain = ctx->fast_norm; h.eps = c.norm_eps;
         h.out = ctx->flog + (size_t)m0 * ctx->fastV; h.ldo = ctx->fastV; h.N = ctx->fastV; h.K = Df;

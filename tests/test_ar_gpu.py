@@ -295,9 +295,12 @@ def test_prefix_kv_reuse_at_model_widths_vs_oracle():
     eng.close()
 
 
-def test_batch32_mixed_lengths_equals_single():
+def test_batch32_mixed_lengths_equals_single(monkeypatch):
     """BASELINE configs[2]: 32 utterances of mixed prompt lengths and mixed frame budgets in one captured lock-step
-    graph; every utterance reproduces its own single-slot run (EOS allowed, so lengths differ)."""
+    graph; every utterance reproduces its own single-slot run (EOS allowed, so lengths differ).  FT_NO_WIDE keeps the
+    batch on the multi-row FMA GEMV, whose per-row arithmetic is that of the single run (the MFMA batch path sums in
+    another order: test_wide_batch_vs_oracle)."""
+    monkeypatch.setenv("FT_NO_WIDE", "1")
     shape = tiny_shape()
     B = 32
     kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
@@ -310,6 +313,36 @@ def test_batch32_mixed_lengths_equals_single():
     for i, p in enumerate(prompts):
         got = np.concatenate([p, firsts[i][:, None], frames[i, : n[i]].T], axis=1)
         assert np.array_equal(got[:, : singles[i].shape[1]], singles[i]), i
+    eng.close()
+
+
+@pytest.mark.parametrize("B", [8, 19])
+def test_wide_batch_vs_oracle(B):
+    """Lock-step batches of >= 8 utterances run every Linear as an M-row MFMA GEMM (skinny split-K kernel), which sums
+    in a different order than the single-utterance GEMV: each utterance must follow the oracle up to a decision whose
+    top-1/top-2 margin is inside the bf16 evaluation-order tolerance."""
+    shape = medium_shape()
+    eng, orc = make_pair(shape, "bf16", std=0.05, max_batch=B)
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    sp = eng._sampling(0.7, 1e-6, 1.1)
+    prompts = [make_prompt(shape, 9 + (3 * i) % 11, seed=300 + i, n_vq=i % 4) for i in range(B)]
+    firsts = [eng.prefill(p.numpy(), sp, slot=i) for i, p in enumerate(prompts)]
+    frames, n = eng.decode(5, [sp] * B, poll=5)
+    checked = 0
+    for i, p in enumerate(prompts):
+        if i % 3 and B > 8:
+            continue                                   # the oracle is slow: every third utterance of the big batch
+        taps = []
+        orc.reset()
+        want = orc.generate(p.clone(), 6, frame_taps=taps, **kw).numpy()
+        got = np.concatenate([p.numpy(), firsts[i][:, None], frames[i, : n[i]].T], axis=1)
+        scale = max(1.0, float(taps[0][0].float().abs().max()))
+        div = first_divergence(got, want)
+        if div is not None:
+            col, row = div
+            assert _margin_ok(taps, col - p.shape[1], row, 0.03 * scale), f"utterance {i} diverged at {div}\n{got}\n{want}"
+        checked += 1
+    assert checked >= 7
     eng.close()
 
 
