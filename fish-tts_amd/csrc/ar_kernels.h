@@ -577,6 +577,46 @@ __global__ __launch_bounds__(256) void gemv_attn_combine_kernel(GemvP p, AttnP a
     });
 }
 
+// Split-KV merge as its own launch (wide lock-step batches: the Wo product is an MFMA GEMM over all rows, so the merge
+// cannot ride inside it).  Same arithmetic as above; writes the bf16 operand copy.  grid (M), 256 threads.
+template <bool ROUND>
+__global__ __launch_bounds__(256) void attn_combine_rows_kernel(AttnP a) {
+    constexpr int MAXS = 8;
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int K = a.H * a.hd;
+    for (int k = 4 * tid; k < K; k += 1024) {
+        const int head = k / a.hd, e = k % a.hd;
+        const size_t base = ((size_t)m * a.H + head) * a.nsplit;
+        float ms[MAXS], ls[MAXS];
+        float4 O[MAXS];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const bool on = s < a.nsplit;
+            const size_t bi = base + (on ? s : 0);
+            ms[s] = on ? a.part_ml[bi * 2] : -INFINITY;
+            ls[s] = on ? a.part_ml[bi * 2 + 1] : 0.f;
+            O[s] = *reinterpret_cast<const float4*>(a.part_o + bi * a.hd + e);
+        }
+        float M = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) M = fmaxf(M, ms[s]);
+        float L = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const float w = ms[s] > -INFINITY ? expf(ms[s] - M) : 0.f;
+            L += ls[s] * w;
+            a0 += O[s].x * w; a1 += O[s].y * w; a2 += O[s].z * w; a3 += O[s].w * w;
+        }
+        const float y0 = rb<ROUND>(a0 / L), y1 = rb<ROUND>(a1 / L), y2 = rb<ROUND>(a2 / L), y3 = rb<ROUND>(a3 / L);
+        float* y = a.y + (size_t)m * a.ldy + k;
+        y[0] = y0; y[1] = y1; y[2] = y2; y[3] = y3;
+        if (a.y_bf) {
+            bf16_t* yb = a.y_bf + (size_t)m * a.ldy + k;
+            yb[0] = f32_to_bf16_bits(y0); yb[1] = f32_to_bf16_bits(y1); yb[2] = f32_to_bf16_bits(y2); yb[3] = f32_to_bf16_bits(y3);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Fast-layer attention fused into the Wo GEMV (+ residual).  The fast transformer attends
 // over <= num_codebooks positions (llama.py:544-580); its attention is the explicit

@@ -39,6 +39,7 @@ struct TapGemmP {
     long ldo, o_bstride;
     int round_lin;      // round acc+bias to bf16 first (an nn.Linear output of a bf16 model; also the SwiGLU steps)
     int round_f32_out;  // out_f32 receives bf16-rounded values
+    long ldw;           // skinny kernel: row stride of W in elements (0 = K, dense)
 };
 
 // offs[] lives in the kernel arguments: a runtime index would force the whole struct into scratch
@@ -356,18 +357,19 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
 // the four partial tiles meet in LDS and are summed in wave order (deterministic).  Epilogue = the nn.Linear
 // rounding points of the prefill (bias, rounded; residual add, rounded; SwiGLU on interleaved (gate, up) rows).
 // Requires K % 128 == 0; act in {ACT_NONE, ACT_SWIGLU}; ntap == 1.
-template <int TS>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(TapGemmP p) {
+template <int TS, int NW>
+__global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(TapGemmP p) {
     constexpr int CH = 4;                          // k-steps (of 32) per register chunk
-    __shared__ float Cs[4][TS * 16][17];
+    __shared__ float Cs[NW][TS * 16][17];
+    const int kper = p.K / NW;                     // this wave's share of K (a multiple of 32)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * TS);
-    const int kw = wave * (p.K >> 2);              // this wave's K quarter
-    const int nch = (p.K >> 2) / (32 * CH);
-    const int rem = ((p.K >> 2) / 32) % CH;        // k-steps of a last partial chunk
+    const int kw = wave * kper;
+    const int nch = kper / (32 * CH);
+    const int rem = (kper / 32) % CH;              // k-steps of a last partial chunk
     const bool nv = n0 + fr < p.N;
-    const bf16_t* wrow = p.W + (size_t)(nv ? n0 + fr : 0) * p.K + kw + fq * 8;
+    const bf16_t* wrow = p.W + (size_t)(nv ? n0 + fr : 0) * (p.ldw ? p.ldw : p.K) + kw + fq * 8;
     const bf16_t* xrow[TS];
     bool tv[TS];
 #pragma unroll
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(TapGemmP p) {
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
             if (s < steps) {
-                w[s] = nv ? __builtin_nontemporal_load(reinterpret_cast<const U4*>(wrow + k0 + s * 32)) : zero;
+                w[s] = nv ? *reinterpret_cast<const U4*>(wrow + k0 + s * 32) : zero;  // plain loads measured faster than nt here
 #pragma unroll
                 for (int j = 0; j < TS; ++j) x[j][s] = tv[j] ? *reinterpret_cast<const U4*>(xrow[j] + k0 + s * 32) : zero;
             }
@@ -424,12 +426,13 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(TapGemmP p) {
         for (int r = 0; r < 4; ++r) Cs[wave][j * 16 + fq * 4 + r][fr] = acc[j][r];
     __syncthreads();
     if (p.act == ACT_SWIGLU) {
-        for (int e = tid; e < TS * 16 * 8; e += 256) {
+        for (int e = tid; e < TS * 16 * 8; e += NW * 64) {
             const int row = e >> 3, c2 = (e & 7) * 2;
             const int t = m0 + row, n = n0 + c2;
             if (t >= p.M || n + 1 >= p.N) continue;
-            float g = ((Cs[0][row][c2] + Cs[1][row][c2]) + Cs[2][row][c2]) + Cs[3][row][c2];
-            float u = ((Cs[0][row][c2 + 1] + Cs[1][row][c2 + 1]) + Cs[2][row][c2 + 1]) + Cs[3][row][c2 + 1];
+            float g = Cs[0][row][c2], u = Cs[0][row][c2 + 1];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) { g += Cs[w][row][c2]; u += Cs[w][row][c2 + 1]; }
             if (p.bias) { g += p.bias[n % p.n_mod]; u += p.bias[(n + 1) % p.n_mod]; }
             if (p.round_lin) { g = round_bf16(g); u = round_bf16(u); }
             float sg = g / (1.0f + expf(-g));
@@ -440,11 +443,13 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(TapGemmP p) {
             if (p.out_f32) p.out_f32[oi] = p.round_f32_out ? round_bf16(o) : o;
         }
     } else {
-        for (int e = tid; e < TS * 16 * 16; e += 256) {
+        for (int e = tid; e < TS * 16 * 16; e += NW * 64) {
             const int row = e >> 4, c = e & 15;
             const int t = m0 + row, n = n0 + c;
             if (t >= p.M || n >= p.N) continue;
-            float v = ((Cs[0][row][c] + Cs[1][row][c]) + Cs[2][row][c]) + Cs[3][row][c];
+            float v = Cs[0][row][c];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += Cs[w][row][c];
             if (p.bias) v += p.bias[n % p.n_mod];
             if (p.round_lin) v = round_bf16(v);
             if (p.resid_f32) v += p.resid_f32[(size_t)t * p.ldr + n];
@@ -452,6 +457,22 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(TapGemmP p) {
             if (p.out_f32) p.out_f32[oi] = p.round_f32_out ? round_bf16(v) : v;
             if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(v);
         }
+    }
+}
+
+// K split: 128-256 contraction steps per wave (one or two register chunks = a single memory round trip per wave)
+static inline int skinny_waves(int N, int K, int TS) {
+    if (TS < 4 && K % 384 == 0 && K / 12 >= 128) return 12;   // 3072 -> 12 x 256 (TS = 4 would spill registers)
+    if (K % 256 == 0 && (K / 8 >= 256 || (N <= 2048 && K / 8 >= 128))) return 8;
+    return 4;
+}
+template <int TS>
+static inline void skinny_gemm_launch(const TapGemmP& p, int gy, hipStream_t st) {
+    const dim3 grid((p.N + 15) / 16, gy);
+    switch (skinny_waves(p.N, p.K, TS)) {
+        case 12: skinny_gemm_kernel<TS, 12><<<grid, 768, 0, st>>>(p); break;
+        case 8: skinny_gemm_kernel<TS, 8><<<grid, 512, 0, st>>>(p); break;
+        default: skinny_gemm_kernel<TS, 4><<<grid, 256, 0, st>>>(p);
     }
 }
 

@@ -576,10 +576,16 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
                 a.vc = (char*)l.vc + (size_t)m0 * ctx->cache_m_stride * ctx->esz;
                 a.cache_m_stride = ctx->cache_m_stride; a.pos = ctx->d_pos + m0; a.pos_off = L.pos_off;
                 a.H = c.n_head; a.Hkv = c.n_local_heads; a.hd = c.head_dim; a.n_slots = ctx->n_slots;
-                a.nsplit = 1;  // M x Hkv blocks already fill the chip
+                // split the cache walk until M x Hkv x nsplit blocks cover the chip (long contexts: voice prompts)
+                int ns = 1;
+                while (ns < ctx->nsplit && (long)M * c.n_local_heads * ns < 256) ns *= 2;
+                a.nsplit = ns;
                 a.eps = c.norm_eps; a.scale = 1.0f / sqrtf((float)c.head_dim);
                 a.y = y; a.ldy = HD; a.y_bf = ybf;
+                a.part_o = ctx->part_o + (size_t)m0 * c.n_head * ctx->nsplit * c.head_dim;
+                a.part_ml = ctx->part_ml + (size_t)m0 * c.n_head * ctx->nsplit * 2;
                 attn_decode<WT, ROUND>(L, a);
+                if (ns > 1) { attn_combine_rows_kernel<ROUND><<<M, 256, 0, L.s>>>(a); L.chk(); }
                 pf_gemm(L, ybf, HD, M, l.wo, l.bo_f32, D, HD, ACT_NONE, x, x, nullptr, D, 1);
                 rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.ffn_norm, c.norm_eps, D, xn);
                 pf_gemm(L, xn, D, M, l.w13, nullptr, 2 * F, D, ACT_SWIGLU, nullptr, nullptr, gbf, F, 0);
@@ -892,10 +898,9 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
     const int mode = L.ctx->prefill_gemm_mode;  // FT_PREFILL_GEMM: 0 = first tile kernel only, 1 = no skinny kernel
     if (mode >= 2 && S <= 128 && K % 128 == 0 && N % 2 == 0) {
         // short prompts are weight-bandwidth bound: 16 weight rows per block, K split over the waves
-        const int nb = (N + 15) / 16;
-        if (S <= 16) skinny_gemm_kernel<1><<<dim3(nb, 1), 256, 0, L.s>>>(p);
-        else if (S <= 32) skinny_gemm_kernel<2><<<dim3(nb, 1), 256, 0, L.s>>>(p);
-        else skinny_gemm_kernel<4><<<dim3(nb, (S + 63) / 64), 256, 0, L.s>>>(p);
+        if (S <= 16) skinny_gemm_launch<1>(p, 1, L.s);
+        else if (S <= 32) skinny_gemm_launch<2>(p, 1, L.s);
+        else skinny_gemm_launch<4>(p, (S + 63) / 64, L.s);
     } else if (mode >= 1 && K % 64 == 0 && N % 128 == 0) {
         // long prompts (reference audio): the pipelined tile kernel of the codec
         if (S <= 1024) {
