@@ -134,3 +134,56 @@ def test_prompt_prefix_split_is_text_independent():
     assert nc == 0 and c.shape[1] < a.shape[1]
     d, nd = build_prompt_split(tok, "Hello world", None, None, 10)
     assert nd == 0 and np.array_equal(c, d)
+
+
+def _toy_ranks():
+    ranks = {bytes([i]): i for i in range(256)}
+    for i, t in enumerate([b"he", b"ll", b"hell", b"hello", b" w", b"or", b" wor", b"ld", b"ab", b"bc"]):
+        ranks[t] = 256 + i
+    return ranks
+
+
+def test_bpe_tokenizer_algorithm():
+    """the published tiktoken algorithm on a hand-made rank table (tiktoken itself is absent:
+    parity with it is unpinned).  Regex pre-split, lowest-rank pair first (leftmost on ties), whole-piece lookup,
+    special tokens matched before text, disallowed specials encoded as text, decode round trip."""
+    from fish_tts_amd.tokenizer import BPETokenizer
+    tok = BPETokenizer(_toy_ranks(), ["<|a|>", "<|semantic:0|>", "<|semantic:1|>"])
+    assert tok.vocab_size == 266 and tok.num_special_tokens == 3
+    assert tok.get_token_id("<|a|>") == 266 and tok.semantic_begin_id == 267 and tok.semantic_end_id == 268
+    assert tok.encode("hello") == [259]                              # whole piece is a token
+    assert tok.encode("hell") == [258] and tok.encode("hel") == [256, ord("l")]
+    assert tok.encode(" world") == [262, 263]                        # " wor" + "ld": merges by rank, not left to right
+    assert tok.encode("abc") == [264, ord("c")]                      # "ab" (264) outranks "bc" (265)
+    assert tok.encode("don't") == [ord("d"), ord("o"), ord("n"), ord("'"), ord("t")]   # contraction is its own piece
+    ids = tok.encode("hello world<|a|>x<|semantic:1|>")
+    assert ids == [259, 262, 263, 266, ord("x"), 268]
+    assert tok.decode(ids) == "hello world<|a|>x<|semantic:1|>"
+    assert tok.encode("<|a|>x", allowed_special=False) == [ord(c) for c in "<|a|>x"]
+    assert tok.encode("<|a|><|semantic:0|>", allowed_special={"<|semantic:0|>"}) == [ord(c) for c in "<|a|>"] + [267]
+    text = "Grüße, 世界! 123\n\n  tabs\tand  spaces "
+    assert tok.decode(tok.encode(text)) == text                       # byte-level: lossless on any UTF-8
+    assert tok.encode("") == []
+
+
+def test_tiktoken_file_loader_and_from_pretrained(tmp_path):
+    import base64
+    import json
+    from fish_tts_amd.tokenizer import BPETokenizer, load_tiktoken_bpe, load_tokenizer
+    ranks = _toy_ranks()
+    lines = [f"{base64.b64encode(t).decode()} {r}" for t, r in ranks.items()]
+    lines.insert(3, "")            # blank lines and a literal "=" token line are skipped (tokenizer.py:106-111)
+    lines.insert(7, "= 999")
+    (tmp_path / "tokenizer.tiktoken").write_text("\n".join(lines))
+    assert load_tiktoken_bpe(tmp_path / "tokenizer.tiktoken") == ranks
+    (tmp_path / "special_tokens.json").write_text(json.dumps(["<|im_end|>", "<|semantic:0|>", "<|semantic:1|>"]))
+    tok = BPETokenizer.from_pretrained(tmp_path)
+    assert tok.get_token_id("<|im_end|>") == 266 and tok.encode("hello<|im_end|>") == [259, 266]
+    try:
+        import tiktoken  # noqa: F401
+    except ImportError:
+        assert isinstance(load_tokenizer(tmp_path), BPETokenizer)
+    (tmp_path / "special_tokens.json").unlink()
+    full = BPETokenizer.from_pretrained(tmp_path)                      # default = the reference's ALL_SPECIAL_TOKENS
+    assert full.num_special_tokens == 15 + 4096 and full.get_token_id("<|begin_of_text|>") == 266
+    assert full.semantic_end_id - full.semantic_begin_id == 4095
