@@ -276,6 +276,7 @@ class FishTTS:
         worker.start()
         try:
             buffer, is_first_chunk, total_tokens = [], True, 0
+            tail_chunk, leftovers = None, []
             with self._gen_lock:
                 for response in generate_long(engine=self._engine, tokenizer=self._tokenizer, text=text,
                                               max_new_tokens=kwargs.get("max_tokens", 2048),
@@ -288,23 +289,52 @@ class FishTTS:
                         total_tokens += response.codes.shape[1]
                         threshold = min_first_chunk if is_first_chunk else chunk_tokens
                         if total_tokens >= threshold:
-                            codes_queue.put(np.concatenate(buffer, axis=1))
+                            chunk = np.concatenate(buffer, axis=1)
                             buffer, total_tokens, is_first_chunk = [], 0, False
+                            # Both queues are bounded.  The reference blocks in put() here and joins the worker before
+                            # draining (synthesizer.py:556-578): harmless when the AR loop is the slow side, a deadlock
+                            # once it is faster than the codec (worker stuck on a full audio queue).  Keep draining.
+                            while True:
+                                try:
+                                    codes_queue.put(chunk, timeout=0.005)
+                                    break
+                                except queue.Full:
+                                    pass
+                                while not audio_queue.empty():
+                                    audio = audio_queue.get_nowait()
+                                    if audio is not None:
+                                        yield audio
                             while not audio_queue.empty():
                                 audio = audio_queue.get_nowait()
                                 if audio is not None:
                                     yield audio
                     elif response.action == "next":
                         if buffer:
-                            codes_queue.put(np.concatenate(buffer, axis=1))
+                            tail_chunk = np.concatenate(buffer, axis=1)
                         break
         finally:
-            codes_queue.put(None)
-        worker.join()
-        while not audio_queue.empty():
-            audio = audio_queue.get_nowait()
+            # hand over the tail and the stop mark without ever blocking on a stuck worker (the consumer may have
+            # abandoned the generator: then pending audio is dropped)
+            for item in ([tail_chunk] if tail_chunk is not None else []) + [None]:
+                while True:
+                    try:
+                        codes_queue.put(item, timeout=0.005)
+                        break
+                    except queue.Full:
+                        pass
+                    try:
+                        leftovers.append(audio_queue.get_nowait())
+                    except queue.Empty:
+                        pass
+        for audio in leftovers:               # drained while handing over, in order
             if audio is not None:
                 yield audio
+        while None not in leftovers:          # the worker always ends with a None
+            audio = audio_queue.get()
+            if audio is None:
+                break
+            yield audio
+        worker.join()
         if error_holder:
             raise error_holder[0]
 

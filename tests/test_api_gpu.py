@@ -167,3 +167,51 @@ def test_synthesize_batch_equals_synthesize(tts):
     singles = [synth.synthesize(t, max_tokens=10, **kw) for t in texts]
     assert synth.synthesize_batch(texts, max_tokens=10, **kw) == singles
     assert synth.synthesize_batch([], max_tokens=10, **kw) == []
+
+
+def test_model_directory_in_reference_layout(tmp_path):
+    """SURVEY §8-f F2 end to end: FishTTS(model_dir) on a directory laid out like the reference's checkpoint
+    (config.json, model.pth with a "state_dict" wrapper, "model." prefixes, separate wq/wk/wv, an audio_* tensor;
+    tokenizer.tiktoken + special_tokens.json; no codec.pth -> vocoder not loaded, as the reference warns)."""
+    import base64
+    import json
+    import fish_tts_amd as ft
+    from fish_tts_amd.generation import generate_long
+    from fish_tts_amd.prompt import build_prompt
+    from fish_tts_amd.tokenizer import NAMED_SPECIAL_TOKENS
+    shape = dataclasses.replace(tiny_shape(), max_seq_len=2304)
+    w = OA.random_weights(shape, seed=3)
+    sd = {}
+    for k, v in w.items():
+        if k.endswith("attention.wqkv.weight"):
+            nh, nkv, hd = (shape.fast_n_head, shape.fast_n_local_heads, shape.fast_head_dim) if k.startswith("fast_") \
+                else (shape.n_head, shape.n_local_heads, shape.head_dim)
+            q, kk, vv = torch.split(v, [nh * hd, nkv * hd, nkv * hd])
+            pre = "model." + k[: -len("wqkv.weight")]
+            sd[pre + "wq.weight"], sd[pre + "wk.weight"], sd[pre + "wv.weight"] = q.clone(), kk.clone(), vv.clone()
+        else:
+            sd["model." + k] = v
+    sd["model.audio_projector.weight"] = torch.zeros(4, 4)
+    torch.save({"state_dict": sd}, tmp_path / "model.pth")
+    cfg = {k: v for k, v in args_from_shape(shape).__dict__.items()}
+    cfg["model_type"] = "dual_ar"
+    (tmp_path / "config.json").write_text(json.dumps(cfg))
+    ranks = {bytes([i]): i for i in range(256)}
+    (tmp_path / "tokenizer.tiktoken").write_text("\n".join(f"{base64.b64encode(t).decode()} {r}" for t, r in ranks.items()))
+    (tmp_path / "special_tokens.json").write_text(json.dumps(NAMED_SPECIAL_TOKENS + [f"<|semantic:{i}|>" for i in range(2048)]))
+    synth = ft.FishTTS(model_dir=tmp_path, precision="fp32", warmup=True)
+    try:
+        assert synth._vocoder is None and synth._is_warmed_up
+        tok = synth._tokenizer
+        assert tok.semantic_begin_id == shape.semantic_begin_id and tok.get_token_id("<|im_end|>") == shape.im_end_id
+        kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+        res = [r for r in generate_long(engine=synth._engine, tokenizer=tok, text="Hi there", max_new_tokens=8, **kw)
+               if r.action == "sample"]
+        prompt = build_prompt(tok, "Hi there", None, None, 10)
+        orc = OA.AROracle(shape, w, torch.float32)
+        seq = orc.generate(torch.from_numpy(prompt), 8, **kw).numpy()
+        assert np.array_equal(res[0].codes, seq[1:, prompt.shape[1]:-1])
+        with pytest.raises(RuntimeError, match="[Vv]ocoder"):
+            synth.synthesize("Hi there", max_tokens=4)
+    finally:
+        synth._engine.close()

@@ -187,3 +187,78 @@ def test_tiktoken_file_loader_and_from_pretrained(tmp_path):
     full = BPETokenizer.from_pretrained(tmp_path)                      # default = the reference's ALL_SPECIAL_TOKENS
     assert full.num_special_tokens == 15 + 4096 and full.get_token_id("<|begin_of_text|>") == 266
     assert full.semantic_end_id - full.semantic_begin_id == 4095
+
+
+def test_checkpoint_key_layout_normalisation():
+    """model.pth variants the reference accepts (llama.py:476-498, 222-227): a "state_dict" wrapper,
+    the "model." prefix, audio_* tensors to drop, separate wq/wk/wv to fuse."""
+    import torch
+    from fish_tts_amd.ar_engine import normalise_state_dict
+    g = torch.Generator().manual_seed(0)
+    wq, wk, wv = (torch.randn(8, 4, generator=g), torch.randn(4, 4, generator=g), torch.randn(4, 4, generator=g))
+    raw = {"state_dict": {"model.layers.0.attention.wq.weight": wq, "model.layers.0.attention.wk.weight": wk,
+                          "model.layers.0.attention.wv.weight": wv, "model.layers.0.attention.wo.weight": torch.ones(4, 8),
+                          "model.audio_projector.weight": torch.zeros(2, 2), "model.embeddings.weight": torch.zeros(3, 4)}}
+    sd = normalise_state_dict(raw)
+    assert set(sd) == {"layers.0.attention.wqkv.weight", "layers.0.attention.wo.weight", "embeddings.weight"}
+    assert torch.equal(sd["layers.0.attention.wqkv.weight"], torch.cat([wq, wk, wv]))
+    plain = {"layers.0.attention.wqkv.weight": torch.cat([wq, wk, wv]), "embeddings.weight": torch.zeros(3, 4)}
+    assert set(normalise_state_dict(plain)) == set(plain)
+
+
+def test_codec_weight_norm_folding_matches_torch():
+    """codec.pth keeps weight-normed convs as parametrizations.weight.original0/1 under a "generator." prefix
+    (vocoder.py:423-429, synthesizer.py:276-282); folded weights must equal what torch materialises."""
+    import torch
+    import torch.nn as nn
+    from torch.nn.utils.parametrizations import weight_norm
+    from fish_tts_amd.codec_engine import fold_weight_norm
+    torch.manual_seed(0)
+    conv = weight_norm(nn.Conv1d(6, 10, 3))
+    convt = weight_norm(nn.ConvTranspose1d(6, 4, 4, stride=2))
+    with torch.no_grad():
+        conv.parametrizations.weight.original0.mul_(1.7)
+        convt.parametrizations.weight.original0.add_(0.3)
+    sd = {"generator.a." + k: v for k, v in conv.state_dict().items()}
+    sd.update({"generator.b." + k: v for k, v in convt.state_dict().items()})
+    sd["discriminator.junk"] = torch.zeros(1)
+    sd["generator.c.alpha"] = torch.ones(1, 6, 1)
+    out = fold_weight_norm({"state_dict": sd})
+    assert set(out) == {"a.weight", "a.bias", "b.weight", "b.bias", "c.alpha"}
+    assert torch.allclose(out["a.weight"], conv.weight.detach(), atol=1e-6)
+    assert torch.allclose(out["b.weight"], convt.weight.detach(), atol=1e-6)
+
+
+def test_stream_does_not_deadlock_when_ar_outruns_codec(monkeypatch):
+    """synthesize_stream's two bounded queues (synthesizer.py:483-584): with an AR loop faster than the codec the
+    reference's put()/join() order can deadlock (worker blocked on a full audio queue while the producer waits);
+    here the producer keeps draining.  Simulated on the CPU: instant frames, a slow decoder, 14 chunks."""
+    import threading
+    import time
+    import fish_tts_amd as ft
+    import fish_tts_amd.generation as gen
+    from fish_tts_amd.synthesizer import _PrefillCache
+
+    def fake_generate_long(**kw):
+        for i in range(131):
+            yield gen.GenerateResponse(action="sample", codes=np.full((10, 1), i, dtype=np.int32), text=kw["text"])
+        yield gen.GenerateResponse(action="next")
+
+    synth = ft.FishTTS.__new__(ft.FishTTS)
+    synth._engine = synth._tokenizer = object()
+    synth._prefix_cache = None
+    synth._prefill_cache, synth._prefill_lock, synth._gen_lock = _PrefillCache(), threading.Lock(), threading.Lock()
+
+    def slow_decode(codes):
+        time.sleep(0.02)
+        return np.asarray(codes)[0].astype(np.int16).tobytes()   # 2 bytes per frame: the frame indices of the chunk
+    synth._decode_to_pcm = slow_decode
+    monkeypatch.setattr(gen, "generate_long", fake_generate_long)
+    out = []
+    t = threading.Thread(target=lambda: out.extend(synth.synthesize_stream("x", chunk_tokens=10, min_first_chunk=4)), daemon=True)
+    t.start()
+    t.join(20)
+    assert not t.is_alive(), "synthesize_stream deadlocked"
+    frames = np.frombuffer(b"".join(out), dtype=np.int16)
+    assert np.array_equal(frames, np.arange(131))                 # every frame, in order
+    assert [len(c) // 2 for c in out] == [4] + [10] * 12 + [7]
