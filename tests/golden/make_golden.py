@@ -57,7 +57,26 @@ class _VQ(nn.Module):
 
 
 class _RVQ(nn.Module):
-    """dac.nn.quantize.ResidualVectorQuantize, decode side only (from_codes)."""
+    """dac.nn.quantize.ResidualVectorQuantize restated from its published definition: from_codes (decode) and the
+    inference forward (encode: residual loop over VectorQuantize.forward = in_proj, L2-normalised nearest neighbour
+    on the factorised codes, out_proj)."""
+
+    def forward(self, z, n_quantizers=None):
+        z_q, residual, codes, latents = 0.0, z, [], []
+        for q in self.quantizers:
+            z_e = q.in_proj(residual)
+            B, D, T = z_e.shape
+            enc = torch.nn.functional.normalize(z_e.permute(0, 2, 1).reshape(B * T, D))
+            cb = torch.nn.functional.normalize(q.codebook.weight)
+            dist = enc.pow(2).sum(1, keepdim=True) - 2 * enc @ cb.t() + cb.pow(2).sum(1, keepdim=True).t()
+            idx = (-dist).max(1)[1].reshape(B, T)
+            z_q_i = q.out_proj(q.codebook(idx).transpose(1, 2))
+            z_q = z_q + z_q_i
+            residual = residual - z_q_i
+            codes.append(idx)
+            latents.append(z_e)
+        zero = torch.zeros(())
+        return z_q, torch.stack(codes, dim=1), torch.cat(latents, dim=1), zero, zero
 
     def __init__(self, input_dim=512, n_codebooks=9, codebook_size=1024, codebook_dim=8,
                  quantizer_dropout=0.0):
@@ -235,6 +254,10 @@ def gen_prompt(inference):
 def main():
     llama, inference, vocoder = import_reference()
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "codec_encode":   # only the encode-side fixture
+        from tests.golden import make_golden_codec
+        make_golden_codec.gen_encode(vocoder)
+        return
     gen_ar(llama, inference, "ar_tiny_f32", tiny_shape(), torch.float32, T=9, n_new=16)
     gen_ar(llama, inference, "ar_tiny_bf16", tiny_shape(), torch.bfloat16, T=9, n_new=16)
     gen_ar(llama, inference, "ar_tinyb_f32", tiny_shape_b(), torch.float32, T=12, n_new=12)
@@ -244,6 +267,7 @@ def main():
     if os.path.exists(os.path.join(ROOT, "oracle", "codec.py")):
         from tests.golden import make_golden_codec
         make_golden_codec.main(vocoder)
+        make_golden_codec.gen_encode(vocoder)
 
 
 if __name__ == "__main__":

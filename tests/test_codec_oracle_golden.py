@@ -41,3 +41,22 @@ def test_codec_is_causal_and_batch_independent():
     assert torch.allclose(one, full[1:2], atol=1e-5)
     tail, _ = orc.decode(codes[:, :, 12:], torch.tensor([T - 12, T - 12]))
     assert not torch.allclose(full[..., 12 * fl:], tail, atol=1e-3)
+
+
+def test_codec_oracle_encode_matches_reference():
+    """DAC.encode of the reference (vocoder.py:885-904; the dac RVQ forward restated in the generator) on seeded audio:
+    the oracle's indices must be equal, batch and ragged lengths included, and so must the decode of those indices."""
+    from tests.golden.make_golden_codec import tiny_encode_shape
+    torch.set_num_threads(4)
+    gold = np.load(os.path.join(G, "codec_encode_tiny.npz"))
+    shape = tiny_encode_shape()
+    w = C.random_weights(shape, seed=0)
+    w.update(C.random_encoder_weights(shape, seed=1))
+    orc = C.CodecOracle(shape, w)
+    for name in ("e1", "e2"):
+        audio = torch.from_numpy(gold[f"{name}.audio"])
+        idx, lens = orc.encode(audio[:, None], torch.from_numpy(gold[f"{name}.lens"]))
+        assert np.array_equal(idx.numpy(), gold[f"{name}.indices"]), name
+        assert np.array_equal(lens.numpy(), gold[f"{name}.indices_lens"]), name
+        back, _ = orc.decode(idx, lens)
+        assert np.allclose(back.numpy(), gold[f"{name}.roundtrip"], atol=1e-5), name
