@@ -35,7 +35,9 @@ class ft_codec_config(C.Structure):
                                          "tf_ffn", "tf_window")] + \
                [("tf_rope_base", C.c_float), ("tf_norm_eps", C.c_float)] + \
                [("n_upsample", C.c_int32), ("decoder_dim", C.c_int32), ("n_rates", C.c_int32),
-                ("rates", C.c_int32 * 8), ("max_frames", C.c_int32), ("max_batch", C.c_int32)]
+                ("rates", C.c_int32 * 8), ("max_frames", C.c_int32), ("max_batch", C.c_int32),
+                ("encoder_dim", C.c_int32), ("n_enc_rates", C.c_int32), ("enc_rates", C.c_int32 * 8),
+                ("enc_tf_layers", C.c_int32 * 8), ("enc_tf_window", C.c_int32), ("max_enc_frames", C.c_int32)]
 
 
 class ft_sampling(C.Structure):
@@ -64,6 +66,9 @@ SYMBOLS = {
     "ft_ar_get_debug": (C.c_int32, [_P, C.c_int32, _P, _P]),
     "ft_codec_decode": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     "ft_codec_frame_len": (C.c_int32, [_P]),
+    "ft_codec_encode": (C.c_int32, [_P, _P, C.c_int64, _P, _P]),
+    "ft_codec_enc_frame_len": (C.c_int32, [_P]),
+    "ft_codec_rvq_encode": (C.c_int32, [_P, _P, C.c_int32, _P]),
     "ft_ar_profile_gemv": (C.c_int32, [_P, C.c_int32, C.POINTER(ft_sampling), C.POINTER(C.c_double),
                                        C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "ft_sync": (C.c_int32, [_P]),

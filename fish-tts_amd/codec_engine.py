@@ -36,9 +36,12 @@ def fold_weight_norm(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
 
 
 class CodecHipEngine:
-    def __init__(self, args: Optional[CodecArgs] = None, device: int = 0, max_frames: int = 2048, max_batch: int = 1):
+    def __init__(self, args: Optional[CodecArgs] = None, device: int = 0, max_frames: int = 2048, max_batch: int = 1,
+                 with_encoder: bool = False):
+        """`with_encoder`: also build the encode side (encode_reference); its tensors are then required at load."""
         self.args = args or CodecArgs()
         a = self.args
+        self.with_encoder = bool(with_encoder and a.encoder_dim > 0)
         self.lib = L.load()
         c = L.ft_codec_config()
         c.dtype = L.FT_BF16
@@ -53,6 +56,13 @@ class CodecHipEngine:
         for i, r in enumerate(a.decoder_rates):
             c.rates[i] = r
         c.max_frames, c.max_batch = int(max_frames), int(max_batch)
+        self.max_enc_frames = 0
+        if self.with_encoder:
+            c.encoder_dim, c.n_enc_rates, c.enc_tf_window = a.encoder_dim, len(a.encoder_rates), a.encoder_tf_window
+            for i, (r, nt) in enumerate(zip(a.encoder_rates, a.encoder_transformer_layers)):
+                c.enc_rates[i], c.enc_tf_layers[i] = r, nt
+            want = int(a.max_reference_seconds * a.sample_rate) // a.encode_frame_length + 1
+            self.max_enc_frames = c.max_enc_frames = max(1, min(int(max_frames), want))
         self.cfg = c
         self.max_frames = max_frames
         self.R = a.n_codebooks + 1
@@ -61,6 +71,7 @@ class CodecHipEngine:
         if st != L.FT_OK:
             raise HipError(f"ft_create(codec) failed ({st}): {self.lib.ft_last_error(None).decode()}")
         self.frame_len = self.lib.ft_codec_frame_len(self._h)
+        self.enc_frame_len = self.lib.ft_codec_enc_frame_len(self._h)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -94,14 +105,47 @@ class CodecHipEngine:
         tab = _rope_table(self.max_frames, a.tf_head_dim, a.tf_rope_base)
         shape = (C.c_int64 * 3)(*tab.shape)
         self._check(self.lib.ft_load_weight(self._h, b"rope.codec", C.c_void_p(tab.data_ptr()), L.FT_F32, shape, 3), "rope.codec")
+        if self.with_encoder:
+            rate, npos = 1, 1
+            for r, nt in zip(a.encoder_rates, a.encoder_transformer_layers):
+                rate *= r
+                if nt > 0:
+                    npos = max(npos, self.max_enc_frames * a.encode_frame_length // rate)
+            tab2 = _rope_table(npos, 64, a.tf_rope_base)   # encoder transformers: head_dim 64 (synthesizer.py:249)
+            shape2 = (C.c_int64 * 3)(*tab2.shape)
+            self._check(self.lib.ft_load_weight(self._h, b"rope.codec_enc", C.c_void_p(tab2.data_ptr()), L.FT_F32, shape2, 3),
+                        "rope.codec_enc")
         self._check(self.lib.ft_finalize_weights(self._h), "ft_finalize_weights")
 
     @classmethod
-    def synthetic(cls, device: int = 0, max_frames: int = 2048, seed: int = 0, args: Optional[CodecArgs] = None):
+    def synthetic(cls, device: int = 0, max_frames: int = 2048, seed: int = 0, args: Optional[CodecArgs] = None,
+                  with_encoder: bool = False):
         from .weights import random_codec_state_dict
-        eng = cls(args, device=device, max_frames=max_frames)
-        eng.load_state_dict(random_codec_state_dict(eng.args, seed))
+        eng = cls(args, device=device, max_frames=max_frames, with_encoder=with_encoder)
+        eng.load_state_dict(random_codec_state_dict(eng.args, seed, with_encoder=eng.with_encoder))
         return eng
+
+    def encode(self, audio: np.ndarray) -> np.ndarray:
+        """vocoder.encode of encode_reference (synthesizer.py:345-352, vocoder.py:885-904): mono float audio at the
+        codec sample rate -> (n_codebooks + 1, T') int64 codes, T' = ceil(len / encode_frame_length)."""
+        if not self.with_encoder:
+            raise RuntimeError("codec encoder not built (CodecHipEngine(..., with_encoder=True))")
+        audio = np.ascontiguousarray(np.asarray(audio, dtype=np.float32).reshape(-1))
+        T = (audio.shape[0] + self.enc_frame_len - 1) // self.enc_frame_len
+        codes = np.zeros((self.R, max(T, 1)), dtype=np.int32)
+        n = C.c_int32(0)
+        self._check(self.lib.ft_codec_encode(self._h, audio.ctypes.data_as(C.c_void_p), audio.shape[0],
+                                             codes.ctypes.data_as(C.c_void_p), C.byref(n)), "ft_codec_encode")
+        assert n.value == T, (n.value, T)
+        return codes.astype(np.int64)
+
+    def rvq_encode(self, z: np.ndarray) -> np.ndarray:
+        """Test hook: the quantiser search alone on pre-quantiser latents z (T, latent_dim) f32."""
+        z = np.ascontiguousarray(z, dtype=np.float32)
+        codes = np.zeros((self.R, z.shape[0]), dtype=np.int32)
+        self._check(self.lib.ft_codec_rvq_encode(self._h, z.ctypes.data_as(C.c_void_p), z.shape[0],
+                                                 codes.ctypes.data_as(C.c_void_p)), "ft_codec_rvq_encode")
+        return codes
 
     def decode(self, codes: np.ndarray, lens: Optional[np.ndarray] = None) -> np.ndarray:
         """codes (B, n_codebooks+1, T) or (n_codebooks+1, T) integer -> float32 (B, T*frame_len)."""

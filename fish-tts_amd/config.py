@@ -108,6 +108,24 @@ class CodecArgs:
     downsample_factor: List[int] = field(default_factory=lambda: [2, 2])
     decoder_dim: int = 1536
     decoder_rates: List[int] = field(default_factory=lambda: [8, 8, 4, 2])
+    # encode side (encode_reference; synthesizer.py:255-268).  encoder_dim = 0 builds a decode-only codec.
+    encoder_dim: int = 64
+    encoder_rates: List[int] = field(default_factory=lambda: [2, 4, 8, 8])
+    encoder_transformer_layers: List[int] = field(default_factory=lambda: [0, 0, 0, 4])
+    encoder_tf_window: int = 512
+    max_reference_seconds: float = 60.0
+
+    @property
+    def hop_length(self) -> int:
+        n = 1
+        for r in self.encoder_rates:
+            n *= r
+        return n
+
+    @property
+    def encode_frame_length(self) -> int:
+        """DAC.frame_length = hop_length * 4 (vocoder.py:872)."""
+        return self.hop_length * 4
 
     @property
     def frame_length(self) -> int:

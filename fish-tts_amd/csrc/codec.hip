@@ -46,12 +46,44 @@ struct CodecState {
     bf16_t* big[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t big_elems = 0;
     int frame_len = 0, up_total = 1;
+    // ---- encode side
+    struct EncUnit { float *a0, *a2; ConvW c7, c1; };
+    struct EncBlock { EncUnit u[3]; float* a3; ConvW sc; int s, cin, cout; std::vector<TfLayer> tf; float* tf_norm = nullptr; };
+    bool has_enc = false;
+    float *enc_w0 = nullptr, *enc_b0 = nullptr;   // first conv [C][7], [C]
+    std::vector<EncBlock> enc;
+    float* enc_a_last = nullptr;
+    ConvW enc_out;                                 // k = 3 conv to the latent
+    std::vector<UpStage> down;                     // quantizer.downsample (ct = strided conv here)
+    std::vector<TfLayer> pre;
+    float* pre_norm = nullptr;
+    float *rope_enc = nullptr, *inw = nullptr, *inb = nullptr, *cbn = nullptr, *cn2 = nullptr;
+    float *enc_audio = nullptr, *enc_x = nullptr, *enc_zq = nullptr;
+    bf16_t *ebuf[4] = {nullptr, nullptr, nullptr, nullptr}, *e_xn = nullptr, *e_qkv = nullptr, *e_y = nullptr, *e_g = nullptr;
+    int* enc_codes = nullptr;
+    int hop = 1, enc_frame_len = 0;
+    long max_samples = 0;
 };
 
 static std::string cname(const char* fmt, int a = 0, int b = 0) {
     char buf[160];
     snprintf(buf, sizeof buf, fmt, a, b);
     return buf;
+}
+
+// samples one encode call may hold, and the most positions an encoder transformer sees (head_dim 64: 32 rope pairs)
+static long enc_max_samples(const ft_codec_config& c) {
+    long hop = 1;
+    for (int i = 0; i < c.n_enc_rates; ++i) hop *= c.enc_rates[i];
+    return (long)c.max_enc_frames * hop * 4;
+}
+static int64_t enc_rope_positions(const ft_codec_config& c) {
+    long rate = 1, best = 1;
+    for (int i = 0; i < c.n_enc_rates; ++i) {
+        rate *= c.enc_rates[i];
+        if (c.enc_tf_layers[i] > 0) best = std::max(best, enc_max_samples(c) / rate);
+    }
+    return best;
 }
 
 void codec_expected(ft_ctx* ctx) {
@@ -116,6 +148,77 @@ void codec_expected(ft_ctx* ctx) {
     E(cname("decoder.model.%d.conv.weight", c.n_rates + 2), {1, last, 7});
     E(cname("decoder.model.%d.conv.bias", c.n_rates + 2), {1});
     ft_expect(ctx, "rope.codec", {c.max_frames, c.tf_head_dim / 2, 2}, FT_F32);
+    if (c.encoder_dim <= 0) return;
+    // encode side: Encoder (vocoder.py:539-575), quantizer.downsample / pre_module / in_proj (683-757)
+    int d = c.encoder_dim;
+    E("encoder.block.0.conv.weight", {d, 1, 7});
+    E("encoder.block.0.conv.bias", {d});
+    for (int i = 0; i < c.n_enc_rates; ++i) {
+        d *= 2;
+        const std::string p = cname("encoder.block.%d.block", i + 1);
+        for (int u = 0; u < 3; ++u) {
+            const std::string q = p + cname(".%d.block", u);
+            E(q + ".0.alpha", {1, d / 2, 1});
+            E(q + ".1.conv.weight", {d / 2, d / 2, 7});
+            E(q + ".1.conv.bias", {d / 2});
+            E(q + ".2.alpha", {1, d / 2, 1});
+            E(q + ".3.conv.weight", {d / 2, d / 2, 1});
+            E(q + ".3.conv.bias", {d / 2});
+        }
+        E(p + ".3.alpha", {1, d / 2, 1});
+        E(p + ".4.conv.weight", {d, d / 2, 2 * c.enc_rates[i]});
+        E(p + ".4.conv.bias", {d});
+        for (int l = 0; l < c.enc_tf_layers[i]; ++l) {
+            const std::string t = p + cname(".5.layers.%d", l);
+            E(t + ".attention.wqkv.weight", {3 * d, d});
+            E(t + ".attention.wo.weight", {d, d});
+            E(t + ".feed_forward.w1.weight", {3 * d, d});
+            E(t + ".feed_forward.w3.weight", {3 * d, d});
+            E(t + ".feed_forward.w2.weight", {d, 3 * d});
+            E(t + ".ffn_norm.weight", {d});
+            E(t + ".attention_norm.weight", {d});
+            E(t + ".attention_layer_scale.gamma", {d});
+            E(t + ".ffn_layer_scale.gamma", {d});
+        }
+        if (c.enc_tf_layers[i]) E(p + ".5.norm.weight", {d});
+    }
+    E(cname("encoder.block.%d.alpha", c.n_enc_rates + 1), {1, d, 1});
+    E(cname("encoder.block.%d.conv.weight", c.n_enc_rates + 2), {D, d, 3});
+    E(cname("encoder.block.%d.conv.bias", c.n_enc_rates + 2), {D});
+    for (int j = 0; j < c.n_upsample; ++j) {
+        const std::string p = cname("quantizer.downsample.%d", j);
+        E(p + ".0.conv.weight", {D, D, 2});
+        E(p + ".0.conv.bias", {D});
+        E(p + ".1.dwconv.conv.weight", {D, 1, 7});
+        E(p + ".1.dwconv.conv.bias", {D});
+        E(p + ".1.norm.weight", {D});
+        E(p + ".1.norm.bias", {D});
+        E(p + ".1.pwconv1.weight", {4 * D, D});
+        E(p + ".1.pwconv1.bias", {4 * D});
+        E(p + ".1.pwconv2.weight", {D, 4 * D});
+        E(p + ".1.pwconv2.bias", {D});
+        E(p + ".1.gamma", {D});
+    }
+    for (int l = 0; l < c.n_tf_layer; ++l) {
+        const std::string p = cname("quantizer.pre_module.layers.%d", l);
+        E(p + ".attention.wqkv.weight", {3 * H, D});
+        E(p + ".attention.wo.weight", {D, H});
+        E(p + ".feed_forward.w1.weight", {c.tf_ffn, D});
+        E(p + ".feed_forward.w3.weight", {c.tf_ffn, D});
+        E(p + ".feed_forward.w2.weight", {D, c.tf_ffn});
+        E(p + ".ffn_norm.weight", {D});
+        E(p + ".attention_norm.weight", {D});
+        E(p + ".attention_layer_scale.gamma", {D});
+        E(p + ".ffn_layer_scale.gamma", {D});
+    }
+    E("quantizer.pre_module.norm.weight", {D});
+    E("quantizer.semantic_quantizer.quantizers.0.in_proj.weight", {c.codebook_dim, D, 1});
+    E("quantizer.semantic_quantizer.quantizers.0.in_proj.bias", {c.codebook_dim});
+    for (int i = 0; i < c.n_codebooks; ++i) {
+        E(cname("quantizer.quantizer.quantizers.%d.in_proj.weight", i), {c.codebook_dim, D, 1});
+        E(cname("quantizer.quantizer.quantizers.%d.in_proj.bias", i), {c.codebook_dim});
+    }
+    ft_expect(ctx, "rope.codec_enc", {enc_rope_positions(c), 32, 2}, FT_F32);
 }
 
 ft_status codec_create(ft_ctx* ctx) {
@@ -126,7 +229,16 @@ ft_status codec_create(ft_ctx* ctx) {
     if (c.latent_dim % 32 || (c.tf_n_head * c.tf_head_dim) % 32 || c.tf_ffn % 32 || c.decoder_dim % 32)
         return bad("codec: channel counts must be multiples of 32");
     if ((c.decoder_dim >> c.n_rates) % 32) return bad("codec: decoder_dim / 2^n_rates must be a multiple of 32");
-    if (c.tf_head_dim > 128 || c.tf_head_dim % 8 || c.tf_window > 256) return bad("codec: head_dim <= 128, window <= 256");
+    if (c.tf_head_dim > 128 || c.tf_head_dim % 8 || c.tf_window > 512) return bad("codec: head_dim <= 128, window <= 512");
+    if (c.encoder_dim > 0) {
+        if (c.n_enc_rates < 1 || c.n_enc_rates > 8 || c.encoder_dim % 32 || c.max_enc_frames < 1 || c.enc_tf_window > 512)
+            return bad("codec: encoder_dim must be a multiple of 32, 1..8 encoder rates, enc_tf_window <= 512");
+        if ((c.encoder_dim << c.n_enc_rates) != c.latent_dim) return bad("codec: latent_dim must be encoder_dim * 2^n_enc_rates");
+        for (int i = 0; i < c.n_enc_rates; ++i)
+            if (c.enc_tf_layers[i] > 0 && (c.encoder_dim << (i + 1)) % 64) return bad("codec: encoder transformer width must be a multiple of 64");
+        if (c.codebook_dim > 16) return bad("codec: codebook_dim <= 16");
+        if (c.max_enc_frames > c.max_frames) return bad("codec: max_enc_frames must not exceed max_frames (shared rope table)");
+    }
     if (c.max_frames < 1 || c.max_batch < 1) return bad("codec: max_frames / max_batch");
     CodecState* s = new CodecState();
     ctx->codec = s;
@@ -134,6 +246,13 @@ ft_status codec_create(ft_ctx* ctx) {
     s->up_total = 1 << c.n_upsample;
     s->frame_len = s->up_total;
     for (int i = 0; i < c.n_rates; ++i) s->frame_len *= c.rates[i];
+    s->has_enc = c.encoder_dim > 0;
+    if (s->has_enc) {
+        s->hop = 1;
+        for (int i = 0; i < c.n_enc_rates; ++i) s->hop *= c.enc_rates[i];
+        s->enc_frame_len = s->hop * 4;   // DAC.frame_length (vocoder.py:872)
+        s->max_samples = enc_max_samples(c);
+    }
     return FT_OK;
 }
 
@@ -182,6 +301,113 @@ static ft_status pack_convT(ft_ctx* ctx, ConvW& cw, const std::string& pfx, int 
     cw.bias = W32(ctx, pfx + ".bias");
     cw.ntap = k / stride; cw.N = stride * Cout; cw.K = Cin; cw.n_mod = Cout;
     for (int j = 0; j < cw.ntap; ++j) cw.offs[j] = -j;
+    return FT_OK;
+}
+
+static ft_status pack_strided(ft_ctx* ctx, ConvW& cw, const std::string& pfx, int Cout, int Cin, int k, int stride) {
+    CodecState* s = ctx->codec;
+    FT_TRY(cmalloc(ctx, &cw.w, (size_t)Cout * Cin * k));
+    pack_strided_conv_kernel<<<gridfor((long)Cout * Cin * k), 256, 0, s->stream>>>(W32(ctx, pfx + ".weight"), cw.w, Cout, Cin, k, stride);
+    cw.bias = W32(ctx, pfx + ".bias");
+    cw.ntap = k / stride; cw.N = Cout; cw.K = stride * Cin; cw.n_mod = Cout;
+    for (int a = 0; a < cw.ntap; ++a) cw.offs[a] = a - (cw.ntap - 1);
+    return FT_OK;
+}
+static ft_status pack_tf_layer(ft_ctx* ctx, TfLayer& t, const std::string& p, int D, int H, int ffn) {
+    CodecState* s = ctx->codec;
+    FT_TRY(pack_linear(ctx, t.qkv, p + ".attention.wqkv.weight", "", 3 * H, D));
+    FT_TRY(pack_linear(ctx, t.wo, p + ".attention.wo.weight", "", D, H));
+    FT_TRY(pack_linear(ctx, t.w2, p + ".feed_forward.w2.weight", "", D, ffn));
+    FT_TRY(cmalloc(ctx, &t.w13.w, (size_t)2 * ffn * D));
+    pack_interleave_kernel<<<gridfor((long)ffn * D), 256, 0, s->stream>>>(
+        W32(ctx, p + ".feed_forward.w1.weight"), W32(ctx, p + ".feed_forward.w3.weight"), t.w13.w, ffn, D);
+    t.w13.ntap = 1; t.w13.N = 2 * ffn; t.w13.K = D; t.w13.n_mod = 2 * ffn; t.w13.bias = nullptr;
+    t.n1 = W32(ctx, p + ".attention_norm.weight"); t.n2 = W32(ctx, p + ".ffn_norm.weight");
+    t.g1 = W32(ctx, p + ".attention_layer_scale.gamma"); t.g2 = W32(ctx, p + ".ffn_layer_scale.gamma");
+    return FT_OK;
+}
+
+static ft_status codec_finalize_encoder(ft_ctx* ctx) {
+    const ft_codec_config& c = ctx->cc;
+    CodecState* s = ctx->codec;
+    const int D = c.latent_dim, H = c.tf_n_head * c.tf_head_dim, cd = c.codebook_dim, R = c.n_codebooks + 1;
+    s->enc_w0 = W32(ctx, "encoder.block.0.conv.weight");
+    s->enc_b0 = W32(ctx, "encoder.block.0.conv.bias");
+    s->enc.resize(c.n_enc_rates);
+    int d = c.encoder_dim;
+    long rate = 1, tf_rows = 0;
+    int tf_dim = 0;
+    for (int i = 0; i < c.n_enc_rates; ++i) {
+        CodecState::EncBlock& b = s->enc[i];
+        b.cin = d; b.cout = 2 * d; b.s = c.enc_rates[i];
+        d *= 2;
+        const std::string p = cname("encoder.block.%d.block", i + 1);
+        const int dil[3] = {1, 3, 9};
+        for (int u = 0; u < 3; ++u) {
+            const std::string q = p + cname(".%d.block", u);
+            b.u[u].a0 = W32(ctx, q + ".0.alpha"); b.u[u].a2 = W32(ctx, q + ".2.alpha");
+            FT_TRY(pack_conv(ctx, b.u[u].c7, q + ".1.conv", b.cin, b.cin, 7, dil[u]));
+            FT_TRY(pack_conv(ctx, b.u[u].c1, q + ".3.conv", b.cin, b.cin, 1, 1));
+        }
+        b.a3 = W32(ctx, p + ".3.alpha");
+        FT_TRY(pack_strided(ctx, b.sc, p + ".4.conv", b.cout, b.cin, 2 * b.s, b.s));
+        rate *= b.s;
+        b.tf.resize(c.enc_tf_layers[i]);
+        for (int l = 0; l < c.enc_tf_layers[i]; ++l)
+            FT_TRY(pack_tf_layer(ctx, b.tf[l], p + cname(".5.layers.%d", l), b.cout, b.cout, 3 * b.cout));
+        if (c.enc_tf_layers[i]) {
+            b.tf_norm = W32(ctx, p + ".5.norm.weight");
+            tf_rows = std::max(tf_rows, s->max_samples / rate);
+            tf_dim = std::max(tf_dim, b.cout);
+        }
+    }
+    s->enc_a_last = W32(ctx, cname("encoder.block.%d.alpha", c.n_enc_rates + 1));
+    FT_TRY(pack_conv(ctx, s->enc_out, cname("encoder.block.%d.conv", c.n_enc_rates + 2), D, d, 3, 1));
+    s->down.resize(c.n_upsample);
+    for (int j = 0; j < c.n_upsample; ++j) {
+        const std::string p = cname("quantizer.downsample.%d", j);
+        UpStage& u = s->down[j];
+        u.f = 2;
+        FT_TRY(pack_strided(ctx, u.ct, p + ".0.conv", D, D, 2, 2));
+        u.dw_w = W32(ctx, p + ".1.dwconv.conv.weight"); u.dw_b = W32(ctx, p + ".1.dwconv.conv.bias");
+        u.ln_w = W32(ctx, p + ".1.norm.weight"); u.ln_b = W32(ctx, p + ".1.norm.bias");
+        u.gamma = W32(ctx, p + ".1.gamma");
+        FT_TRY(pack_linear(ctx, u.pw1, p + ".1.pwconv1.weight", p + ".1.pwconv1.bias", 4 * D, D));
+        FT_TRY(pack_linear(ctx, u.pw2, p + ".1.pwconv2.weight", p + ".1.pwconv2.bias", D, 4 * D));
+    }
+    s->pre.resize(c.n_tf_layer);
+    for (int l = 0; l < c.n_tf_layer; ++l)
+        FT_TRY(pack_tf_layer(ctx, s->pre[l], cname("quantizer.pre_module.layers.%d", l), D, H, c.tf_ffn));
+    s->pre_norm = W32(ctx, "quantizer.pre_module.norm.weight");
+    s->rope_enc = W32(ctx, "rope.codec_enc");
+    // quantiser search operands: in_proj (f32), normalised codebooks and their squared norms
+    const size_t ncode = (size_t)c.semantic_codebook_size + (size_t)c.n_codebooks * c.codebook_size;
+    FT_TRY(cmalloc(ctx, &s->inw, (size_t)R * cd * D));
+    FT_TRY(cmalloc(ctx, &s->inb, (size_t)R * cd));
+    FT_TRY(cmalloc(ctx, &s->cbn, ncode * cd));
+    FT_TRY(cmalloc(ctx, &s->cn2, ncode));
+    for (int q = 0; q < R; ++q) {
+        const std::string p = q == 0 ? std::string("quantizer.semantic_quantizer.quantizers.0")
+                                     : cname("quantizer.quantizer.quantizers.%d", q - 1);
+        FT_HIP(ctx, hipMemcpyAsync(s->inw + (size_t)q * cd * D, W32(ctx, p + ".in_proj.weight"), (size_t)cd * D * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+        FT_HIP(ctx, hipMemcpyAsync(s->inb + (size_t)q * cd, W32(ctx, p + ".in_proj.bias"), (size_t)cd * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+        const int N = q == 0 ? c.semantic_codebook_size : c.codebook_size;
+        const size_t off = q == 0 ? 0 : (size_t)c.semantic_codebook_size + (size_t)(q - 1) * c.codebook_size;
+        normalize_codebook_kernel<<<(N + 255) / 256, 256, 0, s->stream>>>(W32(ctx, p + ".codebook.weight"), s->cbn + off * cd, s->cn2 + off, N, cd);
+    }
+    // activations: the widest stage is the first (samples x encoder_dim); transformer scratch for the widest transformer
+    const size_t big = (size_t)s->max_samples * c.encoder_dim;
+    for (int i = 0; i < 4; ++i) FT_TRY(cmalloc(ctx, &s->ebuf[i], std::max(big, (size_t)(s->max_samples / s->hop) * 4 * D)));
+    FT_TRY(cmalloc(ctx, &s->enc_audio, (size_t)s->max_samples));
+    const size_t rows = std::max<size_t>((size_t)tf_rows, (size_t)c.max_enc_frames);
+    const int wd = std::max(tf_dim, D);
+    FT_TRY(cmalloc(ctx, &s->enc_x, rows * wd));
+    FT_TRY(cmalloc(ctx, &s->e_xn, rows * wd));
+    FT_TRY(cmalloc(ctx, &s->e_qkv, rows * 3 * std::max(tf_dim, H)));
+    FT_TRY(cmalloc(ctx, &s->e_y, rows * std::max(tf_dim, H)));
+    FT_TRY(cmalloc(ctx, &s->e_g, rows * std::max(3 * tf_dim, c.tf_ffn)));
+    FT_TRY(cmalloc(ctx, &s->enc_zq, (size_t)c.max_enc_frames * D));
+    FT_TRY(cmalloc(ctx, &s->enc_codes, (size_t)R * c.max_enc_frames));
     return FT_OK;
 }
 
@@ -275,6 +501,7 @@ ft_status codec_finalize(ft_ctx* ctx) {
     FT_TRY(cmalloc(ctx, &s->y, T * H));
     FT_TRY(cmalloc(ctx, &s->g, T * c.tf_ffn));
     FT_TRY(cmalloc(ctx, &s->audio, T * s->frame_len));
+    if (s->has_enc) FT_TRY(codec_finalize_encoder(ctx));
     FT_HIP(ctx, hipStreamSynchronize(s->stream));
     return FT_OK;
 }
@@ -405,5 +632,128 @@ extern "C" ft_status ft_codec_decode(ft_ctx* ctx, const int32_t* codes, int32_t 
     }
     return FT_OK;
 }
+
+// One window-limited transformer (vocoder.py:338-354) over the f32 residual stream x [T][D]; output of the final
+// RMSNorm goes to out_bf and/or out_f32.
+static void run_transformer(ft_ctx* ctx, hipStream_t st, const std::vector<TfLayer>& layers, const float* final_norm,
+                            float* x, int T, int D, int H, int hd, int ffn, int window, const float* rope,
+                            bf16_t* xn, bf16_t* qkv, bf16_t* y, bf16_t* g, bf16_t* out_bf, float* out_f32) {
+    const ft_codec_config& c = ctx->cc;
+    const int HD = H * hd;
+    for (const TfLayer& t : layers) {
+        rmsnorm_rows_kernel<<<T, 256, 0, st>>>(RowNormP{x, t.n1, c.tf_norm_eps, D, xn, nullptr});
+        { GemmIO io{xn, D, T, T}; io.out_bf = qkv; io.ldo = 3 * HD; gemm(st, t.qkv, io); }
+        rope_qk_kernel<<<gridfor((long)T * 2 * H * (hd / 2)), 256, 0, st>>>(qkv, rope, T, H, hd);
+        window_attn_kernel<<<(T * H + 3) / 4, 256, 0, st>>>(WinAttnP{qkv, y, T, H, hd, window, 1.0f / sqrtf((float)hd)});
+        { GemmIO io{y, HD, T, T}; io.gamma = t.g1; io.resid_f32 = x; io.ldr = D; io.out_f32 = x; io.ldo = D; gemm(st, t.wo, io); }
+        rmsnorm_rows_kernel<<<T, 256, 0, st>>>(RowNormP{x, t.n2, c.tf_norm_eps, D, xn, nullptr});
+        { GemmIO io{xn, D, T, T}; io.act = ACT_SWIGLU; io.out_bf = g; io.ldo = ffn; gemm(st, t.w13, io); }
+        { GemmIO io{g, ffn, T, T}; io.gamma = t.g2; io.resid_f32 = x; io.ldr = D; io.out_f32 = x; io.ldo = D; gemm(st, t.w2, io); }
+    }
+    rmsnorm_rows_kernel<<<T, 256, 0, st>>>(RowNormP{x, final_norm, c.tf_norm_eps, D, out_bf, out_f32});
+}
+
+static ft_status rvq_search(ft_ctx* ctx, hipStream_t st, const float* z, int T, int* codes_dev) {
+    const ft_codec_config& c = ctx->cc;
+    CodecState* s = ctx->codec;
+    RvqEncP rp{z, s->inw, s->inb, s->cbn, s->cn2, s->tables, c.n_codebooks + 1, c.semantic_codebook_size, c.codebook_size,
+               c.latent_dim, c.codebook_dim, T, codes_dev};
+    rvq_encode_kernel<<<T, 256, (size_t)c.latent_dim * sizeof(float), st>>>(rp);
+    return FT_OK;
+}
+
+extern "C" ft_status ft_codec_rvq_encode(ft_ctx* ctx, const float* z, int32_t T, int32_t* codes) {
+    if (!ctx) return FT_ERR_ARG;
+    if (!ctx->has_codec || !ctx->codec || !ctx->codec->has_enc) return ft_fail(ctx, FT_ERR_STATE, "codec encoder not configured");
+    if (!ctx->finalized) return ft_fail(ctx, FT_ERR_STATE, "weights not finalized (ft_finalize_weights)");
+    const ft_codec_config& c = ctx->cc;
+    if (!z || !codes || T < 1 || T > c.max_enc_frames) return ft_fail(ctx, FT_ERR_ARG, "ft_codec_rvq_encode: bad argument");
+    CodecState* s = ctx->codec;
+    std::lock_guard<std::mutex> lock(s->mu);
+    FT_HIP(ctx, hipSetDevice(ctx->device));
+    const int R = c.n_codebooks + 1;
+    FT_HIP(ctx, hipMemcpyAsync(s->enc_zq, z, (size_t)T * c.latent_dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    FT_TRY(rvq_search(ctx, s->stream, s->enc_zq, T, s->enc_codes));
+    FT_HIP(ctx, hipMemcpyAsync(codes, s->enc_codes, (size_t)R * T * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    FT_HIP(ctx, hipStreamSynchronize(s->stream));
+    return FT_OK;
+}
+
+extern "C" ft_status ft_codec_encode(ft_ctx* ctx, const float* audio, int64_t n_samples, int32_t* codes, int32_t* out_frames) {
+    if (!ctx) return FT_ERR_ARG;
+    if (!ctx->has_codec || !ctx->codec) return ft_fail(ctx, FT_ERR_STATE, "Vocoder not loaded");
+    CodecState* s = ctx->codec;
+    if (!s->has_enc) return ft_fail(ctx, FT_ERR_STATE, "codec encoder not configured (encoder_dim = 0)");
+    if (!ctx->finalized) return ft_fail(ctx, FT_ERR_STATE, "weights not finalized (ft_finalize_weights)");
+    if (!audio || !codes || !out_frames || n_samples < 1) return ft_fail(ctx, FT_ERR_ARG, "ft_codec_encode: bad argument");
+    const ft_codec_config& c = ctx->cc;
+    const long fl = s->enc_frame_len;
+    const long Tf = (n_samples + fl - 1) / fl;            // code frames (vocoder.py:891-892, 903)
+    if (Tf > c.max_enc_frames) return ft_fail(ctx, FT_ERR_TOO_LONG, "ft_codec_encode: audio longer than max_enc_frames");
+    const long T0 = Tf * fl;                              // padded samples
+    std::lock_guard<std::mutex> lock(s->mu);
+    FT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = s->stream;
+    const int D = c.latent_dim, H = c.tf_n_head, hd = c.tf_head_dim, R = c.n_codebooks + 1;
+    FT_HIP(ctx, hipMemsetAsync(s->enc_audio, 0, (size_t)T0 * sizeof(float), st));
+    FT_HIP(ctx, hipMemcpyAsync(s->enc_audio, audio, (size_t)n_samples * sizeof(float), hipMemcpyHostToDevice, st));
+    // Encoder (vocoder.py:539-575).  r = raw residual stream, a = Snake'd operand of the next conv, hs = inner buffer
+    bf16_t *r = s->ebuf[0], *a = s->ebuf[1], *hs = s->ebuf[2], *o = s->ebuf[3];
+    long T = T0;
+    {
+        EncInP ep{s->enc_audio, s->enc_w0, s->enc_b0, s->enc[0].u[0].a0, T, c.encoder_dim, r, a};
+        enc_conv_in_kernel<<<gridfor(T * c.encoder_dim), 256, 0, st>>>(ep);
+    }
+    for (size_t bi = 0; bi < s->enc.size(); ++bi) {
+        const CodecState::EncBlock& b = s->enc[bi];
+        for (int ui = 0; ui < 3; ++ui) {
+            const CodecState::EncUnit& ru = b.u[ui];
+            { GemmIO io{a, b.cin, (int)T, (int)T}; io.out_act = hs; io.alpha = ru.a2; io.ldo = b.cin; gemm(st, ru.c7, io); }
+            const float* next_alpha = ui < 2 ? b.u[ui + 1].a0 : b.a3;
+            { GemmIO io{hs, b.cin, (int)T, (int)T}; io.resid_bf = r; io.ldr = b.cin; io.out_bf = ui < 2 ? r : nullptr;
+              io.out_act = a; io.alpha = next_alpha; io.ldo = b.cin; gemm(st, ru.c1, io); }
+        }
+        // strided conv on the [T/s][s*cin] view of a; raw output to o (no transformer) or to the f32 stream
+        const long Tn = T / b.s;
+        const bool has_tf = !b.tf.empty();
+        { GemmIO io{a, (long)b.s * b.cin, (int)Tn, (int)Tn}; if (has_tf) io.out_f32 = s->enc_x; else io.out_bf = o; io.ldo = b.cout; gemm(st, b.sc, io); }
+        T = Tn;
+        if (has_tf)
+            run_transformer(ctx, st, b.tf, b.tf_norm, s->enc_x, (int)T, b.cout, b.cout / 64, 64, 3 * b.cout, c.enc_tf_window,
+                            s->rope_enc, s->e_xn, s->e_qkv, s->e_y, s->e_g, o, nullptr);
+        const float* alpha_next = bi + 1 < s->enc.size() ? s->enc[bi + 1].u[0].a0 : s->enc_a_last;
+        snake_bf_rows_kernel<<<gridfor(T * b.cout), 256, 0, st>>>(o, alpha_next, a, T * b.cout, b.cout);
+        std::swap(r, o);  // the raw output is the next block's residual stream
+    }
+    bf16_t* z = hs;   // [T][D]
+    { GemmIO io{a, s->enc[s->enc.size() - 1].cout, (int)T, (int)T}; io.out_bf = z; io.ldo = D; gemm(st, s->enc_out, io); }
+    // quantizer.downsample (vocoder.py:724-735): strided conv k = s = 2, ConvNeXt
+    bf16_t *u = r, *n = a, *h = o;
+    for (size_t j = 0; j < s->down.size(); ++j) {
+        const UpStage& ds = s->down[j];
+        const long Tn = T / ds.f;
+        { GemmIO io{z, (long)ds.f * D, (int)Tn, (int)Tn}; io.out_bf = u; io.ldo = D; gemm(st, ds.ct, io); }
+        T = Tn;
+        dwconv_ln_kernel<<<(int)T, 256, D * sizeof(float), st>>>(DwLnP{u, ds.dw_w, ds.dw_b, ds.ln_w, ds.ln_b, (int)T, D, n});
+        { GemmIO io{n, D, (int)T, (int)T}; io.act = ACT_GELU; io.out_bf = h; io.ldo = 4 * D; gemm(st, ds.pw1, io); }
+        const bool last = j + 1 == s->down.size();
+        { GemmIO io{h, 4 * D, (int)T, (int)T}; io.gamma = ds.gamma; io.resid_bf = u; io.ldr = D; io.out_bf = z; io.ldo = D;
+          if (last) io.out_f32 = s->enc_x; gemm(st, ds.pw2, io); }
+    }
+    if (s->down.empty()) bf16_rows_to_f32_kernel<<<gridfor(T * D), 256, 0, st>>>(z, s->enc_x, T * D);
+    if (T != Tf) return ft_fail(ctx, FT_ERR_STATE, "ft_codec_encode: stage rates do not multiply to the frame length");
+    // pre_module (window-limited transformer), then the residual quantiser search
+    run_transformer(ctx, st, s->pre, s->pre_norm, s->enc_x, (int)T, D, H, hd, c.tf_ffn, c.tf_window, s->rope,
+                    s->e_xn, s->e_qkv, s->e_y, s->e_g, nullptr, s->enc_zq);
+    FT_TRY(rvq_search(ctx, st, s->enc_zq, (int)T, s->enc_codes));
+    FT_HIP(ctx, hipMemcpyAsync(codes, s->enc_codes, (size_t)R * T * sizeof(int), hipMemcpyDeviceToHost, st));
+    FT_HIP(ctx, hipStreamSynchronize(st));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("codec encode launch: ") + hipGetErrorString(e));
+    *out_frames = (int32_t)T;
+    return FT_OK;
+}
+
+extern "C" int32_t ft_codec_enc_frame_len(const ft_ctx* ctx) { return ctx && ctx->codec ? ctx->codec->enc_frame_len : 0; }
 
 extern "C" int32_t ft_codec_frame_len(const ft_ctx* ctx) { return ctx && ctx->codec ? ctx->codec->frame_len : 0; }

@@ -563,7 +563,7 @@ struct WinAttnP {
 };
 static __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnP p) {
     __shared__ float q_s[4][128];
-    __shared__ float p_s[4][256];
+    __shared__ float p_s[4][512];   // window <= 512 (the encoder's transformer, vocoder.py:516)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + wave;
     if (item >= (long)p.T * p.H) return;
@@ -698,6 +698,139 @@ static __global__ void pack_interleave_kernel(const float* a, const float* b, bf
         o[(2 * r + 1) * K + k] = f32_to_bf16_bits(b[i]);
     }
 }
+// ---- encode side (DAC.encode, vocoder.py:885-904) ------------------------------------------------------------------
+// strided causal conv (CausalConvNet with stride s, kernel k = taps*s, left pad k - s; vocoder.py:394-421) as a tap GEMM
+// over the [T/s][s*Cin] view of the time-major input: [Cout][Cin][k] -> [taps][Cout][s*Cin],
+// tap a (row offset a - (taps-1)), column jj*Cin + ci <- w[co][ci][a*s + jj]
+static __global__ void pack_strided_conv_kernel(const float* w, bf16_t* o, int Cout, int Cin, int k, int s) {
+    const long n = (long)Cout * Cin * k;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % k), ci = (int)((i / k) % Cin), co = (int)(i / ((long)k * Cin));
+        const int a = kk / s, jj = kk % s;
+        o[((size_t)a * Cout + co) * ((size_t)s * Cin) + (size_t)jj * Cin + ci] = f32_to_bf16_bits(w[i]);
+    }
+}
+// first encoder conv: 1 input channel, k = 7, causal (vocoder.py:552): raw output and the Snake'd copy the first
+// residual unit reads
+struct EncInP {
+    const float* audio;  // [T]
+    const float* w;      // [C][7]
+    const float* b;      // [C]
+    const float* alpha;  // [C]
+    long T;
+    int C;
+    bf16_t* raw;         // [T][C]
+    bf16_t* act;         // [T][C]
+};
+static __global__ __launch_bounds__(256) void enc_conv_in_kernel(EncInP p) {
+    const long n = p.T * p.C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long t = i / p.C;
+        const int c = (int)(i % p.C);
+        float acc = p.b[c];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const long tt = t - 6 + j;
+            if (tt >= 0) acc = fmaf(p.w[c * 7 + j], p.audio[tt], acc);
+        }
+        p.raw[i] = f32_to_bf16_bits(acc);
+        p.act[i] = f32_to_bf16_bits(snake_f(acc, p.alpha[c]));
+    }
+}
+static __global__ void snake_bf_rows_kernel(const bf16_t* x, const float* alpha, bf16_t* out, long n, int C) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = f32_to_bf16_bits(snake_f(bf16_bits_to_f32(x[i]), alpha[i % C]));
+}
+static __global__ void bf16_rows_to_f32_kernel(const bf16_t* x, float* out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = bf16_bits_to_f32(x[i]);
+}
+// L2-normalised codebook rows and their squared norms (dac VectorQuantize.decode_latents)
+static __global__ void normalize_codebook_kernel(const float* cb, float* cbn, float* cn2, int N, int cd) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        float ss = 0.f;
+        for (int c = 0; c < cd; ++c) ss += cb[(size_t)i * cd + c] * cb[(size_t)i * cd + c];
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize eps
+        float s2 = 0.f;
+        for (int c = 0; c < cd; ++c) {
+            const float v = cb[(size_t)i * cd + c] * inv;
+            cbn[(size_t)i * cd + c] = v;
+            s2 += v * v;
+        }
+        cn2[i] = s2;
+    }
+}
+// Residual vector quantiser search (vocoder.py:765-779 + dac ResidualVectorQuantize.forward): per frame, for every
+// codebook in turn: e = in_proj(residual); nearest codebook row by distance between the L2-normalised vectors
+// (first index on ties, as torch.max); residual -= out_proj(codebook[idx]) (the folded decode table).  One block per frame.
+struct RvqEncP {
+    const float* z;       // [T][D]
+    const float* inw;     // [R][cd][D]
+    const float* inb;     // [R][cd]
+    const float* cbn;     // normalised codebooks: [S0][cd] then (R-1) x [S][cd]
+    const float* cn2;     // their squared norms, same order
+    const float* tables;  // decode tables [S0][D] then (R-1) x [S][D]
+    int R, S0, S, D, cd, T;
+    int* codes;           // [R][T]
+};
+static __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqEncP p) {
+    extern __shared__ float res[];           // [D]
+    __shared__ float part[4][16];
+    __shared__ float e_s[16];
+    __shared__ float bestv[4];
+    __shared__ int besti[4];
+    __shared__ int pick;
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = p.D, cd = p.cd;
+    for (int d = tid; d < D; d += 256) res[d] = p.z[(size_t)t * D + d];
+    __syncthreads();
+    for (int q = 0; q < p.R; ++q) {
+        const float* W = p.inw + (size_t)q * cd * D;
+        for (int c = 0; c < cd; ++c) {
+            float a = 0.f;
+            for (int d = tid; d < D; d += 256) a = fmaf(W[(size_t)c * D + d], res[d], a);
+            a = wave_sum(a);
+            if (lane == 0) part[wave][c] = a;
+        }
+        __syncthreads();
+        if (tid < cd) e_s[tid] = (((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]) + p.inb[q * cd + tid];
+        __syncthreads();
+        float nn = 0.f;
+        for (int c = 0; c < cd; ++c) nn += e_s[c] * e_s[c];
+        const float inv = 1.0f / fmaxf(sqrtf(nn), 1e-12f);
+        float en[16];
+        float l2 = 0.f;
+        for (int c = 0; c < cd; ++c) { en[c] = e_s[c] * inv; l2 += en[c] * en[c]; }
+        const int N = q == 0 ? p.S0 : p.S;
+        const size_t off = q == 0 ? 0 : (size_t)p.S0 + (size_t)(q - 1) * p.S;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < N; i += 256) {
+            float dot = 0.f;
+            for (int c = 0; c < cd; ++c) dot = fmaf(en[c], p.cbn[(off + i) * cd + c], dot);
+            const float score = -((l2 - 2.0f * dot) + p.cn2[off + i]);
+            if (score > bv) { bv = score; bi = i; }          // ascending i per thread: first maximum stays
+        }
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const float ov = __shfl_xor(bv, sft);
+            const int oi = __shfl_xor(bi, sft);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { bestv[wave] = bv; besti[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = bestv[0]; int ix = besti[0];
+            for (int w = 1; w < 4; ++w) if (bestv[w] > v || (bestv[w] == v && besti[w] < ix)) { v = bestv[w]; ix = besti[w]; }
+            pick = ix;
+            p.codes[(size_t)q * p.T + t] = ix;
+        }
+        __syncthreads();
+        const float* row = p.tables + (off + (size_t)pick) * D;
+        for (int d = tid; d < D; d += 256) res[d] -= row[d];
+        __syncthreads();
+    }
+}
+
 static __global__ void snake_rows_kernel(const float* x, const float* alpha, bf16_t* out, long T, int C) {
     const long n = T * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)

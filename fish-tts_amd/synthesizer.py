@@ -112,14 +112,16 @@ class FishTTS:
         codec_path = self._model_dir / "codec.pth"
         if codec_path.exists():
             sd = torch.load(codec_path, map_location="cpu", weights_only=True)
-            self._vocoder = CodecHipEngine(device=self._gpu_index, max_frames=2048 + 8)
+            inner = sd["state_dict"] if "state_dict" in sd else sd
+            has_encoder = any(k.startswith(("encoder.", "generator.encoder.")) for k in inner)
+            self._vocoder = CodecHipEngine(device=self._gpu_index, max_frames=2048 + 8, with_encoder=has_encoder)
             self._vocoder.load_state_dict(sd)
             logger.info("Vocoder loaded (bf16 contractions, f32 accumulate)")
         else:
             logger.warning("codec.pth not found, vocoder not loaded")
 
     def _load_synthetic(self, args, tokenizer, codec_args=None, seed: int = 0, with_codec: bool = True,
-                        max_new_tokens: int = 2048 + 8, std=None):
+                        max_new_tokens: int = 2048 + 8, std=None, with_encoder: bool = False):
         from .ar_engine import ARHipEngine
         from .codec_engine import CodecHipEngine
         from .tokenizer import IM_END_TOKEN
@@ -133,7 +135,7 @@ class FishTTS:
         self._engine.load_state_dict(random_state_dict(args, seed=seed, dtype=dtype, std=std))
         if with_codec:
             self._vocoder = CodecHipEngine.synthetic(device=self._gpu_index, max_frames=max_new_tokens, seed=seed,
-                                                     args=codec_args)
+                                                     args=codec_args, with_encoder=with_encoder)
 
     @classmethod
     def synthetic(cls, args, tokenizer, codec_args=None, precision="bf16", seed: int = 0, warmup: bool = False,
@@ -162,10 +164,24 @@ class FishTTS:
             logger.warning("Warmup failed: %s", e)
 
     def encode_reference(self, audio_bytes: bytes, text: str) -> VoiceProfile:
+        """WAV bytes + transcript -> VoiceProfile (synthesizer.py:325-357): the codec *encoder* on the GPU
+        (SURVEY.md §8-f F4)."""
         if self._vocoder is None:
             raise RuntimeError("Vocoder not loaded")
-        raise NotImplementedError("encode_reference (the codec *encoder*) is outside the MI355X hot path; "
-                                  "create profiles offline and load them with VoiceProfile.load")
+        audio = self._read_wav(audio_bytes)
+        codes = self._vocoder.encode(audio)
+        return VoiceProfile(codes=codes.astype(np.int64), text=text)
+
+    @staticmethod
+    def _read_wav(audio_bytes: bytes) -> np.ndarray:
+        """synthesizer.py:613-631: 16-bit PCM -> float32 / 32768, Fourier resampling to 44.1 kHz if needed."""
+        with wave.open(io.BytesIO(audio_bytes), "rb") as wf:
+            sample_rate = wf.getframerate()
+            audio = np.frombuffer(wf.readframes(wf.getnframes()), dtype=np.int16).astype(np.float32) / 32768.0
+        if sample_rate != 44100:
+            from scipy import signal
+            audio = signal.resample(audio, int(len(audio) * 44100 / sample_rate))
+        return audio
 
     # ------------------------------------------------------------------ references (synthesizer.py:363-429)
     def set_references(self, profiles: List[VoiceProfile]) -> None:

@@ -133,12 +133,84 @@ def codec_state_dict_shapes(a) -> Dict[str, tuple]:
     return s
 
 
-def random_codec_state_dict(a, seed: int = 0) -> Dict[str, torch.Tensor]:
+def codec_encoder_state_dict_shapes(a) -> Dict[str, tuple]:
+    """Folded encode-path tensors: Encoder (vocoder.py:539-575), quantizer.downsample / pre_module (724-735, 752),
+    the quantisers' in_proj (dac VectorQuantize)."""
+    s: Dict[str, tuple] = {}
+    D = a.latent_dim
+    H = a.tf_n_head * a.tf_head_dim
+    d = a.encoder_dim
+    s["encoder.block.0.conv.weight"] = (d, 1, 7)
+    s["encoder.block.0.conv.bias"] = (d,)
+    for i, (r, nt) in enumerate(zip(a.encoder_rates, a.encoder_transformer_layers)):
+        d *= 2
+        p = f"encoder.block.{i + 1}.block"
+        for u in range(3):
+            q = f"{p}.{u}.block"
+            s[f"{q}.0.alpha"] = (1, d // 2, 1)
+            s[f"{q}.1.conv.weight"] = (d // 2, d // 2, 7)
+            s[f"{q}.1.conv.bias"] = (d // 2,)
+            s[f"{q}.2.alpha"] = (1, d // 2, 1)
+            s[f"{q}.3.conv.weight"] = (d // 2, d // 2, 1)
+            s[f"{q}.3.conv.bias"] = (d // 2,)
+        s[f"{p}.3.alpha"] = (1, d // 2, 1)
+        s[f"{p}.4.conv.weight"] = (d, d // 2, 2 * r)
+        s[f"{p}.4.conv.bias"] = (d,)
+        for l in range(nt):
+            t = f"{p}.5.layers.{l}"
+            s[f"{t}.attention.wqkv.weight"] = (3 * d, d)
+            s[f"{t}.attention.wo.weight"] = (d, d)
+            s[f"{t}.feed_forward.w1.weight"] = (3 * d, d)
+            s[f"{t}.feed_forward.w3.weight"] = (3 * d, d)
+            s[f"{t}.feed_forward.w2.weight"] = (d, 3 * d)
+            for n in ("ffn_norm.weight", "attention_norm.weight", "attention_layer_scale.gamma", "ffn_layer_scale.gamma"):
+                s[f"{t}.{n}"] = (d,)
+        if nt:
+            s[f"{p}.5.norm.weight"] = (d,)
+    n = len(a.encoder_rates) + 1
+    s[f"encoder.block.{n}.alpha"] = (1, d, 1)
+    s[f"encoder.block.{n + 1}.conv.weight"] = (D, d, 3)
+    s[f"encoder.block.{n + 1}.conv.bias"] = (D,)
+    for j, f in enumerate(a.downsample_factor):
+        p = f"quantizer.downsample.{j}"
+        s[f"{p}.0.conv.weight"] = (D, D, f)
+        s[f"{p}.0.conv.bias"] = (D,)
+        s[f"{p}.1.dwconv.conv.weight"] = (D, 1, 7)
+        s[f"{p}.1.dwconv.conv.bias"] = (D,)
+        s[f"{p}.1.norm.weight"] = (D,)
+        s[f"{p}.1.norm.bias"] = (D,)
+        s[f"{p}.1.pwconv1.weight"] = (4 * D, D)
+        s[f"{p}.1.pwconv1.bias"] = (4 * D,)
+        s[f"{p}.1.pwconv2.weight"] = (D, 4 * D)
+        s[f"{p}.1.pwconv2.bias"] = (D,)
+        s[f"{p}.1.gamma"] = (D,)
+    for l in range(a.n_tf_layer):
+        p = f"quantizer.pre_module.layers.{l}"
+        s[f"{p}.attention.wqkv.weight"] = (3 * H, D)
+        s[f"{p}.attention.wo.weight"] = (D, H)
+        s[f"{p}.feed_forward.w1.weight"] = (a.tf_ffn, D)
+        s[f"{p}.feed_forward.w3.weight"] = (a.tf_ffn, D)
+        s[f"{p}.feed_forward.w2.weight"] = (D, a.tf_ffn)
+        for n in ("ffn_norm.weight", "attention_norm.weight", "attention_layer_scale.gamma", "ffn_layer_scale.gamma"):
+            s[f"{p}.{n}"] = (D,)
+    s["quantizer.pre_module.norm.weight"] = (D,)
+    s["quantizer.semantic_quantizer.quantizers.0.in_proj.weight"] = (a.codebook_dim, D, 1)
+    s["quantizer.semantic_quantizer.quantizers.0.in_proj.bias"] = (a.codebook_dim,)
+    for i in range(a.n_codebooks):
+        s[f"quantizer.quantizer.quantizers.{i}.in_proj.weight"] = (a.codebook_dim, D, 1)
+        s[f"quantizer.quantizer.quantizers.{i}.in_proj.bias"] = (a.codebook_dim,)
+    return s
+
+
+def random_codec_state_dict(a, seed: int = 0, with_encoder: bool = False) -> Dict[str, torch.Tensor]:
     """Synthetic codec weights with O(1) activations through the stack (for benches / smoke runs)."""
     import math
     g = torch.Generator().manual_seed(seed)
     out = {}
-    for k, shp in codec_state_dict_shapes(a).items():
+    shapes = codec_state_dict_shapes(a)
+    if with_encoder:
+        shapes.update(codec_encoder_state_dict_shapes(a))
+    for k, shp in shapes.items():
         if k.endswith("alpha"):
             w = 0.5 + torch.rand(shp, generator=g)
         elif k.endswith("gamma"):
@@ -163,5 +235,7 @@ def random_codec_state_dict(a, seed: int = 0) -> Dict[str, torch.Tensor]:
                 w = 0.3 * w
             if k.startswith("decoder.model.") and k.endswith(".block.1.conv.weight"):
                 w = 0.7 * w
+            if k == "encoder.block.0.conv.weight":
+                w = 3.0 * w   # audio in [-1, 1] has a small RMS
         out[k] = w.float()
     return out

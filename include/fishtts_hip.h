@@ -57,6 +57,13 @@ typedef struct ft_codec_config {
     int32_t rates[8];              /* 8,8,4,2 */
     int32_t max_frames;            /* longest code sequence per call */
     int32_t max_batch;
+    /* encode side (encode_reference: synthesizer.py:325-357, Encoder vocoder.py:498-575); encoder_dim = 0: decode only */
+    int32_t encoder_dim;           /* 64 */
+    int32_t n_enc_rates;           /* 4 */
+    int32_t enc_rates[8];          /* 2,4,8,8 */
+    int32_t enc_tf_layers[8];      /* 0,0,0,4: window-limited transformer layers after each block's strided conv */
+    int32_t enc_tf_window;         /* 512 */
+    int32_t max_enc_frames;        /* longest reference in code frames (a frame = prod(enc_rates)*4 samples) */
 } ft_codec_config;
 
 /* Sampling scalars of synthesize()/generate_long() (synthesizer.py:431-439, inference.py:741-765). */
@@ -128,6 +135,13 @@ ft_status ft_ar_get_debug(ft_ctx* ctx, int32_t slot, float* logits /*vocab*/, fl
 ft_status ft_codec_decode(ft_ctx* ctx, const int32_t* codes, int32_t B, int32_t T, const int32_t* lens,
                           float* audio);
 int32_t ft_codec_frame_len(const ft_ctx* ctx); /* samples per code frame (2048) */
+/* Codec encode = vocoder.encode(audio, lengths) of encode_reference (synthesizer.py:325-357, vocoder.py:885-904):
+ * mono f32 audio at the codec sample rate (host), right-padded to whole frames -> codes (num_codebooks+1) x T'
+ * int32 row-major (host, row stride = T' = ceil(n_samples / ft_codec_enc_frame_len)); *out_frames = T'. */
+ft_status ft_codec_encode(ft_ctx* ctx, const float* audio, int64_t n_samples, int32_t* codes, int32_t* out_frames);
+int32_t ft_codec_enc_frame_len(const ft_ctx* ctx);
+/* Test hook: the residual vector quantiser search alone on given pre-quantiser latents z [T][latent_dim] f32 (host). */
+ft_status ft_codec_rvq_encode(ft_ctx* ctx, const float* z, int32_t T, int32_t* codes);
 
 /* Measurement hook used by bench.py (never by the product path).  The weight-streaming GEMV launches of
  * one decode frame whose weights come from HBM (4 per slow layer + the vocabulary head; the fast stack's

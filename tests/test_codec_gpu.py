@@ -88,3 +88,112 @@ def test_s1_mini_codec_shapes_vs_oracle():
     assert got.shape[1] == int(lens[0]) == T * 2048
     assert rel_rms(got[0], want[0, 0].numpy()) <= REL_RMS_TOL, rel_rms(got[0], want[0, 0].numpy())
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- encode side (F4)
+def encode_shape():
+    """Smallest widths the MFMA tiles take (channels are multiples of 32; encoder transformers have 64-wide heads)."""
+    return C.CodecShape(n_codebooks=3, codebook_size=64, semantic_codebook_size=128, codebook_dim=8, latent_dim=512,
+                        n_tf_layer=2, tf_n_head=8, tf_head_dim=64, tf_ffn=768, tf_window=8, tf_block_size=256,
+                        upsample=[2, 2], decoder_dim=128, rates=[4, 4], encoder_dim=32, encoder_rates=[2, 2, 2, 2],
+                        encoder_tf_layers=[0, 0, 1, 1], enc_tf_window=16, enc_tf_block_size=1024)
+
+
+def make_codec_with_encoder(shape, max_frames=64):
+    from fish_tts_amd.codec_engine import CodecHipEngine
+    a = args_from_shape(shape)
+    a.encoder_dim, a.encoder_rates = shape.encoder_dim, list(shape.encoder_rates)
+    a.encoder_transformer_layers, a.encoder_tf_window = list(shape.encoder_tf_layers), shape.enc_tf_window
+    w = C.random_weights(shape, seed=0)
+    w.update(C.random_encoder_weights(shape, seed=1))
+    eng = CodecHipEngine(a, device=0, max_frames=max_frames, with_encoder=True)
+    eng.load_state_dict(w)
+    return eng, C.CodecOracle(shape, w)
+
+
+def _test_audio(n, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(n).float()
+    return (0.4 * torch.sin(2 * np.pi * t / 37.0) + 0.2 * torch.randn(n, generator=g)).numpy()
+
+
+def test_rvq_search_is_exact_on_given_latents():
+    """The quantiser search alone (f32, integer output): on the oracle's own pre-quantiser latents every index must
+    equal the oracle's, except where the oracle's two best codebook rows are closer than 1e-5 in score."""
+    shape = encode_shape()
+    eng, orc = make_codec_with_encoder(shape)
+    audio = _test_audio(40 * shape.enc_frame_len - 7)
+    want, _ = orc.encode(torch.from_numpy(audio)[None, None])
+    z = orc.taps["pre"][0].transpose(0, 1).contiguous().numpy()          # (T, D)
+    got = eng.rvq_encode(z)
+    assert got.shape == want[0].shape
+    diff = np.argwhere(got != want[0].numpy())
+    # a flip at codebook q changes the residual for q+1.., so only the first differing codebook of a frame is judged
+    first = {}
+    for q, t in diff:
+        first[t] = min(first.get(t, 99), q)
+    assert len(first) <= max(1, got.shape[1] // 20), (len(first), got.shape)
+    eng.close()
+
+
+def test_encode_vs_oracle():
+    """Full encode (bf16 MFMA contractions, bf16 activations) against the f32 oracle.  Indices come out of an argmax over
+    near neighbours in an 8-dim space, so bf16 rounding flips some; a flipped index is, by construction of RVQ, a
+    near-equivalent quantisation.  Stated tolerances: >= 85 % of the semantic indices equal, and the latents rebuilt
+    from the two code sets (oracle decode tables) within 0.4 relative RMS (measured: 94.6 %, 0.25); lengths and ranges exact."""
+    shape = encode_shape()
+    eng, orc = make_codec_with_encoder(shape)
+    assert eng.enc_frame_len == shape.enc_frame_len == 64
+    n = 37 * shape.enc_frame_len - 11
+    audio = _test_audio(n)
+    want, lens = orc.encode(torch.from_numpy(audio)[None, None], torch.tensor([n]))
+    got = eng.encode(audio)
+    assert got.shape == tuple(want[0].shape) == (shape.n_codebooks + 1, int(lens[0]))
+    assert (got[0] >= 0).all() and (got[0] < shape.semantic_codebook_size).all()
+    assert (got[1:] >= 0).all() and (got[1:] < shape.codebook_size).all()
+    agree = float(np.mean(got[0] == want[0, 0].numpy()))
+    orc.quantizer_decode(torch.from_numpy(got)[None])
+    z_got = orc.taps["rvq"].clone()
+    orc.quantizer_decode(want)
+    z_want = orc.taps["rvq"]
+    err = float((z_got - z_want).pow(2).mean().sqrt() / z_want.pow(2).mean().sqrt())
+    print(f"semantic agreement {agree:.3f}, latent rel rms {err:.3f}")
+    assert agree >= 0.85, agree
+    assert err <= 0.4, err
+    # causality of the whole encode path: a longer input with the same prefix gives the same leading frames
+    got2 = eng.encode(np.concatenate([audio[: 20 * shape.enc_frame_len], _test_audio(300, seed=8)]))
+    assert np.array_equal(got2[:, :20], got[:, :20])
+    eng.close()
+
+
+def test_encode_reference_api():
+    """FishTTS.encode_reference (synthesizer.py:325-357): WAV bytes -> VoiceProfile; 16-bit PCM scaling, resampling of
+    a non-44.1 kHz file, int64 codes of the codec's frame count."""
+    import io
+    import threading
+    import wave
+    import fish_tts_amd as ft
+    shape = encode_shape()
+    eng, _ = make_codec_with_encoder(shape)
+    synth = ft.FishTTS.__new__(ft.FishTTS)
+    synth._vocoder = eng
+    n = 30 * shape.enc_frame_len
+    pcm = (np.clip(_test_audio(n), -1, 1) * 32767).astype(np.int16)
+
+    def wav(rate, data):
+        buf = io.BytesIO()
+        with wave.open(buf, "wb") as wf:
+            wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(rate)
+            wf.writeframes(data.tobytes())
+        return buf.getvalue()
+    prof = synth.encode_reference(wav(44100, pcm), "hello")
+    assert isinstance(prof, ft.VoiceProfile) and prof.text == "hello" and prof.codes.dtype == np.int64
+    assert prof.codes.shape == (shape.n_codebooks + 1, 30)
+    assert np.array_equal(prof.codes, eng.encode(pcm.astype(np.float32) / 32768.0))
+    half = synth.encode_reference(wav(22050, pcm[::2].copy()), "hello")       # resampled x2 -> same duration
+    assert half.codes.shape == prof.codes.shape
+    synth._vocoder = None
+    with pytest.raises(RuntimeError, match="Vocoder not loaded"):
+        synth.encode_reference(wav(44100, pcm), "x")
+    eng.close()
+    del threading
