@@ -41,18 +41,26 @@ class Utterance:
 
 def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int = 8, on_frames=None) -> None:
     """Fills `frames` of every utterance.  `burst` = frames per scheduling step (graph replays between host looks);
-    `on_frames(index, (R, k) block)` is called as blocks arrive (streaming consumers)."""
+    `on_frames(index, (R, k) block)` is called as blocks arrive (streaming consumers).
+
+    Scheduling: longest frame budget first (LPT), the longest into the lowest slots; the lock-step width of a burst is
+    1 + the highest active slot, so that while the queue drains the batch narrows (cheaper frames) instead of
+    dragging finished slots along."""
     B = engine.max_batch
-    waiting = deque(range(len(utterances)))
+    order = sorted(range(len(utterances)), key=lambda i: -engine._clamp_new(utterances[i].prompt.shape[1],
+                                                                             utterances[i].max_new_tokens))
+    waiting = deque(order)
     owner: List[Optional[int]] = [None] * B
     budget = [0] * B
     idle_sp = engine._sampling(0.7, 0.8, 1.0)
     sps = [idle_sp] * B
+    parked = [False] * B
 
     def emit(i: int, block: np.ndarray):
-        u = utterances[i]
-        u.frames.extend(block[:, j] for j in range(block.shape[1]))
-        if on_frames is not None and block.shape[1]:
+        if block.shape[1] == 0:
+            return
+        utterances[i].frames.extend(block.T)            # rows of block.T are the (R,) columns
+        if on_frames is not None:
             on_frames(i, block)
 
     def fill(slot: int) -> None:
@@ -62,23 +70,28 @@ def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int =
             n_new = engine._clamp_new(u.prompt.shape[1], u.max_new_tokens)
             sp = engine._sampling(u.temperature, u.top_p, u.repetition_penalty, u.seed, u.ban_eos)
             first = engine._start(np.ascontiguousarray(u.prompt, dtype=np.int32), sp, u.prefix, slot)
+            parked[slot] = False
             emit(i, first[:, None])
             if n_new <= 1 or first[0] == engine.im_end_id:
                 continue                                  # finished at its first frame: the slot takes the next one
             owner[slot], budget[slot], sps[slot] = i, n_new - 1, sp
             return
         owner[slot], budget[slot], sps[slot] = None, 0, idle_sp
-        engine.park(slot)
+        if not parked[slot]:
+            engine.park(slot)
+            parked[slot] = True
 
     for s in range(B):
         fill(s)
-    while any(o is not None for o in owner):
-        k = min([burst] + [budget[s] for s in range(B) if owner[s] is not None])
-        frames, n = engine.decode(k, sps, poll=k)
-        for s in range(B):
+    while True:
+        active = [s for s in range(B) if owner[s] is not None]
+        if not active:
+            break
+        width = active[-1] + 1                            # slots above the highest active one are left out
+        k = min([burst] + [budget[s] for s in active])
+        frames, n = engine.decode(k, sps[:width], poll=k)
+        for s in active:
             i = owner[s]
-            if i is None:
-                continue
             got = int(n[s])
             emit(i, frames[s, :got].T)
             budget[s] -= got

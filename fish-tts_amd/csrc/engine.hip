@@ -1142,19 +1142,33 @@ extern "C" ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames,
         for (int m = 0; m < nslots; ++m) all = all && h[m];
         if (all) break;
     }
-    // collect: frames [nf0, nf0+done_frames) of each slot, cut after the first <|im_end|>
-    std::vector<int> seq((size_t)R * ctx->cap);
+    // collect: frames [nf0, nf0+done_frames) of each slot, cut after the first <|im_end|>.  Only the columns
+    // [nf0-1, nf0+done_frames) of the frame store travel (one strided copy per slot, all issued before the wait).
+    const int W = done_frames + 1;
+    std::vector<int> seq((size_t)nslots * R * W);
+    std::vector<char> was_done(nslots);
     for (int m = 0; m < nslots; ++m) {
-        FT_HIP(ctx, hipMemcpy(seq.data(), ctx->d_seq + (size_t)m * R * ctx->cap, seq.size() * sizeof(int), hipMemcpyDeviceToHost));
+        was_done[m] = (char)(ctx->h_pin[2 * nslots + m] != 0);   // state at entry (frozen slots produce nothing new)
+        if (was_done[m] || done_frames == 0) continue;
+        const int c0 = std::min(nf0[m] - 1, ctx->cap - W);        // stay inside the store near its end
+        FT_HIP(ctx, hipMemcpy2DAsync(seq.data() + (size_t)m * R * W, (size_t)W * sizeof(int),
+                                     ctx->d_seq + (size_t)m * R * ctx->cap + std::max(c0, 0), (size_t)ctx->cap * sizeof(int),
+                                     (size_t)std::min(W, ctx->cap) * sizeof(int), R, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int m = 0; m < nslots; ++m) {
         int n = 0;
-        for (int f = 0; f < done_frames; ++f) {
-            const int col = nf0[m] + f;
-            for (int r = 0; r < R; ++r) out_frames[((size_t)m * n_frames + f) * R + r] = seq[(size_t)r * ctx->cap + col];
-            n = f + 1;
-            if (seq[col] == c.im_end_id) break;
+        if (!was_done[m] && done_frames > 0) {
+            const int c0 = std::max(std::min(nf0[m] - 1, ctx->cap - W), 0);
+            const int* sm = seq.data() + (size_t)m * R * W;
+            for (int f = 0; f < done_frames; ++f) {
+                const int col = nf0[m] + f - c0;
+                if (col >= std::min(W, ctx->cap)) break;
+                for (int r = 0; r < R; ++r) out_frames[((size_t)m * n_frames + f) * R + r] = sm[(size_t)r * W + col];
+                n = f + 1;
+                if (sm[col] == c.im_end_id) break;
+            }
         }
-        // a slot that had already emitted <|im_end|> before this call produces nothing new
-        if (nf0[m] >= 1 && seq[nf0[m] - 1] == c.im_end_id) n = 0;
         out_n[m] = n;
     }
     return FT_OK;
