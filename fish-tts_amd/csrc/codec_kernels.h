@@ -40,6 +40,14 @@ struct TapGemmP {
     int round_lin;      // round acc+bias to bf16 first (an nn.Linear output of a bf16 model; also the SwiGLU steps)
     int round_f32_out;  // out_f32 receives bf16-rounded values
     long ldw;           // skinny kernel: row stride of W in elements (0 = K, dense)
+    // skinny kernel, fused RMSNorm (llama.py:172-177) of the X operand: X holds the un-normalised rows (exact bf16
+    // copies of the residual stream), ss_in[row][b] the partial sums of squares the producer GEMM's blocks left
+    // (ss_nblk partials per row, row stride ss_ld); ss_out: this GEMM's own partials of its f32 output rows
+    const bf16_t* gain;
+    const float* ss_in;
+    float* ss_out;
+    int ss_nblk, ss_ld;
+    float eps;
 };
 
 // offs[] lives in the kernel arguments: a runtime index would force the whole struct into scratch
@@ -357,10 +365,11 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
 // the four partial tiles meet in LDS and are summed in wave order (deterministic).  Epilogue = the nn.Linear
 // rounding points of the prefill (bias, rounded; residual add, rounded; SwiGLU on interleaved (gate, up) rows).
 // Requires K % 128 == 0; act in {ACT_NONE, ACT_SWIGLU}; ntap == 1.
-template <int TS, int NW>
+template <int TS, int NW, bool NORM>
 __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(TapGemmP p) {
     constexpr int CH = 4;                          // k-steps (of 32) per register chunk
     __shared__ float Cs[NW][TS * 16][17];
+    __shared__ float inv_s[TS * 16];
     const int kper = p.K / NW;                     // this wave's share of K (a multiple of 32)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -382,42 +391,78 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(TapGemmP p) {
 #pragma unroll
     for (int j = 0; j < TS; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const U4 zero = U4{0u, 0u, 0u, 0u};
-    auto load = [&](U4 (&w)[CH], U4 (&x)[TS][CH], int k0, int steps) {
+    const bf16_t* grow = NORM ? p.gain + kw + fq * 8 : nullptr;
+    auto load = [&](U4 (&w)[CH], U4 (&x)[TS][CH], U4 (&g)[CH], int k0, int steps) {
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
             if (s < steps) {
                 w[s] = nv ? *reinterpret_cast<const U4*>(wrow + k0 + s * 32) : zero;  // plain loads measured faster than nt here
+                if constexpr (NORM) g[s] = *reinterpret_cast<const U4*>(grow + k0 + s * 32);
 #pragma unroll
                 for (int j = 0; j < TS; ++j) x[j][s] = tv[j] ? *reinterpret_cast<const U4*>(xrow[j] + k0 + s * 32) : zero;
             }
         }
     };
-    auto compute = [&](const U4 (&w)[CH], const U4 (&x)[TS][CH], int steps) {
+    float inv[TS];
+    if constexpr (NORM) {
+        // 1/rms of every row of this block column from the producer's per-block partial sums of squares
+        // one wave per row: its lanes fetch the row's partials in one coalesced load, DPP tree sum (fixed order)
+        for (int t = wave; t < TS * 16; t += NW) {
+            const int row = m0 + t;
+            float ss = 0.f;
+            if (row < p.M)
+                for (int b = lane; b < p.ss_nblk; b += 64) ss += p.ss_in[(size_t)row * p.ss_ld + b];
+            ss = wave_sum(ss);
+            if (lane == 0) inv_s[t] = rsqrt_exact(ss / (float)p.K + p.eps);
+        }
+    }
+    U4 wa[CH], wb[CH], xa[TS][CH], xb[TS][CH], ga[CH], gb[CH];
+    if (nch > 0) load(wa, xa, ga, 0, CH);   // in flight while the norms are summed
+    if constexpr (NORM) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TS; ++j) inv[j] = inv_s[j * 16 + fr];
+    }
+    auto compute = [&](const U4 (&w)[CH], const U4 (&x)[TS][CH], const U4 (&g)[CH], int steps) {
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
             if (s < steps) {
                 bf16x8 b;
                 __builtin_memcpy(&b, &w[s], 16);
+                float gv[8];
+                if constexpr (NORM) Vec<bf16_t>::unpack(g[s], gv);
 #pragma unroll
                 for (int j = 0; j < TS; ++j) {
                     bf16x8 a;
-                    __builtin_memcpy(&a, &x[j][s], 16);
+                    if constexpr (NORM) {   // x -> round(round(x / rms) * gain), the two roundings of llama.py:172-177
+                        float xv[8];
+                        Vec<bf16_t>::unpack(x[j][s], xv);
+                        U4 o;
+                        uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const float y0 = round_bf16(xv[e] * inv[j]) * gv[e];
+                            const float y1 = round_bf16(xv[e + 1] * inv[j]) * gv[e + 1];
+                            ow[e >> 1] = (uint32_t)f32_to_bf16_bits(y0) | ((uint32_t)f32_to_bf16_bits(y1) << 16);
+                        }
+                        __builtin_memcpy(&a, &o, 16);
+                    } else {
+                        __builtin_memcpy(&a, &x[j][s], 16);
+                    }
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
                 }
             }
         }
     };
-    U4 wa[CH], wb[CH], xa[TS][CH], xb[TS][CH];
-    if (nch > 0) load(wa, xa, 0, CH);
     for (int c = 0; c < nch; c += 2) {
-        if (c + 1 < nch) load(wb, xb, (c + 1) * 32 * CH, CH);
-        compute(wa, xa, CH);
-        if (c + 2 < nch) load(wa, xa, (c + 2) * 32 * CH, CH);
-        if (c + 1 < nch) compute(wb, xb, CH);
+        if (c + 1 < nch) load(wb, xb, gb, (c + 1) * 32 * CH, CH);
+        compute(wa, xa, ga, CH);
+        if (c + 2 < nch) load(wa, xa, ga, (c + 2) * 32 * CH, CH);
+        if (c + 1 < nch) compute(wb, xb, gb, CH);
     }
     if (rem) {
-        load(wa, xa, nch * 32 * CH, rem);
-        compute(wa, xa, rem);
+        load(wa, xa, ga, nch * 32 * CH, rem);
+        compute(wa, xa, ga, rem);
     }
     // lane holds C[token = j*16 + 4*fq + r][n = fr]
 #pragma unroll
@@ -444,18 +489,26 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(TapGemmP p) {
         }
     } else {
         for (int e = tid; e < TS * 16 * 16; e += NW * 64) {
-            const int row = e >> 4, c = e & 15;
+            const int row = e >> 4, c = e & 15;      // 16 consecutive lanes finish one row's 16 columns
             const int t = m0 + row, n = n0 + c;
-            if (t >= p.M || n >= p.N) continue;
-            float v = Cs[0][row][c];
+            const bool ok = t < p.M && n < p.N;
+            float stored = 0.f;
+            if (ok) {
+                float v = Cs[0][row][c];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) v += Cs[w][row][c];
-            if (p.bias) v += p.bias[n % p.n_mod];
-            if (p.round_lin) v = round_bf16(v);
-            if (p.resid_f32) v += p.resid_f32[(size_t)t * p.ldr + n];
-            const size_t oi = (size_t)t * p.ldo + n;
-            if (p.out_f32) p.out_f32[oi] = p.round_f32_out ? round_bf16(v) : v;
-            if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(v);
+                for (int w = 1; w < NW; ++w) v += Cs[w][row][c];
+                if (p.bias) v += p.bias[n % p.n_mod];
+                if (p.round_lin) v = round_bf16(v);
+                if (p.resid_f32) v += p.resid_f32[(size_t)t * p.ldr + n];
+                const size_t oi = (size_t)t * p.ldo + n;
+                stored = p.round_f32_out ? round_bf16(v) : v;
+                if (p.out_f32) p.out_f32[oi] = stored;
+                if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(v);
+            }
+            if (p.ss_out) {   // this block's share of the row's sum of squares, for the next GEMM's fused RMSNorm
+                const float sq = row16_sum(stored * stored);
+                if (c == 0 && t < p.M) p.ss_out[(size_t)t * p.ss_ld + blockIdx.x] = sq;
+            }
         }
     }
 }
@@ -469,10 +522,20 @@ static inline int skinny_waves(int N, int K, int TS) {
 template <int TS>
 static inline void skinny_gemm_launch(const TapGemmP& p, int gy, hipStream_t st) {
     const dim3 grid((p.N + 15) / 16, gy);
-    switch (skinny_waves(p.N, p.K, TS)) {
-        case 12: skinny_gemm_kernel<TS, 12><<<grid, 768, 0, st>>>(p); break;
-        case 8: skinny_gemm_kernel<TS, 8><<<grid, 512, 0, st>>>(p); break;
-        default: skinny_gemm_kernel<TS, 4><<<grid, 256, 0, st>>>(p);
+    int nw = skinny_waves(p.N, p.K, TS);
+    if (p.gain && TS == 4) nw = 4;   // the fused norm's extra registers: keep the 64-row variant off the spill edge
+    if (p.gain) {
+        switch (nw) {
+            case 12: skinny_gemm_kernel<TS, 12, true><<<grid, 768, 0, st>>>(p); break;
+            case 8: skinny_gemm_kernel<TS, 8, true><<<grid, 512, 0, st>>>(p); break;
+            default: skinny_gemm_kernel<TS, 4, true><<<grid, 256, 0, st>>>(p);
+        }
+    } else {
+        switch (nw) {
+            case 12: skinny_gemm_kernel<TS, 12, false><<<grid, 768, 0, st>>>(p); break;
+            case 8: skinny_gemm_kernel<TS, 8, false><<<grid, 512, 0, st>>>(p); break;
+            default: skinny_gemm_kernel<TS, 4, false><<<grid, 256, 0, st>>>(p);
+        }
     }
 }
 

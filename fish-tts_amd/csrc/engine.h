@@ -65,6 +65,11 @@ struct ft_ctx {
     ft::bf16_t *pf_xn = nullptr, *pf_ybf = nullptr, *pf_g = nullptr;
     // lock-step batches of >= wide_min utterances run every Linear on the MFMA skinny kernel (bf16 operand copies)
     ft::bf16_t *mb_xn = nullptr, *mb_ybf = nullptr, *mb_g = nullptr;
+    // fused RMSNorm of the wide path: exact bf16 copy of the residual stream + per-block partial sums of squares
+    ft::bf16_t* mb_xb = nullptr;
+    float* mb_ss = nullptr;   // [max(dim, fast_dim) / 16][max_batch]
+    bool wide_fuse = false;
+    int wide_fuse_max = 16;   // largest lock-step batch that takes the fused-norm GEMMs
     int wide_min = 8;
     bool wide_ok = false;
     bool prefill_v0 = false;

@@ -191,6 +191,16 @@ static ft_status ar_alloc(ft_ctx* ctx) {
             FT_TRY(dmalloc(ctx, &ctx->mb_xn, M * (size_t)std::max(c.dim, c.fast_dim)));
             FT_TRY(dmalloc(ctx, &ctx->mb_ybf, M * (size_t)std::max(c.n_head * c.head_dim, c.fast_n_head * c.fast_head_dim)));
             FT_TRY(dmalloc(ctx, &ctx->mb_g, M * (size_t)std::max(c.intermediate_size, c.fast_intermediate_size)));
+            FT_TRY(dmalloc(ctx, &ctx->mb_xb, M * (size_t)std::max(c.dim, c.fast_dim)));
+            FT_TRY(dmalloc(ctx, &ctx->mb_ss, M * (size_t)(std::max(c.dim, c.fast_dim) / 16 + 1)));
+            // the norm rides inside the consumer GEMM only where every Linear of a layer takes the skinny kernel, and only up
+            // to 16 rows: measured +8 % at B=8, +5 % at B=16, -4 % at B=32 (the in-register normalisation of two row tiles
+            // costs more VALU time than the removed launches)
+            if (getenv("FT_FUSE_NORM_MAX")) ctx->wide_fuse_max = atoi(getenv("FT_FUSE_NORM_MAX"));
+            auto sk = [](int k) { return k % 128 == 0; };
+            ctx->wide_fuse = !getenv("FT_NO_FUSE_NORM") && sk(c.dim) && sk(c.n_head * c.head_dim) && sk(c.intermediate_size) &&
+                             sk(c.fast_dim) && sk(c.fast_n_head * c.fast_head_dim) && sk(c.fast_intermediate_size) &&
+                             c.dim % 16 == 0 && c.fast_dim % 16 == 0 && c.max_batch <= 128;
         }
     }
     const size_t nchunk = ((size_t)c.vocab_size + 1023) / 1024;
@@ -261,7 +271,7 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     int* ibufs[] = {ctx->d_pos, ctx->d_tok, ctx->d_tokn, ctx->d_seq, ctx->d_nf, ctx->d_done, ctx->d_prompt};
     for (int* b : ibufs) if (b) hipFree(b);
     if (ctx->d_ctl) hipFree(ctx->d_ctl);
-    { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g, ctx->mb_xn, ctx->mb_ybf, ctx->mb_g}; for (void* q : pf) if (q) hipFree(q); }
+    { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g, ctx->mb_xn, ctx->mb_ybf, ctx->mb_g, ctx->mb_xb, ctx->mb_ss}; for (void* q : pf) if (q) hipFree(q); }
     for (auto& l : ctx->layers) { if (l.bqkv_f32) hipFree(l.bqkv_f32); if (l.bo_f32) hipFree(l.bo_f32); }
     if (ctx->samp_hist) hipFree(ctx->samp_hist);
     if (ctx->samp_cut) hipFree(ctx->samp_cut);
@@ -417,8 +427,15 @@ struct Launch {
     void chk() { hipError_t e = hipGetLastError(); if (e != hipSuccess && err == hipSuccess) err = e; }
 };
 
+struct PfX {   // fused RMSNorm hooks of the skinny kernel (codec_kernels.h TapGemmP)
+    const void* gain = nullptr;   // normalise the X rows with this gain ...
+    const float* ss_in = nullptr; // ... and the producer's partial sums of squares (nblk per row)
+    int nblk = 0;
+    float* ss_out = nullptr;      // leave this GEMM's own partials for the next consumer
+};
 static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, const float* bias, int N, int K,
-                    int act, const float* resid, float* out_f32, bf16_t* out_bf, long ldo, int round_out);
+                    int act, const float* resid, float* out_f32, bf16_t* out_bf, long ldo, int round_out,
+                    const PfX& fx = PfX());
 // A lock-step batch of >= wide_min rows (bf16): every Linear is an M-row GEMM on the MFMA skinny kernel (weights read
 // once for the whole batch), norms run as their own row kernels, attention hands bf16 copies to the Wo GEMM.
 static bool wide_batch(const Launch& L) {
@@ -568,8 +585,20 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
                 bf16_t* xn = ctx->mb_xn + (size_t)m0 * D;
                 bf16_t* ybf = ctx->mb_ybf + (size_t)m0 * HD;
                 bf16_t* gbf = ctx->mb_g + (size_t)m0 * F;
-                rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.attn_norm, c.norm_eps, D, xn);
-                pf_gemm(L, xn, D, M, l.wqkv, l.bqkv_f32, (int)qkvN, D, ACT_NONE, nullptr, qkv, nullptr, (long)qkvN, 0);
+                // fused norm: the Wo / W2 epilogues leave an exact bf16 copy of x and per-block sums of squares,
+                // the next GEMM normalises its operand on the fly (layer 0 reads the embedding kernel's x: row kernel)
+                const bool fuse = ctx->wide_fuse && M <= ctx->wide_fuse_max;
+                bf16_t* xb = ctx->mb_xb + (size_t)m0 * D;
+                float* ss = ctx->mb_ss + (size_t)m0 * (std::max(c.dim, c.fast_dim) / 16 + 1);
+                PfX leave; leave.ss_out = fuse ? ss : nullptr;
+                PfX nrm; nrm.ss_in = ss; nrm.nblk = D / 16;
+                if (fuse && li > 0) {
+                    nrm.gain = l.attn_norm;
+                    pf_gemm(L, xb, D, M, l.wqkv, l.bqkv_f32, (int)qkvN, D, ACT_NONE, nullptr, qkv, nullptr, (long)qkvN, 0, nrm);
+                } else {
+                    rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.attn_norm, c.norm_eps, D, xn);
+                    pf_gemm(L, xn, D, M, l.wqkv, l.bqkv_f32, (int)qkvN, D, ACT_NONE, nullptr, qkv, nullptr, (long)qkvN, 0);
+                }
                 AttnP a{};
                 a.qkv = qkv; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->rope;
                 a.kc = (char*)l.kc + (size_t)m0 * ctx->cache_m_stride * ctx->esz;
@@ -586,10 +615,15 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
                 a.part_ml = ctx->part_ml + (size_t)m0 * c.n_head * ctx->nsplit * 2;
                 attn_decode<WT, ROUND>(L, a);
                 if (ns > 1) { attn_combine_rows_kernel<ROUND><<<M, 256, 0, L.s>>>(a); L.chk(); }
-                pf_gemm(L, ybf, HD, M, l.wo, l.bo_f32, D, HD, ACT_NONE, x, x, nullptr, D, 1);
-                rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.ffn_norm, c.norm_eps, D, xn);
-                pf_gemm(L, xn, D, M, l.w13, nullptr, 2 * F, D, ACT_SWIGLU, nullptr, nullptr, gbf, F, 0);
-                pf_gemm(L, gbf, F, M, l.w2, nullptr, D, F, ACT_NONE, x, x, nullptr, D, 1);
+                pf_gemm(L, ybf, HD, M, l.wo, l.bo_f32, D, HD, ACT_NONE, x, x, fuse ? xb : nullptr, D, 1, leave);
+                if (fuse) {
+                    nrm.gain = l.ffn_norm;
+                    pf_gemm(L, xb, D, M, l.w13, nullptr, 2 * F, D, ACT_SWIGLU, nullptr, nullptr, gbf, F, 0, nrm);
+                } else {
+                    rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.ffn_norm, c.norm_eps, D, xn);
+                    pf_gemm(L, xn, D, M, l.w13, nullptr, 2 * F, D, ACT_SWIGLU, nullptr, nullptr, gbf, F, 0);
+                }
+                pf_gemm(L, gbf, F, M, l.w2, nullptr, D, F, ACT_NONE, x, x, fuse ? xb : nullptr, D, 1, leave);
             }
             continue;
         }
@@ -653,6 +687,12 @@ static void enqueue_head(Launch& L) {
     if (wide_batch(L)) {
         if constexpr (ROUND) {
             bf16_t* xn = ctx->mb_xn + (size_t)L.m0 * c.dim;
+            if (ctx->wide_fuse && L.M <= ctx->wide_fuse_max && c.n_layer > 0 && c.vocab_size % 2 == 0) {  // x and its partials: last slow W2
+                PfX nrm; nrm.gain = ctx->norm; nrm.ss_in = ctx->mb_ss + (size_t)L.m0 * (std::max(c.dim, c.fast_dim) / 16 + 1); nrm.nblk = c.dim / 16;
+                pf_gemm(L, ctx->mb_xb + (size_t)L.m0 * c.dim, c.dim, L.M, ctx->head, nullptr, c.vocab_size, c.dim, ACT_NONE, nullptr,
+                        ctx->logits + (size_t)L.m0 * c.vocab_size, nullptr, c.vocab_size, 0, nrm);
+                return;
+            }
             rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(ctx->x + (size_t)L.m0 * c.dim, ctx->norm, c.norm_eps, c.dim, xn);
             pf_gemm(L, xn, c.dim, L.M, ctx->head, nullptr, c.vocab_size, c.dim, ACT_NONE, nullptr,
                     ctx->logits + (size_t)L.m0 * c.vocab_size, nullptr, c.vocab_size, 0);
@@ -735,8 +775,19 @@ static void enqueue_fast_step(Launch& L, const int cb) {
                     bf16_t* xn = ctx->mb_xn + (size_t)m0 * Df;
                     bf16_t* ybf = ctx->mb_ybf + (size_t)m0 * HDf;
                     bf16_t* gbf = ctx->mb_g + (size_t)m0 * Ff;
-                    rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xl, l.attn_norm, c.norm_eps, Df, xn);
-                    pf_gemm(L, xn, Df, M, l.wqkv, nullptr, (int)qkvN, Df, ACT_NONE, nullptr, qkvf, nullptr, (long)qkvN, 0);
+                    // fused norm as in the slow layers; layer 0 reads hid / the code embedding (row kernel)
+                    const bool fuse = ctx->wide_fuse && M <= ctx->wide_fuse_max;
+                    bf16_t* xb = ctx->mb_xb + (size_t)m0 * Df;
+                    float* ss = ctx->mb_ss + (size_t)m0 * (std::max(c.dim, c.fast_dim) / 16 + 1);
+                    PfX leave; leave.ss_out = fuse ? ss : nullptr;
+                    PfX nrm; nrm.ss_in = ss; nrm.nblk = Df / 16;
+                    if (fuse && li > 0) {
+                        nrm.gain = l.attn_norm;
+                        pf_gemm(L, xb, Df, M, l.wqkv, nullptr, (int)qkvN, Df, ACT_NONE, nullptr, qkvf, nullptr, (long)qkvN, 0, nrm);
+                    } else {
+                        rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xl, l.attn_norm, c.norm_eps, Df, xn);
+                        pf_gemm(L, xn, Df, M, l.wqkv, nullptr, (int)qkvN, Df, ACT_NONE, nullptr, qkvf, nullptr, (long)qkvN, 0);
+                    }
                     FastAttnP a{};
                     a.qkv = qkvf; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->frope;
                     a.kc = (char*)l.kc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
@@ -748,10 +799,15 @@ static void enqueue_fast_step(Launch& L, const int cb) {
                     // y (f32) and its bf16 copy share the row stride HDf here
                     fast_attn_kernel<WT, ROUND><<<dim3(Hf, M), 64, 0, L.s>>>(a, yf, HDf);
                     L.chk();
-                    pf_gemm(L, ybf, HDf, M, l.wo, nullptr, Df, HDf, ACT_NONE, xl, xf, nullptr, Df, 1);
-                    rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xf, l.ffn_norm, c.norm_eps, Df, xn);
-                    pf_gemm(L, xn, Df, M, l.w13, nullptr, 2 * Ff, Df, ACT_SWIGLU, nullptr, nullptr, gbf, Ff, 0);
-                    pf_gemm(L, gbf, Ff, M, l.w2, nullptr, Df, Ff, ACT_NONE, xf, xf, nullptr, Df, 1);
+                    pf_gemm(L, ybf, HDf, M, l.wo, nullptr, Df, HDf, ACT_NONE, xl, xf, fuse ? xb : nullptr, Df, 1, leave);
+                    if (fuse) {
+                        nrm.gain = l.ffn_norm;
+                        pf_gemm(L, xb, Df, M, l.w13, nullptr, 2 * Ff, Df, ACT_SWIGLU, nullptr, nullptr, gbf, Ff, 0, nrm);
+                    } else {
+                        rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xf, l.ffn_norm, c.norm_eps, Df, xn);
+                        pf_gemm(L, xn, Df, M, l.w13, nullptr, 2 * Ff, Df, ACT_SWIGLU, nullptr, nullptr, gbf, Ff, 0);
+                    }
+                    pf_gemm(L, gbf, Ff, M, l.w2, nullptr, Df, Ff, ACT_NONE, xf, xf, fuse ? xb : nullptr, Df, 1, leave);
                 }
                 continue;
             }
@@ -789,9 +845,15 @@ static void enqueue_fast_step(Launch& L, const int cb) {
         if (wide) {
             if constexpr (ROUND) {
                 bf16_t* xn = ctx->mb_xn + (size_t)m0 * Df;
-                rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(xf, ctx->fast_norm, c.norm_eps, Df, xn);
-                pf_gemm(L, xn, Df, L.M, ctx->fast_out, nullptr, ctx->fastV, Df, ACT_NONE, nullptr,
-                        ctx->flog + (size_t)m0 * ctx->fastV, nullptr, ctx->fastV, 0);
+                if (ctx->wide_fuse && L.M <= ctx->wide_fuse_max && c.n_fast_layer > 0 && ctx->fastV % 2 == 0) {
+                    PfX nrm; nrm.gain = ctx->fast_norm; nrm.ss_in = ctx->mb_ss + (size_t)m0 * (std::max(c.dim, c.fast_dim) / 16 + 1); nrm.nblk = Df / 16;
+                    pf_gemm(L, ctx->mb_xb + (size_t)m0 * Df, Df, L.M, ctx->fast_out, nullptr, ctx->fastV, Df, ACT_NONE, nullptr,
+                            ctx->flog + (size_t)m0 * ctx->fastV, nullptr, ctx->fastV, 0, nrm);
+                } else {
+                    rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(xf, ctx->fast_norm, c.norm_eps, Df, xn);
+                    pf_gemm(L, xn, Df, L.M, ctx->fast_out, nullptr, ctx->fastV, Df, ACT_NONE, nullptr,
+                            ctx->flog + (size_t)m0 * ctx->fastV, nullptr, ctx->fastV, 0);
+                }
             }
             enqueue_sample<WT, ROUND>(L, cb, cb == c.num_codebooks - 1);
             return;
@@ -890,17 +952,22 @@ static ft_status upload_ctl(ft_ctx* ctx, int m0, int n, const ft_sampling* sp) {
 // (Linear output rounded, residual add rounded, SwiGLU steps rounded; llama.py:172-190,229-283,322-331).
 // K/V of all positions are appended first, then every position attends over the cache.
 static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, const float* bias, int N, int K,
-                    int act, const float* resid, float* out_f32, bf16_t* out_bf, long ldo, int round_out) {
+                    int act, const float* resid, float* out_f32, bf16_t* out_bf, long ldo, int round_out, const PfX& fx) {
     TapGemmP p{};
+    p.gain = (const bf16_t*)fx.gain; p.ss_in = fx.ss_in; p.ss_out = fx.ss_out; p.ss_nblk = fx.nblk;
+    p.ss_ld = std::max(L.ctx->c.dim, L.ctx->c.fast_dim) / 16 + 1; p.eps = L.ctx->c.norm_eps;
     p.X = X; p.ldx = ldx; p.T_in = S; p.W = (const bf16_t*)W; p.ntap = 1; p.offs[0] = 0; p.M = S; p.N = N; p.K = K;
     p.bias = bias; p.n_mod = N; p.act = act; p.resid_f32 = resid; p.ldr = ldo; p.out_f32 = out_f32; p.out_bf = out_bf;
     p.ldo = ldo; p.round_lin = 1; p.round_f32_out = round_out;
     const int mode = L.ctx->prefill_gemm_mode;  // FT_PREFILL_GEMM: 0 = first tile kernel only, 1 = no skinny kernel
-    if (mode >= 2 && S <= 128 && K % 128 == 0 && N % 2 == 0) {
+    const bool fused = fx.gain || fx.ss_out;
+    if ((mode >= 2 || fused) && S <= 128 && K % 128 == 0 && N % 2 == 0) {
         // short prompts are weight-bandwidth bound: 16 weight rows per block, K split over the waves
         if (S <= 16) skinny_gemm_launch<1>(p, 1, L.s);
         else if (S <= 32) skinny_gemm_launch<2>(p, 1, L.s);
         else skinny_gemm_launch<4>(p, (S + 63) / 64, L.s);
+    } else if (fused) {
+        L.err = hipErrorInvalidValue;   // the fused norm exists on the skinny kernel only (callers check the shapes)
     } else if (mode >= 1 && K % 64 == 0 && N % 128 == 0) {
         // long prompts (reference audio): the pipelined tile kernel of the codec
         if (S <= 1024) {
