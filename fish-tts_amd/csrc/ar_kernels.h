@@ -529,145 +529,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     }
 }
 
-// Prompt-pass attention: P consecutive prompt positions per block share every K/V row they read (the per-position
-// kernel above re-reads the whole prefix for each position: quadratic L2 traffic).  All K/V are already in the cache
-// (pass 1 of the prefill), so this is the attend-only half.  The arithmetic per position is that of
-// attn_decode_kernel with nsplit = 1 - same key-to-lane-group mapping, same online-softmax order per group, same merge
-// order - so the two kernels agree bit for bit (tests/test_ar_gpu.py).  grid (Hkv, ceil(n_rows / P)), 256 threads.
-template <typename WT, int G, int P, bool ROUND>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnP p, int n_rows) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int kvh = blockIdx.x, r0 = blockIdx.y * P;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hd = p.hd, hp = hd >> 1;
-    const int LPP = hd >> 3, PPW = 64 / LPP, NSLOT = 4 * PPW;
-    float* q_s = smem;                      // [P][G][hd]
-    float* ml_s = q_s + P * G * hd;         // [NSLOT][G][2]
-    float* acc_s = ml_s + NSLOT * G * 2;    // [NSLOT][G][hd]
-    const WT* qn = reinterpret_cast<const WT*>(p.qn);
-    const WT* kc = reinterpret_cast<const WT*>(p.kc) + (size_t)kvh * p.n_slots * hd;
-    const WT* vc = reinterpret_cast<const WT*>(p.vc) + (size_t)kvh * p.n_slots * hd;
-    const int grp = lane / LPP, gl = lane % LPP;
-    const int slot = wave * PPW + grp;
-    const int rows = min(P, n_rows - r0);                 // live positions of this block
-    const int hi = p.pos_off + r0 + rows;                 // keys [0, hi) are visible to the last live position
-    auto load_kv = [&](int j, float(&kv)[8], float(&vv)[8]) {
-        if constexpr (sizeof(WT) == 2) {
-            Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(kc) + (size_t)j * hd + gl * 8, kv);
-            Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(vc) + (size_t)j * hd + gl * 8, vv);
-        } else {
-            const float* kf = reinterpret_cast<const float*>(kc) + (size_t)j * hd + gl * 8;
-            const float* vf = reinterpret_cast<const float*>(vc) + (size_t)j * hd + gl * 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { kv[e] = kf[e]; vv[e] = vf[e]; }
-        }
-    };
-    float kn8[8], vn8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { kn8[e] = 0.f; vn8[e] = 0.f; }
-    if (wave * PPW + grp < hi) load_kv(wave * PPW + grp, kn8, vn8);   // travels while the queries are built
-
-    // queries: q-norm (one rounding) + RoPE at each position, as phase 1 of attn_decode_kernel
-    for (int item = wave; item < P * G; item += 4) {
-        const int i = item / G, g = item % G;
-        if (i >= rows) continue;
-        const float* src = p.qkv + (size_t)(r0 + i) * p.ldq + (size_t)(kvh * G + g) * hd;
-        const int pos = p.pos_off + r0 + i;
-        float x0 = 0.f, x1 = 0.f;
-        if (lane < hp) { x0 = src[2 * lane]; x1 = src[2 * lane + 1]; }
-        if (qn) {
-            const float ss = wave_sum(x0 * x0 + x1 * x1);
-            const float inv = rsqrt_exact(ss / (float)hd + p.eps);
-            if (lane < hp) {
-                x0 = rb<ROUND>((x0 * inv) * ld_elem(qn, 2 * lane));
-                x1 = rb<ROUND>((x1 * inv) * ld_elem(qn, 2 * lane + 1));
-            }
-        }
-        if (lane < hp) {
-            const float c = p.rope[((size_t)pos * hp + lane) * 2];
-            const float s = p.rope[((size_t)pos * hp + lane) * 2 + 1];
-            q_s[(i * G + g) * hd + 2 * lane] = rb<ROUND>(x0 * c - x1 * s);
-            q_s[(i * G + g) * hd + 2 * lane + 1] = rb<ROUND>(x1 * c + x0 * s);
-        }
-    }
-    __syncthreads();
-    float qr[P][G][8];
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qr[i][g][e] = i < rows ? q_s[(i * G + g) * hd + gl * 8 + e] : 0.f;
-    float mrun[P][G], lrun[P][G], acc[P][G][8];
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            mrun[i][g] = -INFINITY; lrun[i][g] = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[i][g][e] = 0.f;
-        }
-    for (int base = wave * PPW; base < hi; base += NSLOT) {
-        const int j = base + grp;
-        float kv[8], vv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { kv[e] = kn8[e]; vv[e] = vn8[e]; }
-        if (j + NSLOT < hi) load_kv(j + NSLOT, kn8, vn8);              // next row of this lane group
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const bool valid = i < rows && j <= p.pos_off + r0 + i;    // causal: key position <= query position
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                float d = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d = fmaf(qr[i][g][e], kv[e], d);
-                if (LPP > 1) d = group_sum_rt(d, LPP);
-                if (valid) {
-                    const float s = d * p.scale;
-                    const float mn = fmaxf(mrun[i][g], s);
-                    const float corr = expf(mrun[i][g] - mn);
-                    const float pj = expf(s - mn);
-                    lrun[i][g] = lrun[i][g] * corr + pj;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[i][g][e] = acc[i][g][e] * corr + pj * vv[e];
-                    mrun[i][g] = mn;
-                }
-            }
-        }
-    }
-    // merge the lane groups, one position at a time (the LDS image is that of attn_decode_kernel)
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        if (i >= rows) break;                                          // block-uniform
-        __syncthreads();
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (gl == 0) { ml_s[(slot * G + g) * 2] = mrun[i][g]; ml_s[(slot * G + g) * 2 + 1] = lrun[i][g]; }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc_s[(size_t)(slot * G + g) * hd + gl * 8 + e] = acc[i][g][e];
-        }
-        __syncthreads();
-        const int m = r0 + i;
-        for (int idx = tid; idx < G * hd; idx += 256) {
-            const int g = idx / hd, e = idx % hd;
-            float M = -INFINITY;
-            for (int s = 0; s < NSLOT; ++s) M = fmaxf(M, ml_s[(s * G + g) * 2]);
-            float L = 0.f, O = 0.f;
-            if (M > -INFINITY) {
-                for (int s = 0; s < NSLOT; ++s) {
-                    const float w = expf(ml_s[(s * G + g) * 2] - M);
-                    L += ml_s[(s * G + g) * 2 + 1] * w;
-                    O += acc_s[(size_t)(s * G + g) * hd + e] * w;
-                }
-            }
-            const int head = kvh * G + g;
-            const float yo = rb<ROUND>(O / L);
-            p.y[(size_t)m * p.ldy + head * hd + e] = yo;
-            if (p.y_bf) p.y_bf[(size_t)m * p.ldy + head * hd + e] = f32_to_bf16_bits(yo);
-        }
-    }
-}
-
 // Wo GEMV (+ residual) whose input vector is assembled on the fly from the split-KV partials of
 // attn_decode_kernel: y[head][e] = sum_s O_s w_s / sum_s l_s w_s, w_s = exp(m_s - max m).  Saves the
 // separate combine launch; each lane merges only the 8 (4) consecutive elements it multiplies.

@@ -1010,24 +1010,8 @@ static void prefill_gemm(Launch& L, int slot, int Lp, int pos0) {
         a.eps = c.norm_eps; a.scale = 1.0f / sqrtf((float)c.head_dim); a.y = ctx->pf_y; a.ldy = HD; a.y_bf = ctx->pf_ybf;
         Launch LA = L;
         LA.M = Lp;
-        const bool attn_v0 = getenv("FT_PREFILL_ATTN_V0") != nullptr;   // read per call: tests toggle it
-        const bool tiled = !attn_v0 && (G == 1 || G == 2 || G == 4) && Lp > 1;
         for (int pass = 0; pass < 2; ++pass) {
             a.kv_only = pass == 0; a.no_append = pass == 1;
-            if (pass == 1 && tiled) {
-                // attend: 4 prompt positions per block share their K/V reads
-                constexpr int P = 4;
-                const int nslot_p = 4 * (64 / (c.head_dim >> 3));
-                const size_t lds_p = ((size_t)P * G * c.head_dim + (size_t)nslot_p * G * 2 + (size_t)nslot_p * G * c.head_dim) * sizeof(float);
-                const dim3 gridp(c.n_local_heads, (Lp + P - 1) / P);
-                switch (G) {
-                    case 1: attn_prefill_kernel<bf16_t, 1, P, true><<<gridp, 256, lds_p, L.s>>>(a, Lp); break;
-                    case 2: attn_prefill_kernel<bf16_t, 2, P, true><<<gridp, 256, lds_p, L.s>>>(a, Lp); break;
-                    default: attn_prefill_kernel<bf16_t, 4, P, true><<<gridp, 256, lds_p, L.s>>>(a, Lp); break;
-                }
-                L.chk();
-                continue;
-            }
             const dim3 grid(c.n_local_heads, 1, Lp);
             switch (G) {
                 case 1: attn_decode_kernel<bf16_t, 1, true><<<grid, 256, lds, L.s>>>(a); break;

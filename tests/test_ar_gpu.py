@@ -216,27 +216,6 @@ def test_prefill_gemm_paths_vs_oracle(monkeypatch, Lp):
             assert _margin_ok(taps, 0, div[1], 0.03 * scale), (mode, div)
 
 
-@pytest.mark.parametrize("shape_fn,Lp", [(tiny_shape, 37), (medium_shape, 131)])
-def test_prefill_attention_tiles_equal_per_position_kernel(monkeypatch, shape_fn, Lp):
-    """The prompt-pass attention that shares K/V reads between 4 positions per block keeps the arithmetic of the
-    per-position kernel (FT_PREFILL_ATTN_V0): logits and first frame bit for bit."""
-    shape = shape_fn()
-    prompt = make_prompt(shape, Lp, seed=77, n_vq=4).numpy()
-    out = []
-    for v0 in (False, True):
-        if v0:
-            monkeypatch.setenv("FT_PREFILL_ATTN_V0", "1")
-        else:
-            monkeypatch.delenv("FT_PREFILL_ATTN_V0", raising=False)
-        eng, _ = make_pair(shape, "bf16", std=0.05 if shape_fn is medium_shape else None)
-        first = eng.prefill(prompt, eng._sampling(0.7, 1e-6, 1.0))
-        logits, hidden = eng.debug_state()
-        out.append((first.copy(), logits.copy(), hidden.copy()))
-        eng.close()
-    assert np.array_equal(out[0][0], out[1][0])
-    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
-
-
 def test_split_kv_attention_matches_single_block(monkeypatch):
     shape = tiny_shape()
     prompt = make_prompt(shape, 40, seed=4, n_vq=4).numpy()
