@@ -529,13 +529,48 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     }
 }
 
+// Merge of the split-KV partials of one head at 4 consecutive elements e..e+3: y = sum_s O_s w_s / sum_s l_s w_s,
+// w_s = exp(m_s - max m).  Splits are taken 8 at a time (all loads of a chunk issued before use); up to 8 splits this
+// is a single pass, beyond that the running (max, sum, acc) are rescaled per chunk.
+__device__ __forceinline__ void merge_splits4(const AttnP& a, size_t base, int e, float (&y)[4]) {
+    float M = -INFINITY, L = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int c0 = 0; c0 < a.nsplit; c0 += 8) {
+        float ms[8], ls[8];
+        float4 O[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const bool on = c0 + s < a.nsplit;
+            const size_t bi = base + (on ? c0 + s : 0);
+            ms[s] = on ? a.part_ml[bi * 2] : -INFINITY;
+            ls[s] = on ? a.part_ml[bi * 2 + 1] : 0.f;
+            O[s] = *reinterpret_cast<const float4*>(a.part_o + bi * a.hd + e);
+        }
+        float Mc = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) Mc = fmaxf(Mc, ms[s]);
+        if (!(Mc > -INFINITY)) continue;              // nothing visible in this chunk
+        const float Mn = fmaxf(M, Mc);
+        if (c0 > 0 && M > -INFINITY) {                // rescale what earlier chunks gathered
+            const float r = expf(M - Mn);
+            L *= r; a0 *= r; a1 *= r; a2 *= r; a3 *= r;
+        }
+        M = Mn;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float w = ms[s] > -INFINITY ? expf(ms[s] - M) : 0.f;
+            L += ls[s] * w;
+            a0 += O[s].x * w; a1 += O[s].y * w; a2 += O[s].z * w; a3 += O[s].w * w;
+        }
+    }
+    y[0] = a0 / L; y[1] = a1 / L; y[2] = a2 / L; y[3] = a3 / L;
+}
+
 // Wo GEMV (+ residual) whose input vector is assembled on the fly from the split-KV partials of
 // attn_decode_kernel: y[head][e] = sum_s O_s w_s / sum_s l_s w_s, w_s = exp(m_s - max m).  Saves the
 // separate combine launch; each lane merges only the 8 (4) consecutive elements it multiplies.
 template <typename WT, int NT, int R, bool ROUND>
 __global__ __launch_bounds__(256) void gemv_attn_combine_kernel(GemvP p, AttnP a) {
     extern __shared__ __attribute__((aligned(16))) float y_s[];  // [H*hd]
-    constexpr int MAXS = 8;  // nsplit <= 8 (engine enforces)
     const int tid = threadIdx.x, lane = tid & 63;
     const int row0 = (blockIdx.x * 4 + (tid >> 6)) * R;
     const int m = blockIdx.y;
@@ -545,28 +580,10 @@ __global__ __launch_bounds__(256) void gemv_attn_combine_kernel(GemvP p, AttnP a
     for (int k = 4 * tid; k < K; k += 1024) {   // 4 consecutive elements of one head per thread
         const int head = k / a.hd, e = k % a.hd;
         const size_t base = ((size_t)m * a.H + head) * a.nsplit;
-        float ms[MAXS], ls[MAXS];
-        float4 O[MAXS];
-#pragma unroll
-        for (int s = 0; s < MAXS; ++s) {  // every load issued before anything is consumed
-            const bool on = s < a.nsplit;
-            const size_t bi = base + (on ? s : 0);
-            ms[s] = on ? a.part_ml[bi * 2] : -INFINITY;
-            ls[s] = on ? a.part_ml[bi * 2 + 1] : 0.f;
-            O[s] = *reinterpret_cast<const float4*>(a.part_o + bi * a.hd + e);
-        }
-        float M = -INFINITY;
-#pragma unroll
-        for (int s = 0; s < MAXS; ++s) M = fmaxf(M, ms[s]);
-        float L = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-        for (int s = 0; s < MAXS; ++s) {
-            const float w = ms[s] > -INFINITY ? expf(ms[s] - M) : 0.f;
-            L += ls[s] * w;
-            a0 += O[s].x * w; a1 += O[s].y * w; a2 += O[s].z * w; a3 += O[s].w * w;
-        }
-        y_s[k] = rb<ROUND>(a0 / L); y_s[k + 1] = rb<ROUND>(a1 / L);
-        y_s[k + 2] = rb<ROUND>(a2 / L); y_s[k + 3] = rb<ROUND>(a3 / L);
+        float yv[4];
+        merge_splits4(a, base, e, yv);
+        y_s[k] = rb<ROUND>(yv[0]); y_s[k + 1] = rb<ROUND>(yv[1]);
+        y_s[k + 2] = rb<ROUND>(yv[2]); y_s[k + 3] = rb<ROUND>(yv[3]);
     }
     __syncthreads();
     if (row0 >= p.N) return;
@@ -581,33 +598,14 @@ __global__ __launch_bounds__(256) void gemv_attn_combine_kernel(GemvP p, AttnP a
 // cannot ride inside it).  Same arithmetic as above; writes the bf16 operand copy.  grid (M), 256 threads.
 template <bool ROUND>
 __global__ __launch_bounds__(256) void attn_combine_rows_kernel(AttnP a) {
-    constexpr int MAXS = 8;
     const int m = blockIdx.x, tid = threadIdx.x;
     const int K = a.H * a.hd;
     for (int k = 4 * tid; k < K; k += 1024) {
         const int head = k / a.hd, e = k % a.hd;
         const size_t base = ((size_t)m * a.H + head) * a.nsplit;
-        float ms[MAXS], ls[MAXS];
-        float4 O[MAXS];
-#pragma unroll
-        for (int s = 0; s < MAXS; ++s) {
-            const bool on = s < a.nsplit;
-            const size_t bi = base + (on ? s : 0);
-            ms[s] = on ? a.part_ml[bi * 2] : -INFINITY;
-            ls[s] = on ? a.part_ml[bi * 2 + 1] : 0.f;
-            O[s] = *reinterpret_cast<const float4*>(a.part_o + bi * a.hd + e);
-        }
-        float M = -INFINITY;
-#pragma unroll
-        for (int s = 0; s < MAXS; ++s) M = fmaxf(M, ms[s]);
-        float L = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-        for (int s = 0; s < MAXS; ++s) {
-            const float w = ms[s] > -INFINITY ? expf(ms[s] - M) : 0.f;
-            L += ls[s] * w;
-            a0 += O[s].x * w; a1 += O[s].y * w; a2 += O[s].z * w; a3 += O[s].w * w;
-        }
-        const float y0 = rb<ROUND>(a0 / L), y1 = rb<ROUND>(a1 / L), y2 = rb<ROUND>(a2 / L), y3 = rb<ROUND>(a3 / L);
+        float yv[4];
+        merge_splits4(a, base, e, yv);
+        const float y0 = rb<ROUND>(yv[0]), y1 = rb<ROUND>(yv[1]), y2 = rb<ROUND>(yv[2]), y3 = rb<ROUND>(yv[3]);
         float* y = a.y + (size_t)m * a.ldy + k;
         y[0] = y0; y[1] = y1; y[2] = y2; y[3] = y3;
         if (a.y_bf) {

@@ -60,6 +60,10 @@ struct ft_ctx {
           *femb = nullptr, *xf = nullptr, *qkvf = nullptr, *gf = nullptr, *flog = nullptr, *part_o = nullptr,
           *part_ml = nullptr;
     int n_slots = 0, nsplit = 1, cap = 0, fastV = 0, y_ld = 0;
+    // KV splits of the decode attention: nsplit is what the next enqueue uses; it follows the context length
+    // (8 up to 768 positions, 16 up to 3072, 32 beyond) unless FT_ATTN_NSPLIT pins it; buffers hold nsplit_max
+    int nsplit_max = 1;
+    bool nsplit_fixed = false;
     // MFMA prefill workspace (bf16 precision): S = max_seq_len rows
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_y = nullptr;
     ft::bf16_t *pf_xn = nullptr, *pf_ybf = nullptr, *pf_g = nullptr;

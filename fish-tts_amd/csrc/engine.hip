@@ -128,10 +128,13 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     ctx->n_slots = c.max_seq_len + ((8 - c.max_seq_len % 8) % 8);  // llama.py:387
     const char* ns = getenv("FT_ATTN_NSPLIT");
     ctx->nsplit = ns ? atoi(ns) : (ctx->n_slots > 512 ? 8 : 1);
+    ctx->nsplit_fixed = ns != nullptr;
+    ctx->nsplit_max = ctx->nsplit_fixed ? ctx->nsplit : (ctx->n_slots > 3072 ? 32 : ctx->n_slots > 768 ? 16 : ctx->nsplit);
     ctx->nt_weights = getenv("FT_NO_NT") ? 0 : 1;
     { const char* br = getenv("FT_BATCH_ROWS"); ctx->batch_rows = br ? atoi(br) : 4; }
     if (ctx->nsplit < 1) ctx->nsplit = 1;
-    if (ctx->nsplit > 8) ctx->nsplit = 8;
+    if (ctx->nsplit > 32) ctx->nsplit = 32;
+    ctx->nsplit_max = std::max(1, std::min(32, std::max(ctx->nsplit_max, ctx->nsplit)));
     ctx->cap = c.max_new_tokens + 24;
     ctx->fastV = c.codebook_size < 1024 ? c.codebook_size : 1024;  // inference.py:134
     const size_t qkvN = (size_t)(c.n_head + 2 * c.n_local_heads) * c.head_dim;
@@ -149,8 +152,8 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     FT_TRY(dmalloc(ctx, &ctx->qkvf, M * fqkvN));
     FT_TRY(dmalloc(ctx, &ctx->gf, M * c.fast_intermediate_size));
     FT_TRY(dmalloc(ctx, &ctx->flog, M * ctx->fastV));
-    FT_TRY(dmalloc(ctx, &ctx->part_o, M * c.n_head * ctx->nsplit * c.head_dim));
-    FT_TRY(dmalloc(ctx, &ctx->part_ml, M * c.n_head * ctx->nsplit * 2));
+    FT_TRY(dmalloc(ctx, &ctx->part_o, M * c.n_head * ctx->nsplit_max * c.head_dim));
+    FT_TRY(dmalloc(ctx, &ctx->part_ml, M * c.n_head * ctx->nsplit_max * 2));
     ctx->cache_m_stride = (size_t)c.n_local_heads * ctx->n_slots * c.head_dim;
     ctx->fcache_m_stride = (size_t)c.fast_n_local_heads * c.num_codebooks * c.fast_head_dim;
     ctx->layers.resize(c.n_layer);
@@ -1139,7 +1142,8 @@ extern "C" void ft_ar_kv_free(ft_ctx* ctx, ft_kv_snapshot* snap) {
 }
 
 static ft_status get_graph(ft_ctx* ctx, int M, hipGraphExec_t* out) {
-    auto it = ctx->graphs.find(M);
+    const int key = M * 64 + ctx->nsplit;   // the captured grids depend on the batch width and on the KV split count
+    auto it = ctx->graphs.find(key);
     if (it != ctx->graphs.end()) { *out = it->second; return FT_OK; }
     const int R = ctx->c.num_codebooks + 1;
     hipGraph_t graph = nullptr;
@@ -1156,7 +1160,7 @@ static ft_status get_graph(ft_ctx* ctx, int M, hipGraphExec_t* out) {
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     hipGraphDestroy(graph);
     if (e != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("graph instantiate: ") + hipGetErrorString(e));
-    ctx->graphs[M] = exec;
+    ctx->graphs[key] = exec;
     *out = exec;
     return FT_OK;
 }
@@ -1187,6 +1191,15 @@ extern "C" ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames,
         budget = std::min(budget, ctx->n_slots - h[nslots + m]);  // cache positions left
     }
     if (budget < 0) budget = 0;
+    if (!ctx->nsplit_fixed && ctx->nsplit_max > 1) {
+        // KV splits follow the longest context this call will reach (more blocks walking the cache in parallel)
+        int pos_end = 0;
+        for (int m = 0; m < nslots; ++m)
+            if (!h[2 * nslots + m]) pos_end = std::max(pos_end, h[nslots + m] + budget);
+        // measured at s1-mini shapes (tools/longctx_probe.py): 8 splits are fastest up to ~700 positions, 16 up to ~3000
+        const int want = pos_end <= 768 ? 8 : pos_end <= 3072 ? 16 : 32;
+        ctx->nsplit = std::min(want, ctx->nsplit_max);
+    }
     hipGraphExec_t exec = nullptr;
     const bool eager = getenv("FT_NO_GRAPH") != nullptr;
     if (!eager && budget > 0) FT_TRY(get_graph(ctx, nslots, &exec));

@@ -234,6 +234,28 @@ def test_split_kv_attention_matches_single_block(monkeypatch):
     assert np.max(np.abs(la - lb)) < 1e-4
 
 
+@pytest.mark.parametrize("Lp,want_splits", [(1000, 16), (3300, 32)])
+def test_kv_split_count_follows_context_length(monkeypatch, Lp, want_splits):
+    """Past 768 / 3072 cached positions the decode attention walks the cache with 16 / 32 splits instead of 8 (merged
+    8 at a time with a rescale): same tokens and logits (1e-4) as the pinned 8-split run."""
+    import dataclasses
+    shape = dataclasses.replace(tiny_shape(), max_seq_len=4096)
+    prompt = make_prompt(shape, Lp, seed=9, n_vq=5).numpy()
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    monkeypatch.delenv("FT_ATTN_NSPLIT", raising=False)
+    eng, _ = make_pair(shape, "fp32")
+    a = eng.generate(prompt, 12, **kw)
+    la, _ = eng.debug_state()
+    eng.close()
+    monkeypatch.setenv("FT_ATTN_NSPLIT", "8")
+    eng, _ = make_pair(shape, "fp32")
+    b = eng.generate(prompt, 12, **kw)
+    lb, _ = eng.debug_state()
+    eng.close()
+    assert np.array_equal(a, b), want_splits
+    assert np.max(np.abs(la - lb)) < 1e-4
+
+
 def test_lockstep_batch_equals_single(monkeypatch):
     shape = tiny_shape()
     kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
