@@ -363,6 +363,7 @@ struct AttnP {
     // for every position (kv_only), pass 2 attends reading every key from the cache (no_append)
     int row_is_pos, kv_only, no_append;
     bf16_t* y_bf;    // optional bf16 copy of y
+    bf16_t* q_out;   // kv_only pass: the normalised, rotated queries [row][H*hd] for the MFMA prompt attention
 };
 
 template <typename WT, int G, bool ROUND>
@@ -448,7 +449,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
             st_elem(vc, (size_t)pos * hd + e, v_new[e]);
         }
     }
-    if (p.kv_only) return;
+    if (p.kv_only) {
+        if (p.q_out)
+            for (int idx = tid; idx < G * hd; idx += 256)
+                p.q_out[(size_t)m * p.H * hd + (size_t)kvh * G * hd + idx] = f32_to_bf16_bits(q_s[idx]);
+        return;
+    }
 
     // phase 2: this block's share of the cached positions
     float qr[G][8];

@@ -358,6 +358,137 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
     else tapgemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, b, fr, fq);
 }
 
+// ---- prompt-pass attention on the matrix cores (llama.py:229-283 with the causal mask of 437) -----------------------
+// One block = 64 query positions of one query head (4 waves x 16 rows); K and V^T tiles of 32 cached positions are staged
+// in LDS once per block and shared by the waves.  S = Q K^T and O += P V run on v_mfma_f32_16x16x32_bf16; the softmax is
+// the online form in f32; P enters the second product as two bf16 planes (hi = bf16(p), lo = bf16(p - hi)), i.e. with
+// f32-like precision, so the result follows the f32 SDPA of the reference up to summation order (one rounding at the end).
+struct FlashP {
+    const bf16_t* q;    // [S][H*hd] normalised + rotated queries
+    const bf16_t* kc;   // [Hkv][n_slots][hd]
+    const bf16_t* vc;
+    bf16_t* y_bf;       // [S][H*hd]
+    int S, H, Hkv, hd, n_slots, pos0;
+    float scale;
+};
+template <int HD>
+__global__ __launch_bounds__(256) void flash_prefill_kernel(FlashP p) {
+    constexpr int KT = 32;                  // keys per tile
+    constexpr int LDK = HD + 8;             // K tile row stride (bf16)
+    constexpr int LDV = KT + 8;             // V^T tile row stride
+    constexpr int LDP = KT + 8;
+    constexpr int NS = HD / 32;             // k-steps of Q K^T
+    constexpr int NT = HD / 16;             // 16-wide output column tiles
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KT * LDK];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[HD * LDV];
+    __shared__ __attribute__((aligned(16))) bf16_t Ps[4][2][16 * LDP];
+    const int h = blockIdx.x, q0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int G = p.H / p.Hkv, kvh = h / G;
+    const bf16_t* kc = p.kc + (size_t)kvh * p.n_slots * HD;
+    const bf16_t* vc = p.vc + (size_t)kvh * p.n_slots * HD;
+    // Q fragments of this wave's 16 rows (A operand: row = lane & 15, 8 consecutive d per lane)
+    const int qrow = min(q0 + wave * 16 + fr, p.S - 1);
+    bf16x8 qf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        qf[s] = *reinterpret_cast<const bf16x8*>(p.q + (size_t)qrow * p.H * HD + (size_t)h * HD + s * 32 + fq * 8);
+    f32x4 O[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) O[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float mrun[4], lrun[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.f; }
+    const int last_row = min(q0 + 63, p.S - 1);
+    const int kmax = p.pos0 + last_row;                    // last visible key of the block
+    for (int kt = 0; kt <= kmax; kt += KT) {
+        __syncthreads();                                    // previous tile fully consumed
+        for (int c = tid; c < KT * (HD / 8); c += 256) {   // 16-byte pieces: key row, 8 dims
+            const int kr = c / (HD / 8), d8 = (c % (HD / 8)) * 8;
+            const int j = kt + kr;
+            U4 kv = U4{0u, 0u, 0u, 0u}, vv = U4{0u, 0u, 0u, 0u};
+            if (j <= kmax) {
+                kv = *reinterpret_cast<const U4*>(kc + (size_t)j * HD + d8);
+                vv = *reinterpret_cast<const U4*>(vc + (size_t)j * HD + d8);
+            }
+            *reinterpret_cast<U4*>(&Ks[kr * LDK + d8]) = kv;
+            const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Vt[(d8 + e) * LDV + kr] = ve[e];
+        }
+        __syncthreads();
+        // S = Q K^T for two 16-key sub-tiles: lane holds S[q = 4 fq + r][key = sub * 16 + fr]
+        f32x4 sc[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            sc[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(sub * 16 + fr) * LDK + s * 32 + fq * 8]);
+                sc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], kf, sc[sub], 0, 0, 0);
+            }
+        }
+        float pr[2][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qabs = p.pos0 + q0 + wave * 16 + fq * 4 + r;
+            float s0 = sc[0][r] * p.scale, s1 = sc[1][r] * p.scale;
+            if (kt + fr > qabs) s0 = -INFINITY;             // causal mask (also hides the zero padding of the last tile)
+            if (kt + 16 + fr > qabs) s1 = -INFINITY;
+            float mx = fmaxf(s0, s1);
+            mx = fmaxf(mx, dpp_f<DPP_XOR1>(mx));
+            mx = fmaxf(mx, dpp_f<DPP_XOR2>(mx));
+            mx = fmaxf(mx, dpp_f<DPP_HALF_MIRROR>(mx));
+            mx = fmaxf(mx, dpp_f<DPP_MIRROR>(mx));          // max over the row's 32 keys
+            const float mn = fmaxf(mrun[r], mx);
+            float corr = 1.f, p0 = 0.f, p1 = 0.f;
+            if (mn > -INFINITY) {                           // rows past the prompt end may see nothing yet
+                corr = expf(mrun[r] - mn);
+                p0 = expf(s0 - mn);
+                p1 = expf(s1 - mn);
+            }
+            mrun[r] = mn;
+            lrun[r] = lrun[r] * corr + (p0 + p1);           // per-lane share of the row sum, reduced at the end
+#pragma unroll
+            for (int t = 0; t < NT; ++t) O[t][r] *= corr;
+            pr[0][r] = p0; pr[1][r] = p1;
+        }
+        // P to the A-operand layout through this wave's LDS patch, split into two bf16 planes
+        bf16_t* Ph = Ps[wave][0];
+        bf16_t* Pl = Ps[wave][1];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = pr[sub][r];
+                const bf16_t hi = f32_to_bf16_bits(v);
+                const bf16_t lo = f32_to_bf16_bits(v - bf16_bits_to_f32(hi));
+                Ph[(fq * 4 + r) * LDP + sub * 16 + fr] = hi;
+                Pl[(fq * 4 + r) * LDP + sub * 16 + fr] = lo;
+            }
+        __syncthreads();
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ph[fr * LDP + fq * 8]);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Pl[fr * LDP + fq * 8]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[(t * 16 + fr) * LDV + fq * 8]);
+            O[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, vf, O[t], 0, 0, 0);
+            O[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, vf, O[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = q0 + wave * 16 + fq * 4 + r;
+        const float l = row16_sum(lrun[r]);
+        if (row < p.S) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                p.y_bf[(size_t)row * p.H * HD + (size_t)h * HD + t * 16 + fr] = f32_to_bf16_bits(O[t][r] / l);
+        }
+    }
+}
+
 // ---- skinny GEMM: few rows (prompt positions / lock-step utterances), weights streamed once ----------------------
 // out[t][n] = sum_k X[t][k] W[n][k] for M <= 16*TS rows per block column.  The problem is weight-bandwidth bound,
 // so the grid is cut along N only (16 weight rows per block => N/16 blocks) and the four waves of a block split K;

@@ -66,7 +66,7 @@ struct ft_ctx {
     bool nsplit_fixed = false;
     // MFMA prefill workspace (bf16 precision): S = max_seq_len rows
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_y = nullptr;
-    ft::bf16_t *pf_xn = nullptr, *pf_ybf = nullptr, *pf_g = nullptr;
+    ft::bf16_t *pf_xn = nullptr, *pf_ybf = nullptr, *pf_g = nullptr, *pf_qbf = nullptr;
     // lock-step batches of >= wide_min utterances run every Linear on the MFMA skinny kernel (bf16 operand copies)
     ft::bf16_t *mb_xn = nullptr, *mb_ybf = nullptr, *mb_g = nullptr;
     // fused RMSNorm of the wide path: exact bf16 copy of the residual stream + per-block partial sums of squares

@@ -186,6 +186,7 @@ static ft_status ar_alloc(ft_ctx* ctx) {
         FT_TRY(dmalloc(ctx, &ctx->pf_xn, S * c.dim));
         FT_TRY(dmalloc(ctx, &ctx->pf_ybf, S * c.n_head * c.head_dim));
         FT_TRY(dmalloc(ctx, &ctx->pf_g, S * c.intermediate_size));
+        FT_TRY(dmalloc(ctx, &ctx->pf_qbf, S * c.n_head * c.head_dim));
         // wide lock-step batches: no fast-layer f32 bias copies exist, and the fast widths must fit the MFMA tiles
         ctx->wide_ok = !getenv("FT_NO_WIDE") && !c.fast_attention_qkv_bias && !c.fast_attention_o_bias &&
                        c.fast_dim % 32 == 0 && (c.fast_n_head * c.fast_head_dim) % 32 == 0 && c.fast_intermediate_size % 32 == 0;
@@ -274,7 +275,7 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     int* ibufs[] = {ctx->d_pos, ctx->d_tok, ctx->d_tokn, ctx->d_seq, ctx->d_nf, ctx->d_done, ctx->d_prompt};
     for (int* b : ibufs) if (b) hipFree(b);
     if (ctx->d_ctl) hipFree(ctx->d_ctl);
-    { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g, ctx->mb_xn, ctx->mb_ybf, ctx->mb_g, ctx->mb_xb, ctx->mb_ss}; for (void* q : pf) if (q) hipFree(q); }
+    { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g, ctx->mb_xn, ctx->mb_ybf, ctx->mb_g, ctx->mb_xb, ctx->mb_ss, ctx->pf_qbf}; for (void* q : pf) if (q) hipFree(q); }
     for (auto& l : ctx->layers) { if (l.bqkv_f32) hipFree(l.bqkv_f32); if (l.bo_f32) hipFree(l.bo_f32); }
     if (ctx->samp_hist) hipFree(ctx->samp_hist);
     if (ctx->samp_cut) hipFree(ctx->samp_cut);
@@ -1013,8 +1014,21 @@ static void prefill_gemm(Launch& L, int slot, int Lp, int pos0) {
         a.eps = c.norm_eps; a.scale = 1.0f / sqrtf((float)c.head_dim); a.y = ctx->pf_y; a.ldy = HD; a.y_bf = ctx->pf_ybf;
         Launch LA = L;
         LA.M = Lp;
+        // pass 0 appends K/V of every position (and leaves the finished queries); pass 1 attends: on the matrix cores
+        // for 64- and 128-wide heads, otherwise position by position with the decode kernel
+        const bool flash = !getenv("FT_PREFILL_ATTN_V0") && (c.head_dim == 64 || c.head_dim == 128) && Lp > 1;
+        a.q_out = flash ? ctx->pf_qbf : nullptr;
         for (int pass = 0; pass < 2; ++pass) {
             a.kv_only = pass == 0; a.no_append = pass == 1;
+            if (pass == 1 && flash) {
+                FlashP fp{ctx->pf_qbf, (const bf16_t*)a.kc, (const bf16_t*)a.vc, ctx->pf_ybf, Lp, c.n_head, c.n_local_heads,
+                          c.head_dim, ctx->n_slots, pos0, a.scale};
+                const dim3 gridf(c.n_head, (Lp + 63) / 64);
+                if (c.head_dim == 128) flash_prefill_kernel<128><<<gridf, 256, 0, L.s>>>(fp);
+                else flash_prefill_kernel<64><<<gridf, 256, 0, L.s>>>(fp);
+                L.chk();
+                continue;
+            }
             const dim3 grid(c.n_local_heads, 1, Lp);
             switch (G) {
                 case 1: attn_decode_kernel<bf16_t, 1, true><<<grid, 256, lds, L.s>>>(a); break;

@@ -183,7 +183,8 @@ def test_s1mini_shapes_greedy_vs_reference_golden():
 @pytest.mark.parametrize("Lp", [12, 40, 100, 200, 700, 1100])
 def test_prefill_gemm_paths_vs_oracle(monkeypatch, Lp):
     """The S = Lp prompt pass (skinny split-K MFMA kernel for Lp <= 128, pipelined tile kernel above, first tile
-    kernel with FT_PREFILL_GEMM=0, position-by-position decode kernels with FT_PREFILL_V0) all reproduce the oracle's
+    kernel with FT_PREFILL_GEMM=0, MFMA flash attention or, with FT_PREFILL_ATTN_V0, the per-position attention kernel;
+    position-by-position decode kernels for everything with FT_PREFILL_V0) all reproduce the oracle's
     frame-0 logits within the bf16 evaluation-order tolerance, and pick the oracle's first frame unless the oracle's
     own top-2 margin is inside that tolerance."""
     shape = medium_shape(max_seq_len=2048)   # 700 = a 30 s voice-cloning reference; 1100 reaches the 128x128 tiles
@@ -193,8 +194,8 @@ def test_prefill_gemm_paths_vs_oracle(monkeypatch, Lp):
     orc = None
     results = {}
     for mode, env in [("default", {}), ("tile64", {"FT_PREFILL_GEMM": "1"}), ("tile_v0", {"FT_PREFILL_GEMM": "0"}),
-                      ("per_position", {"FT_PREFILL_V0": "1"})]:
-        for k in ("FT_PREFILL_GEMM", "FT_PREFILL_V0"):
+                      ("attention_per_position", {"FT_PREFILL_ATTN_V0": "1"}), ("per_position", {"FT_PREFILL_V0": "1"})]:
+        for k in ("FT_PREFILL_GEMM", "FT_PREFILL_V0", "FT_PREFILL_ATTN_V0"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
