@@ -415,6 +415,28 @@ def test_prompt_too_long_raises():
     eng.close()
 
 
+def test_generation_is_clamped_to_the_cache_like_the_reference():
+    """inference.py:296-308: a prompt that nearly fills max_seq_len gets max_seq_len - T new columns at most, and
+    max_new_tokens = 0 means "until the cache is full"; batch and streaming variants against the oracle."""
+    import dataclasses
+    shape = dataclasses.replace(tiny_shape(), max_seq_len=64)
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    eng, orc = make_pair(shape, "fp32", max_new_tokens=80)
+    for T, ask in ((57, 30), (40, 0), (63, 5)):
+        prompt = make_prompt(shape, T, seed=40 + T, n_vq=3)
+        want = orc.generate(prompt.clone(), ask, **kw).numpy()
+        got = eng.generate(prompt.numpy(), ask, **kw)
+        assert got.shape[1] <= shape.max_seq_len and np.array_equal(got, want), (T, ask, got.shape, want.shape)
+        orc.reset()
+        cols = torch.cat(list(orc.generate_stream(prompt.clone(), ask, **kw)), dim=1).numpy()
+        blocks = np.concatenate(list(eng.generate_streaming(prompt.numpy(), ask, chunk=3, **kw)), axis=1)
+        assert np.array_equal(blocks, cols), (T, ask)
+        orc.reset()
+    with pytest.raises(Exception, match="empty prompt|bad argument"):
+        eng.prefill(np.zeros((11, 0), dtype=np.int32), eng._sampling(0.7, 0.7, 1.0))
+    eng.close()
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_sampling_kernel_vs_oracle(precision):
     """The sampling kernel alone, on identical logits and identical Exp(1) noise, against
