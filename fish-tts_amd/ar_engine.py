@@ -146,6 +146,30 @@ class ARHipEngine:
                                               C.byref(sampling), out.ctypes.data_as(C.c_void_p)), "ft_ar_prefill")
         return out
 
+    def prefill_many(self, prompts: Sequence[np.ndarray], samplings: Sequence[L.ft_sampling], slot0: int = 0,
+                     prefixes: Optional[Sequence[Optional["KVPrefix"]]] = None) -> np.ndarray:
+        """Prompts of the contiguous slots [slot0, slot0 + n): each prompt pass on its own, then every first frame in
+        one lock-step pass (a scheduler's initial fill).  Returns (n, R) first frames."""
+        n = len(prompts)
+        next_pos = np.zeros(n, dtype=np.int32)
+        for i, prompt in enumerate(prompts):
+            prompt = np.ascontiguousarray(prompt, dtype=np.int32)
+            assert prompt.ndim == 2 and prompt.shape[0] == self.R, prompt.shape
+            pf = prefixes[i] if prefixes is not None else None
+            pos0 = 0
+            if pf is not None:
+                assert 0 < pf.n_pos < prompt.shape[1], (pf.n_pos, prompt.shape)
+                self.kv_restore(pf, slot0 + i)
+                pos0, prompt = pf.n_pos, np.ascontiguousarray(prompt[:, pf.n_pos:])
+            self._check(self.lib.ft_ar_prefill_slow(self._h, slot0 + i, prompt.ctypes.data_as(C.c_void_p), prompt.shape[1],
+                                                    pos0), "ft_ar_prefill")
+            next_pos[i] = pos0 + prompt.shape[1]
+        arr = (L.ft_sampling * n)(*samplings)
+        out = np.zeros((n, self.R), dtype=np.int32)
+        self._check(self.lib.ft_ar_first_frames(self._h, slot0, n, arr, next_pos.ctypes.data_as(C.c_void_p),
+                                                out.ctypes.data_as(C.c_void_p)), "ft_ar_first_frames")
+        return out
+
     def park(self, slot: int) -> None:
         """Marks a slot idle (finished) for lock-step decoding until its next prefill."""
         self._check(self.lib.ft_ar_park(self._h, slot), "ft_ar_park")

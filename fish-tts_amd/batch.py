@@ -81,8 +81,25 @@ def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int =
             engine.park(slot)
             parked[slot] = True
 
-    for s in range(B):
-        fill(s)
+    # initial fill: the prompt passes one by one, the first frames of all slots in one lock-step pass
+    n0 = min(B, len(waiting))
+    if n0 > 1:
+        first_ids = [waiting.popleft() for _ in range(n0)]
+        us = [utterances[i] for i in first_ids]
+        sp0 = [engine._sampling(u.temperature, u.top_p, u.repetition_penalty, u.seed, u.ban_eos) for u in us]
+        firsts = engine.prefill_many([u.prompt for u in us], sp0, 0, [u.prefix for u in us])
+        for s, (i, u) in enumerate(zip(first_ids, us)):
+            n_new = engine._clamp_new(u.prompt.shape[1], u.max_new_tokens)
+            emit(i, firsts[s][:, None])
+            if n_new <= 1 or firsts[s][0] == engine.im_end_id:
+                fill(s)                                   # done at its first frame: the slot takes the next one
+            else:
+                owner[s], budget[s], sps[s] = i, n_new - 1, sp0[s]
+        for s in range(n0, B):
+            fill(s)
+    else:
+        for s in range(B):
+            fill(s)
     while True:
         active = [s for s in range(B) if owner[s] is not None]
         if not active:

@@ -989,7 +989,7 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
     L.chk();
 }
 
-static void prefill_gemm(Launch& L, int slot, int Lp, int pos0) {
+static void prefill_gemm(Launch& L, int slot, int Lp, int pos0, bool with_tail = true) {
     ft_ctx* ctx = L.ctx;
     const ft_ar_config& c = ctx->c;
     const int D = c.dim, HD = c.n_head * c.head_dim, F = c.intermediate_size;
@@ -1050,6 +1050,7 @@ static void prefill_gemm(Launch& L, int slot, int Lp, int pos0) {
     }
     // the last position feeds the head and the fast stack through the decode kernels
     hipMemcpyAsync(ctx->x + (size_t)slot * D, ctx->pf_x + (size_t)(Lp - 1) * D, D * sizeof(float), hipMemcpyDeviceToDevice, L.s);
+    if (!with_tail) return;   // ft_ar_prefill_slow: the first frames of several slots are drawn together later
     enqueue_fproj<bf16_t, true>(L);
     enqueue_frame_tail<bf16_t, true>(L);
 }
@@ -1089,6 +1090,56 @@ extern "C" ft_status ft_ar_prefill_at(ft_ctx* ctx, int32_t slot, const int32_t* 
     ctx->h_pin[0] = pos0 + Lp;
     FT_HIP(ctx, hipMemcpyAsync(ctx->d_pos + slot, ctx->h_pin, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     FT_HIP(ctx, hipMemcpyAsync(out_frame, ctx->d_tok + (size_t)slot * R, R * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FT_OK;
+}
+
+// Prompt pass without the first frame: K/V of the prompt and the last position's hidden state stay on the device.
+extern "C" ft_status ft_ar_prefill_slow(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_t Lp, int32_t pos0) {
+    FT_TRY(ar_ready(ctx));
+    const ft_ar_config& c = ctx->c;
+    if (!prompt) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill_slow: null argument");
+    if (slot < 0 || slot >= c.max_batch) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill_slow: bad slot");
+    if (Lp < 1 || pos0 < 0) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill_slow: empty prompt");
+    if (pos0 + Lp >= c.max_seq_len) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "Input sequence length %d exceeds max_seq_len %d", pos0 + Lp, c.max_seq_len);
+        return ft_fail(ctx, FT_ERR_TOO_LONG, buf);
+    }
+    const int R = c.num_codebooks + 1;
+    FT_TRY(ft_ar_reset(ctx, slot));
+    FT_HIP(ctx, hipMemcpyAsync(ctx->d_prompt, prompt, (size_t)R * Lp * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    Launch L{ctx, ctx->stream, slot, 1, 0};
+    if (!ctx->prefill_v0) {
+        prefill_gemm(L, slot, Lp, pos0, false);
+    } else {
+        for (int t = 0; t < Lp; ++t) {
+            L.pos_off = pos0 + t;
+            enqueue_slow_only(L, ctx->d_prompt, Lp, 0, t);
+        }
+    }
+    if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("prefill launch: ") + hipGetErrorString(L.err));
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // d_prompt is reused by the next call
+    return FT_OK;
+}
+
+// First frames of slots [slot0, slot0 + n) whose prompts went through ft_ar_prefill_slow: one lock-step pass of the
+// vocabulary head, the semantic draw and the fast codebooks over all of them.
+extern "C" ft_status ft_ar_first_frames(ft_ctx* ctx, int32_t slot0, int32_t n, const ft_sampling* sp, const int32_t* next_pos,
+                                        int32_t* out_frames) {
+    FT_TRY(ar_ready(ctx));
+    const ft_ar_config& c = ctx->c;
+    if (!sp || !next_pos || !out_frames) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_first_frames: null argument");
+    if (slot0 < 0 || n < 1 || slot0 + n > c.max_batch) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_first_frames: bad slot range");
+    const int R = c.num_codebooks + 1;
+    FT_TRY(upload_ctl(ctx, slot0, n, sp));
+    Launch L{ctx, ctx->stream, slot0, n, 0};
+    if (c.dtype == FT_BF16) { enqueue_fproj<bf16_t, true>(L); enqueue_frame_tail<bf16_t, true>(L); }
+    else { enqueue_fproj<float, false>(L); enqueue_frame_tail<float, false>(L); }
+    if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("first-frame launch: ") + hipGetErrorString(L.err));
+    // finalize() advanced every position 0 -> 1; the next input position of a slot is the end of its prompt
+    FT_HIP(ctx, hipMemcpyAsync(ctx->d_pos + slot0, next_pos, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    FT_HIP(ctx, hipMemcpyAsync(out_frames, ctx->d_tok + (size_t)slot0 * R, (size_t)n * R * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FT_OK;
 }

@@ -95,6 +95,13 @@ ft_status ft_ar_reset(ft_ctx* ctx, int32_t slot);
  * generated frame (num_codebooks+1 int32) to out_frame (host).  No repetition penalty. */
 ft_status ft_ar_prefill(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_t Lp,
                         const ft_sampling* sp, int32_t* out_frame);
+/* Several prompts at once (a batch scheduler's initial fill): ft_ar_prefill_slow runs the prompt pass of one slot
+ * without its first frame (K/V + last hidden state stay on the device); ft_ar_first_frames then draws the first frames
+ * of the contiguous slots [slot0, slot0+n) in one lock-step pass (head, semantic draw, fast codebooks) - the per-slot
+ * equivalent is ft_ar_prefill_at.  next_pos[i] = pos0_i + Lp_i; out_frames: n x (num_codebooks+1) int32 (host). */
+ft_status ft_ar_prefill_slow(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_t Lp, int32_t pos0);
+ft_status ft_ar_first_frames(ft_ctx* ctx, int32_t slot0, int32_t n, const ft_sampling* sp, const int32_t* next_pos,
+                             int32_t* out_frames);
 /* Marks a slot idle for lock-step decoding: it counts as already finished (ft_ar_decode reports 0 frames for
  * it and it limits nothing); a later ft_ar_prefill[_at] on the slot re-activates it.  Slots that emit
  * <|im_end|> freeze the same way on the device, so a host scheduler can refill finished slots between
