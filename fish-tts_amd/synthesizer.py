@@ -269,20 +269,33 @@ class FishTTS:
     def synthesize_stream(self, text: str, references: Optional[List[VoiceProfile]] = None, chunk_tokens: int = 20,
                           min_first_chunk: int = 10, **kwargs) -> Iterator[bytes]:
         """Streaming synthesis: AR generation on this thread, codec decode on a worker thread with two bounded
-        queues; each chunk is decoded independently from zero context (synthesizer.py:483-584)."""
+        queues; each chunk is decoded independently from zero context (synthesizer.py:483-584).
+
+        Extension `seamless=True` (keyword): the codec is strictly causal, so decoding all codes so far and emitting only
+        the new samples yields exactly the waveform of the non-streaming decode - no restart artefacts at chunk
+        boundaries (the stateful streaming decode of SURVEY.md §8-f F4, done by recomputation: a 10 s utterance in
+        20-frame chunks costs ~40 ms of extra codec time in total)."""
         from .generation import generate_long
+        seamless = bool(kwargs.get("seamless", False))
         prompt_text, prompt_tokens = self._get_prompt_data(references)
         codes_queue: "queue.Queue" = queue.Queue(maxsize=3)
         audio_queue: "queue.Queue" = queue.Queue(maxsize=3)
         error_holder: List[Exception] = []
 
         def decoder_worker():
+            history, emitted = [], 0
             try:
                 while True:
                     codes = codes_queue.get()
                     if codes is None:
                         break
-                    audio_queue.put(self._decode_to_pcm(codes))
+                    if not seamless:
+                        audio_queue.put(self._decode_to_pcm(codes))
+                        continue
+                    history.append(codes)
+                    pcm = self._decode_to_pcm(np.concatenate(history, axis=1))   # prefix decode == prefix of the decode
+                    audio_queue.put(pcm[emitted:])
+                    emitted = len(pcm)
             except Exception as e:  # noqa: BLE001
                 error_holder.append(e)
             finally:

@@ -1,5 +1,5 @@
 /* libfishtts_hip.so — C ABI of the MI355X (gfx950) hot path: dual-AR semantic-token decode +
- * DAC codec decode.  Plain pointers and sizes only; no torch types.
+ * DAC codec decode (and encode, for encode_reference).  Plain pointers and sizes only; no torch types.
  *
  * The reference (smolGura/fish-tts) is pure Python and has no FFI; the seams this library
  * sits behind are the Python-level operators named in SURVEY.md §8(b).  Each entry point

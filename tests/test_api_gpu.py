@@ -215,3 +215,18 @@ def test_model_directory_in_reference_layout(tmp_path):
             synth.synthesize("Hi there", max_tokens=4)
     finally:
         synth._engine.close()
+
+
+def test_seamless_stream_equals_the_full_decode(tts):
+    """synthesize_stream(seamless=True): the chunks, concatenated, are exactly the PCM of decoding the whole code
+    sequence at once (strict causality of the codec), unlike the reference's independent chunk decodes."""
+    synth, tok, orc, corc, shape, cshape = tts
+    from fish_tts_amd.generation import generate_long
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    chunks = list(synth.synthesize_stream("Hi there", chunk_tokens=6, min_first_chunk=3, max_tokens=20, seamless=True, **kw))
+    codes = np.concatenate([r.codes for r in generate_long(engine=synth._engine, tokenizer=tok, text="Hi there",
+                                                           max_new_tokens=20, streaming=True, **kw) if r.action == "sample"], axis=1)
+    whole = synth._decode_to_pcm(codes)
+    assert b"".join(chunks) == whole
+    plain = list(synth.synthesize_stream("Hi there", chunk_tokens=6, min_first_chunk=3, max_tokens=20, **kw))
+    assert [len(c) for c in plain] == [len(c) for c in chunks] and b"".join(plain) != whole
