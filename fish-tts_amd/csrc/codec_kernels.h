@@ -402,22 +402,37 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashP p) {
     for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.f; }
     const int last_row = min(q0 + 63, p.S - 1);
     const int kmax = p.pos0 + last_row;                    // last visible key of the block
-    for (int kt = 0; kt <= kmax; kt += KT) {
-        __syncthreads();                                    // previous tile fully consumed
-        for (int c = tid; c < KT * (HD / 8); c += 256) {   // 16-byte pieces: key row, 8 dims
+    // K/V rows of a tile travel in registers one tile ahead of their use (global loads overlap the MFMAs of the
+    // previous tile); each thread owns CPT 16-byte pieces of the [KT][HD] tile
+    constexpr int CPT = KT * (HD / 8) / 256;
+    U4 kreg[CPT], vreg[CPT];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + i * 256;
             const int kr = c / (HD / 8), d8 = (c % (HD / 8)) * 8;
             const int j = kt + kr;
-            U4 kv = U4{0u, 0u, 0u, 0u}, vv = U4{0u, 0u, 0u, 0u};
+            kreg[i] = U4{0u, 0u, 0u, 0u}; vreg[i] = U4{0u, 0u, 0u, 0u};
             if (j <= kmax) {
-                kv = *reinterpret_cast<const U4*>(kc + (size_t)j * HD + d8);
-                vv = *reinterpret_cast<const U4*>(vc + (size_t)j * HD + d8);
+                kreg[i] = *reinterpret_cast<const U4*>(kc + (size_t)j * HD + d8);
+                vreg[i] = *reinterpret_cast<const U4*>(vc + (size_t)j * HD + d8);
             }
-            *reinterpret_cast<U4*>(&Ks[kr * LDK + d8]) = kv;
-            const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv);
+        }
+    };
+    fetch(0);
+    for (int kt = 0; kt <= kmax; kt += KT) {
+        __syncthreads();                                    // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + i * 256;
+            const int kr = c / (HD / 8), d8 = (c % (HD / 8)) * 8;
+            *reinterpret_cast<U4*>(&Ks[kr * LDK + d8]) = kreg[i];
+            const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vreg[i]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) Vt[(d8 + e) * LDV + kr] = ve[e];
         }
         __syncthreads();
+        if (kt + KT <= kmax) fetch(kt + KT);
         // S = Q K^T for two 16-key sub-tiles: lane holds S[q = 4 fq + r][key = sub * 16 + fr]
         f32x4 sc[2];
 #pragma unroll

@@ -41,8 +41,36 @@ def pmc(src, counter, dst):
     print("wrote", dst)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and sys.argv[1] != "mfma":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])
+
+
+def mfma(src, dst):
+    """MFMA utilisation per kernel from one --pmc pass of SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE:
+    util = MFMA-busy cycles / (kernel cycles x 1024 SIMDs); GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
+    f = glob.glob(src + "/**/*_counter_collection.csv", recursive=True)[0]
+    agg = defaultdict(lambda: defaultdict(float))
+    n = defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            n[r["Kernel_Name"]] += 1
+    rows = []
+    for k, c in agg.items():
+        busy, act = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("GRBM_GUI_ACTIVE", 0.0)
+        if busy <= 0 or act <= 0:
+            continue
+        cyc = act / 8.0
+        rows.append((k, n[k], busy, cyc, busy / (cyc * 1024.0)))
+    with open(dst, "w") as o:
+        o.write("| kernel | dispatches | MFMA-busy cycles (all SIMDs) | kernel cycles | MFMA utilisation | dense-bf16 TFLOP/s equivalent |\n|---|---|---|---|---|---|\n")
+        for k, nn, busy, cyc, u in sorted(rows, key=lambda r: -r[2]):
+            o.write(f"| `{k[:80]}` | {nn} | {busy:.3g} | {cyc:.3g} | {100 * u:.1f} % | {2500 * u:.0f} |\n")
+    print("wrote", dst)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "mfma":
+    mfma(sys.argv[2], sys.argv[3])
