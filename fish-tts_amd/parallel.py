@@ -52,3 +52,23 @@ def deal_utterances(lengths: Sequence[int], world: int) -> List[List[int]]:
         out[r].append(i)
         loads[r] += lengths[i]
     return out
+
+
+def synthesize_sharded(tts, texts: Sequence[str], dst: int = 0, **kw):
+    """BASELINE configs[3] (a large batch across the GPUs of one node): every rank (one process per GPU, its own
+    `FishTTS(max_batch=...)`) synthesises the share `deal_utterances` gives it - texts dealt by length, longest first -
+    in its own lock-step batch; rank `dst` receives the WAV bytes of all texts in input order (others get None).  The
+    only communication is the final gather of results; nothing crosses GPUs while decoding."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    share = deal_utterances([len(t) for t in texts], world)[rank]
+    wavs = tts.synthesize_batch([texts[i] for i in share], seed=kw.pop("seed", 0) + (share[0] if share else 0), **kw) if share else []
+    gathered = [None] * world if rank == dst else None
+    dist.gather_object(list(zip(share, wavs)), gathered, dst=dst)
+    if rank != dst:
+        return None
+    out = [None] * len(texts)
+    for part in gathered:
+        for i, w in part:
+            out[i] = w
+    return out

@@ -35,7 +35,19 @@ def _worker(rank, world, port, q):
     ref = random_state_dict(args, seed=0, dtype=torch.float32)
     ok = all(torch.equal(got[k], ref[k]) for k in ref) and set(got) == set(ref)
     mine = deal_utterances([5, 9, 3, 7], world)[rank]
-    q.put((rank, ok, mine))
+
+    class FakeTTS:   # stands in for FishTTS(max_batch=...) on a GPU: records what this rank was asked to speak
+        def synthesize_batch(self, texts, seed=0, **kw):
+            return [f"rank{rank}:{t}".encode() for t in texts]
+    from fish_tts_amd.parallel import synthesize_sharded
+    texts = ["bb", "a", "dddd", "ccc", "eeeee"]
+    wavs = synthesize_sharded(FakeTTS(), texts, dst=0)
+    sharded_ok = True
+    if rank == 0:
+        sharded_ok = [w.split(b":")[1].decode() for w in wavs] == texts and len({w.split(b":")[0] for w in wavs}) == world
+    else:
+        sharded_ok = wavs is None
+    q.put((rank, ok and sharded_ok, mine))
     dist.barrier()
     dist.destroy_process_group()
 
