@@ -311,17 +311,31 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
         }
     };
     const int nsteps = p.ntap * (p.K / BK);
+    const int nchunks = p.K / BK;
+    // the A stripe of the NEXT K chunk also travels in registers while this chunk's taps run (with one tap - linears,
+    // 1x1 convs, the prompt GEMMs - its load latency would otherwise be exposed once per step)
+    constexpr int ACH = ((BM + MAXH) * QPR + 255) / 256;
+    U4 areg[ACH];
+    auto load_a = [&](int kc) {
+#pragma unroll
+        for (int u = 0; u < ACH; ++u) {
+            const int c = tid + 256 * u, r = c / QPR, q = c % QPR;
+            const int t = m0 + offmin + r;
+            areg[u] = (c < srows * QPR && t >= 0 && t < p.T_in)
+                          ? *reinterpret_cast<const U4*>(X + (size_t)t * p.ldx + kc * BK + q * 8) : U4{0u, 0u, 0u, 0u};
+        }
+    };
+    load_a(0);
     auto do_step = [&](int step, U4 (&breg)[BCH], bf16_t* Bcur) {
         const int kc = step / p.ntap, tap = step % p.ntap;
         if (tap == 0) {
             // previous chunk's MFMAs are done (barrier at the end of its last step): restage the A stripe
-            for (int c = tid; c < srows * QPR; c += 256) {
-                const int r = c / QPR, q = c % QPR;
-                const int t = m0 + offmin + r;
-                U4 v = U4{0u, 0u, 0u, 0u};
-                if (t >= 0 && t < p.T_in) v = *reinterpret_cast<const U4*>(X + (size_t)t * p.ldx + kc * BK + q * 8);
-                *reinterpret_cast<U4*>(&As[r * LD + q * 8]) = v;
+#pragma unroll
+            for (int u = 0; u < ACH; ++u) {
+                const int c = tid + 256 * u, r = c / QPR, q = c % QPR;
+                if (c < srows * QPR) *reinterpret_cast<U4*>(&As[r * LD + q * 8]) = areg[u];
             }
+            if (kc + 1 < nchunks) load_a(kc + 1);
         }
         store_b(breg, Bcur);
         __syncthreads();
