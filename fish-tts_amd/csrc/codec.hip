@@ -532,7 +532,8 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
         // 64-row tiles everywhere: the 128x128 instantiation spills registers and, at these sizes, leaves CUs idle
         // (215-frame decode 9.9 -> 6.2 ms); FT_CODEC_BIG_M=<rows> restores the wide tiles above that many rows
         static const long big_thr = getenv("FT_CODEC_BIG_M") ? atol(getenv("FT_CODEC_BIG_M")) : (1L << 60);
-        const bool small_m = io.M <= big_thr;
+        const bool vec_ok = io.act != ACT_SWIGLU && w.N % 8 == 0 && w.n_mod % 8 == 0 && io.ldo % 8 == 0 && io.ldr % 8 == 0;
+        const bool small_m = io.M <= big_thr || !vec_ok;   // the 128x128 tile has the vector epilogue only
         const bool k64 = w.K % 64 == 0;
         if (w.N % 128 == 0 || (w.N % 96 != 0 && w.N > 96)) {
             if (small_m) { if (k64) FT_TG(64, 64, 64); else FT_TG(64, 64, 32); }

@@ -368,8 +368,14 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
     }
     // vector epilogue whenever rows are 16-byte addressable (every real layer); SwiGLU pairs keep the lane epilogue
     const bool vec_ok = p.act != ACT_SWIGLU && (p.N % 8) == 0 && (p.n_mod % 8) == 0 && (p.ldo % 8) == 0 && (p.ldr % 8) == 0;
-    if (vec_ok) tapgemm_epilogue_lds<BM, BN, TM, TN>(p, acc, reinterpret_cast<float*>(lds), m0, n0, b, wm, wn, fr, fq);
-    else tapgemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, b, fr, fq);
+    if constexpr (TM * TN >= 16) {
+        // 128x128: instantiating the lane epilogue here makes the compiler keep all 16 accumulator tiles in scratch for
+        // the whole kernel (272 B/lane); the host selects this tile only for layers the vector epilogue covers
+        tapgemm_epilogue_lds<BM, BN, TM, TN>(p, acc, reinterpret_cast<float*>(lds), m0, n0, b, wm, wn, fr, fq);
+    } else {
+        if (vec_ok) tapgemm_epilogue_lds<BM, BN, TM, TN>(p, acc, reinterpret_cast<float*>(lds), m0, n0, b, wm, wn, fr, fq);
+        else tapgemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, b, fr, fq);
+    }
 }
 
 // ---- prompt-pass attention on the matrix cores (llama.py:229-283 with the causal mask of 437) -----------------------
