@@ -74,7 +74,7 @@ struct ft_ctx {
     float* mb_ss = nullptr;   // [max(dim, fast_dim) / 16][max_batch]
     bool wide_fuse = false;
     int wide_fuse_max = 16;   // largest lock-step batch that takes the fused-norm GEMMs
-    int wide_min = 8;
+    int wide_min = 5;   // measured: the MFMA path wins from 5 rows (B=5: 2.79 vs 3.33 ms per frame), B <= 4 keeps the bit-exact multi-row GEMV
     bool wide_ok = false;
     bool prefill_v0 = false;
     int prefill_gemm_mode = 2;
