@@ -531,11 +531,23 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashP p) {
 // the four partial tiles meet in LDS and are summed in wave order (deterministic).  Epilogue = the nn.Linear
 // rounding points of the prefill (bias, rounded; residual add, rounded; SwiGLU on interleaved (gate, up) rows).
 // Requires K % 128 == 0; act in {ACT_NONE, ACT_SWIGLU}; ntap == 1.
-template <int TS, int NW, bool NORM>
+// XLDS: the X rows reach the MFMA operand registers through a per-wave LDS patch - loaded in full 256-byte row pieces
+// (4 rows per load instruction) and re-read fragment-shaped with ds_read_b128 - instead of 16 rows x 64 bytes per load
+// instruction straight from L2 (the per-CU address path was the limit of that form: tools/mb_skinny.hip).
+constexpr int SKINNY_LDX = 136;   // LDS row stride of an X chunk (128 k + 8 pad, bf16): fragment reads spread over the banks
+template <int TS, int NW>
+constexpr size_t skinny_lds_bytes(bool xlds) {
+    const size_t cs = (size_t)NW * TS * 16 * 17 * sizeof(float);
+    const size_t xs = xlds ? (size_t)NW * TS * 16 * SKINNY_LDX * 2 : 0;
+    return TS * 16 * sizeof(float) + (cs > xs ? cs : xs);
+}
+template <int TS, int NW, bool NORM, bool XLDS>
 __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(TapGemmP p) {
     constexpr int CH = 4;                          // k-steps (of 32) per register chunk
-    __shared__ float Cs[NW][TS * 16][17];
-    __shared__ float inv_s[TS * 16];
+    extern __shared__ __attribute__((aligned(16))) unsigned char skinny_smem[];
+    float* inv_s = reinterpret_cast<float*>(skinny_smem);                                  // [TS*16]
+    float (*Cs)[TS * 16][17] = reinterpret_cast<float (*)[TS * 16][17]>(skinny_smem + TS * 16 * sizeof(float));   // [NW]
+    bf16_t* Xs = reinterpret_cast<bf16_t*>(skinny_smem + TS * 16 * sizeof(float));         // [NW][TS*16][SKINNY_LDX], aliases Cs
     const int kper = p.K / NW;                     // this wave's share of K (a multiple of 32)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
@@ -564,9 +576,22 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(TapGemmP p) {
             if (s < steps) {
                 w[s] = nv ? *reinterpret_cast<const U4*>(wrow + k0 + s * 32) : zero;  // plain loads measured faster than nt here
                 if constexpr (NORM) g[s] = *reinterpret_cast<const U4*>(grow + k0 + s * 32);
+                if constexpr (!XLDS) {
 #pragma unroll
-                for (int j = 0; j < TS; ++j) x[j][s] = tv[j] ? *reinterpret_cast<const U4*>(xrow[j] + k0 + s * 32) : zero;
+                    for (int j = 0; j < TS; ++j) x[j][s] = tv[j] ? *reinterpret_cast<const U4*>(xrow[j] + k0 + s * 32) : zero;
+                }
             }
+        }
+        if constexpr (XLDS) {
+            // load instruction i = j*CH + s: rows 4i .. 4i+3 of the block column, 16 lanes x 16 B = one 256-byte row piece each
+#pragma unroll
+            for (int j = 0; j < TS; ++j)
+#pragma unroll
+                for (int s = 0; s < CH; ++s) {
+                    const int row = (j * CH + s) * 4 + fq;
+                    const bool ok = m0 + row < p.M && fr * 8 < steps * 32;
+                    x[j][s] = ok ? *reinterpret_cast<const U4*>(p.X + (size_t)(m0 + row) * p.ldx + kw + k0 + fr * 8) : zero;
+                }
         }
     };
     float inv[TS];
@@ -589,7 +614,16 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(TapGemmP p) {
 #pragma unroll
         for (int j = 0; j < TS; ++j) inv[j] = inv_s[j * 16 + fr];
     }
+    bf16_t* xs_w = Xs + (size_t)wave * TS * 16 * SKINNY_LDX;   // this wave's patch
     auto compute = [&](const U4 (&w)[CH], const U4 (&x)[TS][CH], const U4 (&g)[CH], int steps) {
+        if constexpr (XLDS) {
+            // LDS operations of one wave execute in order: the fragment reads below see these writes without a barrier
+#pragma unroll
+            for (int j = 0; j < TS; ++j)
+#pragma unroll
+                for (int s = 0; s < CH; ++s)
+                    *reinterpret_cast<U4*>(&xs_w[((j * CH + s) * 4 + fq) * SKINNY_LDX + fr * 8]) = x[j][s];
+        }
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
             if (s < steps) {
@@ -600,9 +634,12 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(TapGemmP p) {
 #pragma unroll
                 for (int j = 0; j < TS; ++j) {
                     bf16x8 a;
+                    U4 xf;
+                    if constexpr (XLDS) xf = *reinterpret_cast<const U4*>(&xs_w[(j * 16 + fr) * SKINNY_LDX + s * 32 + fq * 8]);
+                    else xf = x[j][s];
                     if constexpr (NORM) {   // x -> round(round(x / rms) * gain), the two roundings of llama.py:172-177
                         float xv[8];
-                        Vec<bf16_t>::unpack(x[j][s], xv);
+                        Vec<bf16_t>::unpack(xf, xv);
                         U4 o;
                         uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
 #pragma unroll
@@ -613,7 +650,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(TapGemmP p) {
                         }
                         __builtin_memcpy(&a, &o, 16);
                     } else {
-                        __builtin_memcpy(&a, &x[j][s], 16);
+                        __builtin_memcpy(&a, &xf, 16);
                     }
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
                 }
@@ -630,6 +667,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(TapGemmP p) {
         load(wa, xa, ga, nch * 32 * CH, rem);
         compute(wa, xa, ga, rem);
     }
+    if constexpr (XLDS) __syncthreads();   // Cs aliases the X patches: every wave is done reading
     // lane holds C[token = j*16 + 4*fq + r][n = fr]
 #pragma unroll
     for (int j = 0; j < TS; ++j)
@@ -690,19 +728,35 @@ static inline void skinny_gemm_launch(const TapGemmP& p, int gy, hipStream_t st)
     const dim3 grid((p.N + 15) / 16, gy);
     int nw = skinny_waves(p.N, p.K, TS);
     if (p.gain && TS == 4) nw = 4;   // the fused norm's extra registers: keep the 64-row variant off the spill edge
+    static const bool direct = getenv("FT_SKINNY_DIRECT") != nullptr;
+    const bool xlds = !direct;
+#define FT_SK(NWV, NORMV, XV)                                                                                       \
+    do {                                                                                                              \
+        constexpr size_t lds_ = skinny_lds_bytes<TS, NWV>(XV);                                                        \
+        static bool attr_ = false;                                                                                    \
+        if (!attr_ && lds_ > 48 * 1024) {                                                                             \
+            hipFuncSetAttribute((const void*)skinny_gemm_kernel<TS, NWV, NORMV, XV>,                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                               \
+            attr_ = true;                                                                                             \
+        }                                                                                                             \
+        skinny_gemm_kernel<TS, NWV, NORMV, XV><<<grid, NWV * 64, lds_, st>>>(p);                                      \
+    } while (0)
+#define FT_SK_X(NWV, NORMV) do { if (xlds) FT_SK(NWV, NORMV, true); else FT_SK(NWV, NORMV, false); } while (0)
     if (p.gain) {
         switch (nw) {
-            case 12: skinny_gemm_kernel<TS, 12, true><<<grid, 768, 0, st>>>(p); break;
-            case 8: skinny_gemm_kernel<TS, 8, true><<<grid, 512, 0, st>>>(p); break;
-            default: skinny_gemm_kernel<TS, 4, true><<<grid, 256, 0, st>>>(p);
+            case 12: FT_SK_X(12, true); break;
+            case 8: FT_SK_X(8, true); break;
+            default: FT_SK_X(4, true);
         }
     } else {
         switch (nw) {
-            case 12: skinny_gemm_kernel<TS, 12, false><<<grid, 768, 0, st>>>(p); break;
-            case 8: skinny_gemm_kernel<TS, 8, false><<<grid, 512, 0, st>>>(p); break;
-            default: skinny_gemm_kernel<TS, 4, false><<<grid, 256, 0, st>>>(p);
+            case 12: FT_SK_X(12, false); break;
+            case 8: FT_SK_X(8, false); break;
+            default: FT_SK_X(4, false);
         }
     }
+#undef FT_SK_X
+#undef FT_SK
 }
 
 // ---- residual vector quantiser decode (vocoder.py:800-811): x[t][:] = sum_i table_i[code_i[t]][:]
