@@ -1446,6 +1446,8 @@ struct SampCut {
     int all_kept;
     int argmax;       // lowest index is not tracked here; filled by samp_race when needed
     float Lmax, Mt, Z2, Tc;
+    int degenerate;   // samp_cut_kernel: a class held >= 65536 logits (its packed counters wrapped): the global-histogram
+                      // kernels redo the row; 0 in every realistic case
 };
 
 constexpr int SAMP_REP = 8;                        // histogram replicas (spreads same-class atomics)
@@ -1460,6 +1462,7 @@ struct SampBigP {
     float* part_score;   // [M][nchunk]
     int* part_idx;       // [M][nchunk]
     int nchunk;
+    int fallback_only;   // samp_hist / samp_threshold: run only for rows samp_cut_kernel marked degenerate (no edits)
 };
 
 __device__ __forceinline__ float key16_value(unsigned k16) {
@@ -1481,7 +1484,8 @@ static __global__ __launch_bounds__(256) void samp_hist_kernel(SampBigP b) {
     const int nfv = p.nf[m];
     const int R = p.ncb + 1;
     const int* seq = p.seq + (size_t)m * R * p.cap;
-    if (nfv > 0) {
+    if (b.fallback_only && !b.cut[m].degenerate) return;   // settled by samp_cut_kernel (which also edited the row)
+    if (nfv > 0 && !b.fallback_only) {
         const int it = nfv - 1;
         const int ws = it < 16 ? 0 : it - 16;
         const int npen = p.cb == 0 ? R : 16;
@@ -1497,7 +1501,7 @@ static __global__ __launch_bounds__(256) void samp_hist_kernel(SampBigP b) {
         __syncthreads();
         if (tid < npen && pen_id[tid] >= 0) L[pen_id[tid]] = pen_val[tid];
     }
-    if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end >= c0 && p.im_end < c0 + 1024 && p.im_end < V)
+    if (!b.fallback_only && p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end >= c0 && p.im_end < c0 + 1024 && p.im_end < V)
         L[p.im_end] = -INFINITY;
     __syncthreads();
     unsigned* hist = b.hist + (size_t)m * SAMP_HIST_STRIDE + (size_t)(blockIdx.x % SAMP_REP) * SAMP_REP_STRIDE;
@@ -1539,63 +1543,35 @@ constexpr int SAMP_TH_ROW = 33;
 constexpr int SAMP_TH_OVF = 8;
 constexpr size_t SAMP_TH_LDS = (size_t)SAMP_TH_THREADS * SAMP_TH_ROW * 4;
 
-static __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cimg[];
-    __shared__ float red[16];
-    __shared__ int redi[16];
-    __shared__ float wsum[16];
-    __shared__ int wact[16];
-    __shared__ int AL[1024];  // active groups, ascending
-    __shared__ unsigned ovf_key[SAMP_TH_OVF];
-    __shared__ unsigned ovf_cnt[SAMP_TH_OVF];
-    __shared__ int ovf_n;
-    __shared__ SampCut cut_s;
+// Shared-memory scratch of the cut search (one 1024-thread block per row)
+struct SampThShared {
+    float red[16];
+    int redi[16];
+    float wsum[16];
+    int wact[16];
+    int AL[1024];  // active groups, ascending
+    unsigned ovf_key[SAMP_TH_OVF];
+    unsigned ovf_cnt[SAMP_TH_OVF];
+    int ovf_n;
+    SampCut cut_s;
+};
+
+// The top-p cut of one row from the LDS image of its class histogram (thread t owns classes [64 t, 64 t + 64),
+// `has` = the group holds anything, kmax_t = its highest occupied class or -1).  Writes b.cut[m].
+__device__ __forceinline__ void samp_cut_from_image(const SampBigP& b, const int m, const uint32_t* cimg, SampThShared& sh,
+                                                    const bool has, const int kmax_t) {
     const SampP& p = b.s;
-    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RowCtl ctl = p.ctl[m];
-    unsigned* hist0 = b.hist + (size_t)m * SAMP_HIST_STRIDE;
-    if (tid == 0) ovf_n = 0;
-    __syncthreads();
-    // ---- stage: thread t owns group t (classes [64 t, 64 t + 64)); replicas are summed, then cleared
-    uint32_t* row = cimg + tid * SAMP_TH_ROW;
-    int kmax_t = -1;
-    unsigned gtot = 0;
-    unsigned gr[SAMP_REP];
-#pragma unroll
-    for (int r = 0; r < SAMP_REP; ++r) { gr[r] = hist0[(size_t)r * SAMP_REP_STRIDE + 65536 + tid]; gtot += gr[r]; }
-    const bool has = gtot != 0u;
-    if (has) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {  // 32 classes at a time keeps the sums in registers
-            unsigned cs[32];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) cs[j] = 0u;
-#pragma unroll
-            for (int r = 0; r < SAMP_REP; ++r) {
-                if (gr[r]) {
-                    unsigned* hr = hist0 + (size_t)r * SAMP_REP_STRIDE;
-                    if (half == 1) hr[65536 + tid] = 0u;
-                    U4* h4 = reinterpret_cast<U4*>(hr + 64 * tid + 32 * half);
-#pragma unroll
-                    for (int v = 0; v < 8; ++v) {
-                        const U4 q = h4[v];
-                        h4[v] = U4{0u, 0u, 0u, 0u};
-                        cs[4 * v] += q.x; cs[4 * v + 1] += q.y; cs[4 * v + 2] += q.z; cs[4 * v + 3] += q.w;
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 32; j += 2) {
-                const int cj = 32 * half + j;
-                unsigned c0 = cs[j], c1 = cs[j + 1];
-                if (c0) kmax_t = 64 * tid + cj;
-                if (c1) kmax_t = 64 * tid + cj + 1;
-                if (c0 >= 65535u) { const int sl = atomicAdd(&ovf_n, 1); if (sl < SAMP_TH_OVF) { ovf_key[sl] = 64 * tid + cj; ovf_cnt[sl] = c0; } c0 = 65535u; }
-                if (c1 >= 65535u) { const int sl = atomicAdd(&ovf_n, 1); if (sl < SAMP_TH_OVF) { ovf_key[sl] = 64 * tid + cj + 1; ovf_cnt[sl] = c1; } c1 = 65535u; }
-                row[cj >> 1] = c0 | (c1 << 16);
-            }
-        }
-    }
+    float* red = sh.red;
+    int* redi = sh.redi;
+    float* wsum = sh.wsum;
+    int* wact = sh.wact;
+    int* AL = sh.AL;
+    unsigned* ovf_key = sh.ovf_key;
+    unsigned* ovf_cnt = sh.ovf_cnt;
+    int& ovf_n = sh.ovf_n;
+    SampCut& cut_s = sh.cut_s;
     // ---- compact the active groups (ascending) so the arithmetic below is spread over all threads
     const unsigned long long hb = __ballot(has);
     if (lane == 0) wact[wave] = __popcll(hb);
@@ -1693,9 +1669,178 @@ static __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b)
     if (tid == 0) {
         SampCut o;
         o.kstar = kstar; o.nk = nk; o.all_kept = all_kept; o.argmax = 0;
-        o.Lmax = Lmax; o.Mt = Mt; o.Z2 = Z2; o.Tc = Tc;
+        o.Lmax = Lmax; o.Mt = Mt; o.Z2 = Z2; o.Tc = Tc; o.degenerate = 0;
         b.cut[m] = o;
     }
+}
+
+static __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cimg[];
+    __shared__ SampThShared sh;
+    const SampP& p = b.s;
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (b.fallback_only && !b.cut[m].degenerate) return;   // samp_cut_kernel already settled this row
+    unsigned* hist0 = b.hist + (size_t)m * SAMP_HIST_STRIDE;
+    if (tid == 0) sh.ovf_n = 0;
+    __syncthreads();
+    // ---- stage: thread t owns group t (classes [64 t, 64 t + 64)); replicas are summed, then cleared
+    uint32_t* row = cimg + tid * SAMP_TH_ROW;
+    int kmax_t = -1;
+    unsigned gtot = 0;
+    unsigned gr[SAMP_REP];
+#pragma unroll
+    for (int r = 0; r < SAMP_REP; ++r) { gr[r] = hist0[(size_t)r * SAMP_REP_STRIDE + 65536 + tid]; gtot += gr[r]; }
+    const bool has = gtot != 0u;
+    if (has) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // 32 classes at a time keeps the sums in registers
+            unsigned cs[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) cs[j] = 0u;
+#pragma unroll
+            for (int r = 0; r < SAMP_REP; ++r) {
+                if (gr[r]) {
+                    unsigned* hr = hist0 + (size_t)r * SAMP_REP_STRIDE;
+                    if (half == 1) hr[65536 + tid] = 0u;
+                    U4* h4 = reinterpret_cast<U4*>(hr + 64 * tid + 32 * half);
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        const U4 q = h4[v];
+                        h4[v] = U4{0u, 0u, 0u, 0u};
+                        cs[4 * v] += q.x; cs[4 * v + 1] += q.y; cs[4 * v + 2] += q.z; cs[4 * v + 3] += q.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 32; j += 2) {
+                const int cj = 32 * half + j;
+                unsigned c0 = cs[j], c1 = cs[j + 1];
+                if (c0) kmax_t = 64 * tid + cj;
+                if (c1) kmax_t = 64 * tid + cj + 1;
+                if (c0 >= 65535u) { const int sl = atomicAdd(&sh.ovf_n, 1); if (sl < SAMP_TH_OVF) { sh.ovf_key[sl] = 64 * tid + cj; sh.ovf_cnt[sl] = c0; } c0 = 65535u; }
+                if (c1 >= 65535u) { const int sl = atomicAdd(&sh.ovf_n, 1); if (sl < SAMP_TH_OVF) { sh.ovf_key[sl] = 64 * tid + cj + 1; sh.ovf_cnt[sl] = c1; } c1 = 65535u; }
+                row[cj >> 1] = c0 | (c1 << 16);
+            }
+        }
+    }
+    samp_cut_from_image(b, m, cimg, sh, has, kmax_t);
+}
+
+// Histogram and cut search of one row in ONE block: the 65 536 class counters live in LDS as packed u16 pairs (the
+// image samp_cut_from_image reads), filled with LDS atomics, so neither the ~V global atomics of samp_hist_kernel nor the
+// replica read-back of samp_threshold_kernel happen.  A packed counter wraps only if >= 65 536 logits of the row share
+// one bf16 value; the check sum(counts) == V catches that (any wrap changes the total) and hands the row to the
+// global-histogram pair, which otherwise returns at once.  Also applies the repetition penalty / EOS ban to the row.
+static __global__ __launch_bounds__(1024) void samp_cut_kernel(SampBigP b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cimg[];
+    __shared__ SampThShared sh;
+    __shared__ int pen_id[32];
+    __shared__ float pen_val[32];
+    const SampP& p = b.s;
+    const int m = blockIdx.x, tid = threadIdx.x;
+    float* L = p.logits + (size_t)m * p.ldl;
+    const int V = p.V;
+    const RowCtl ctl = p.ctl[m];
+    const int nfv = p.nf[m];
+    const int R = p.ncb + 1;
+    const int* seq = p.seq + (size_t)m * R * p.cap;
+    for (int i = tid; i < SAMP_TH_THREADS * SAMP_TH_ROW; i += 1024) cimg[i] = 0u;
+    if (tid == 0) sh.ovf_n = 0;
+    if (nfv > 0) {   // repetition penalty (inference.py:38-46): gather all, then scatter (duplicates write the same value)
+        const int it = nfv - 1;
+        const int ws = it < 16 ? 0 : it - 16;
+        const int npen = p.cb == 0 ? R : 16;
+        if (tid < npen) {
+            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
+            pen_id[tid] = -1;
+            if (id >= 0 && id < V) {
+                const float sv = L[id];
+                pen_id[tid] = id;
+                pen_val[tid] = sv < 0.f ? round_bf16(sv * ctl.rep) : round_bf16(sv / ctl.rep);
+            }
+        }
+        __syncthreads();
+        if (tid < npen && pen_id[tid] >= 0) L[pen_id[tid]] = pen_val[tid];
+    }
+    if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end < V) L[p.im_end] = -INFINITY;
+    __syncthreads();
+    auto count1 = [&](float v) {
+        const unsigned k = order_key(v) >> 16;
+        atomicAdd(&cimg[(k >> 6) * SAMP_TH_ROW + ((k & 63u) >> 1)], (k & 1u) ? 0x10000u : 1u);
+    };
+    // 16 logits per thread and step, all four 16-byte loads issued before the first counter update (one block walks
+    // the whole row: a load-use chain per element would cost a memory round trip 152 times)
+    const int V16 = ((reinterpret_cast<uintptr_t>(L) & 15) == 0) ? (V / 16384) * 16384 : 0;
+    for (int base = 0; base < V16; base += 16384) {
+        float4 f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f[u] = *reinterpret_cast<const float4*>(L + base + u * 4096 + tid * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { count1(f[u].x); count1(f[u].y); count1(f[u].z); count1(f[u].w); }
+    }
+    for (int base = V16; base < V; base += 4096) {   // tail (and unaligned rows): 4 scalar loads in flight
+        float f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = base + u * 1024 + tid; f[u] = i < V ? L[i] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (base + u * 1024 + tid < V) count1(f[u]);
+    }
+    __syncthreads();
+    // my group: occupancy, highest occupied class, and the row total for the wrap check
+    const uint32_t* row = cimg + tid * SAMP_TH_ROW;
+    int kmax_t = -1;
+    unsigned tot = 0;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+        const uint32_t w = row[j];
+        const unsigned c0 = w & 0xffffu, c1 = w >> 16;
+        if (c0) kmax_t = 64 * tid + 2 * j;
+        if (c1) kmax_t = 64 * tid + 2 * j + 1;
+        tot += c0 + c1;
+    }
+    const int total = (int)block_sum((float)tot, sh.red);   // exact: V < 2^24
+    if (total != V) {   // block-uniform; a packed counter wrapped: some class holds >= 65 536 logits of this row
+        // recount with saturating updates (compare-and-swap) and an exact side table for what exceeds 65 535 - slow, and
+        // only ever taken for such degenerate rows
+        __shared__ unsigned exc_key[SAMP_TH_OVF];
+        __shared__ unsigned exc_cnt[SAMP_TH_OVF];
+        for (int i = tid; i < SAMP_TH_THREADS * SAMP_TH_ROW; i += 1024) cimg[i] = 0u;
+        if (tid < SAMP_TH_OVF) { exc_key[tid] = 0xffffffffu; exc_cnt[tid] = 0u; }
+        __syncthreads();
+        for (int i = tid; i < V; i += 1024) {
+            const unsigned k = order_key(L[i]) >> 16;
+            uint32_t* d = &cimg[(k >> 6) * SAMP_TH_ROW + ((k & 63u) >> 1)];
+            const unsigned shft = (k & 1u) * 16u;
+            for (;;) {
+                const uint32_t old = *reinterpret_cast<volatile uint32_t*>(d);
+                if (((old >> shft) & 0xffffu) == 65535u) {          // saturated: the excess goes to the side table
+                    for (int q = 0; q < SAMP_TH_OVF; ++q) {
+                        const unsigned prev = atomicCAS(&exc_key[q], 0xffffffffu, k);
+                        if (prev == 0xffffffffu || prev == k) { atomicAdd(&exc_cnt[q], 1u); break; }
+                    }
+                    break;
+                }
+                if (atomicCAS(d, old, old + (1u << shft)) == old) break;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+            for (int q = 0; q < SAMP_TH_OVF; ++q)
+                if (exc_key[q] != 0xffffffffu) { sh.ovf_key[n] = exc_key[q]; sh.ovf_cnt[n] = 65535u + exc_cnt[q]; ++n; }
+            sh.ovf_n = n;
+        }
+        kmax_t = -1;
+        tot = 0;
+        for (int j = 0; j < 32; ++j) {
+            const uint32_t w = row[j];
+            if (w & 0xffffu) kmax_t = 64 * tid + 2 * j;
+            if (w >> 16) kmax_t = 64 * tid + 2 * j + 1;
+            tot += (w & 0xffffu) + (w >> 16);
+        }
+        __syncthreads();
+    }
+    samp_cut_from_image(b, m, cimg, sh, tot != 0u, kmax_t);
 }
 
 static __global__ __launch_bounds__(256) void samp_count_kernel(SampBigP b) {

@@ -737,16 +737,26 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
         b.part_score = ctx->samp_part_score + (size_t)m0 * b.nchunk;
         b.part_idx = ctx->samp_part_idx + (size_t)m0 * b.nchunk;
         const dim3 gridc(b.nchunk, L.M);
-        samp_hist_kernel<<<gridc, 256, 0, L.s>>>(b);
         {
             static bool attr_done = false;
             if (!attr_done) {
                 hipFuncSetAttribute((const void*)samp_threshold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)SAMP_TH_LDS);
+                hipFuncSetAttribute((const void*)samp_cut_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)SAMP_TH_LDS);
                 attr_done = true;
             }
         }
-        samp_threshold_kernel<<<L.M, SAMP_TH_THREADS, SAMP_TH_LDS, L.s>>>(b);
+        // histogram + cut search of a row in one block (LDS counters); FT_SAMPLER_GLOBAL_HIST selects the first
+        // implementation (global-atomic histogram, then the cut search on its read-back)
+        const bool global_hist = getenv("FT_SAMPLER_GLOBAL_HIST") != nullptr;   // read per enqueue: tests toggle it
+        b.fallback_only = 0;
+        if (!global_hist) {
+            samp_cut_kernel<<<L.M, SAMP_TH_THREADS, SAMP_TH_LDS, L.s>>>(b);
+        } else {
+            samp_hist_kernel<<<gridc, 256, 0, L.s>>>(b);
+            samp_threshold_kernel<<<L.M, SAMP_TH_THREADS, SAMP_TH_LDS, L.s>>>(b);
+        }
         samp_count_kernel<<<gridc, 256, 0, L.s>>>(b);
         samp_race_kernel<<<gridc, 256, 0, L.s>>>(b);
         samp_finish_kernel<WT><<<L.M, 256, 0, L.s>>>(b);

@@ -475,3 +475,47 @@ def test_sampling_kernel_vs_oracle(precision):
                 bad.append((trial, cb, tp, temp, rep, got, want))
     eng.close()
     assert not bad, f"{len(bad)}/{n_cases} draws differ: {bad[:8]}"
+
+
+def test_large_vocabulary_sampler_vs_oracle(monkeypatch):
+    """The 155 776-way draw (LDS class histogram + cut search in one block, chip-wide race) on identical logits and
+    noise against the oracle: flat and peaked distributions, ties at the top, penalties, top-p from 1e-6 to 1; and the
+    same draws through the global-histogram kernels (FT_SAMPLER_GLOBAL_HIST), which remain the fallback."""
+    import dataclasses
+    V = 155776
+    n_sem = 2048
+    n_text = V - 15 - n_sem
+    shape = dataclasses.replace(tiny_shape(), vocab_size=V, semantic_begin_id=n_text + 15,
+                                semantic_end_id=n_text + 15 + n_sem - 1, im_end_id=n_text + 4)
+    g = torch.Generator().manual_seed(21)
+    R = shape.num_codebooks + 1
+    cases = []
+    for trial in range(8):
+        spread = [0.3, 1.0, 3.0, 8.0][trial % 4]
+        logits = (spread * torch.randn(V, generator=g)).to(torch.bfloat16)
+        if trial % 3 == 0:
+            logits[torch.randint(0, V, (3,), generator=g)] = logits.max()
+        if trial == 5:
+            logits[:70000] = logits.min() - 1   # one class (far below any cut: a cut inside a tie class has no defined
+            #                                     member order in the reference) holds > 65 535 logits: the packed
+            #                                     counters wrap and the global-histogram fallback runs
+        window = torch.randint(0, 1024, (R, 16), generator=g).int()
+        window[0] = torch.randint(0, V, (16,), generator=g).int()
+        q = torch.empty(V).exponential_(1.0, generator=g).clamp_min_(1e-6)
+        for tp, temp, rep in ((0.8, 0.7, 1.1), (0.2, 1.0, 1.5), (1.0, 1.3, 1.0), (1e-6, 0.7, 1.2)):
+            want = O.sample(logits.clone()[None, None], torch.tensor(temp), torch.tensor(tp), torch.tensor(rep),
+                            window[:, 0], noise=lambda p: q.to(p.dtype))[0].item()
+            cases.append((logits, window, q, tp, temp, rep, want))
+    for mode in ("lds", "global"):
+        if mode == "global":
+            monkeypatch.setenv("FT_SAMPLER_GLOBAL_HIST", "1")
+        else:
+            monkeypatch.delenv("FT_SAMPLER_GLOBAL_HIST", raising=False)
+        eng, _ = make_pair(shape, "bf16")
+        bad = []
+        for ci, (logits, window, q, tp, temp, rep, want) in enumerate(cases):
+            got = eng.test_sample(logits.float().numpy(), 0, eng._sampling(temp, tp, rep), window.numpy(), q.numpy())
+            if got != want and not (logits[got] == logits[want]):
+                bad.append((mode, ci, tp, temp, rep, got, want))
+        eng.close()
+        assert not bad, bad[:6]
