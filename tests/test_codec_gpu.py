@@ -197,3 +197,30 @@ def test_encode_reference_api():
         synth.encode_reference(wav(44100, pcm), "x")
     eng.close()
     del threading
+
+
+def test_s1_mini_codec_encode_shapes_vs_oracle():
+    """Encode side at the real widths (encoder 64..1024 channels, strides 2,4,8,8, the window-512 4-layer transformer,
+    1024-wide pre-module, 4096 + 9 x 1024 codebooks) on 6 frames of audio against the f32 oracle, plus the
+    size-independent properties: reproducible, causal (a prefix of the audio gives the prefix of the codes), and the
+    decode of the codes has the input's length."""
+    shape = C.CodecShape()
+    eng, orc = make_codec_with_encoder(shape, max_frames=16)
+    n = 6 * shape.enc_frame_len - 100
+    audio = _test_audio(n, seed=13)
+    want, lens = orc.encode(torch.from_numpy(audio)[None, None], torch.tensor([n]))
+    got = eng.encode(audio)
+    assert got.shape == (10, 6) == tuple(want[0].shape) and int(lens[0]) == 6
+    assert (got[0] < 4096).all() and (got[1:] < 1024).all() and (got >= 0).all()
+    orc.quantizer_decode(torch.from_numpy(got)[None])
+    z_got = orc.taps["rvq"].clone()
+    orc.quantizer_decode(want)
+    z_want = orc.taps["rvq"]
+    err = float((z_got - z_want).pow(2).mean().sqrt() / z_want.pow(2).mean().sqrt())
+    agree = float(np.mean(got[0] == want[0, 0].numpy()))
+    print(f"real shapes: semantic agreement {agree:.2f}, latent rel rms {err:.3f}")
+    assert err <= 0.5, err                       # 6 frames only: no agreement-rate bound, the latent distance bound
+    assert np.array_equal(got, eng.encode(audio))
+    assert np.array_equal(eng.encode(audio[: 4 * shape.enc_frame_len])[:, :4], got[:, :4])
+    assert eng.decode(got).shape == (1, 6 * shape.frame_len)
+    eng.close()
