@@ -598,13 +598,22 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(TapGemmP p) {
     if constexpr (NORM) {
         // 1/rms of every row of this block column from the producer's per-block partial sums of squares
         // one wave per row: its lanes fetch the row's partials in one coalesced load, DPP tree sum (fixed order)
-        for (int t = wave; t < TS * 16; t += NW) {
-            const int row = m0 + t;
+        // (all of a wave's rows are fetched before the first reduction: one memory round trip, not one per row)
+        constexpr int RPW = (TS * 16 + NW - 1) / NW;
+        float ssr[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int t = wave + i * NW, row = m0 + t;
             float ss = 0.f;
-            if (row < p.M)
+            if (t < TS * 16 && row < p.M)
                 for (int b = lane; b < p.ss_nblk; b += 64) ss += p.ss_in[(size_t)row * p.ss_ld + b];
-            ss = wave_sum(ss);
-            if (lane == 0) inv_s[t] = rsqrt_exact(ss / (float)p.K + p.eps);
+            ssr[i] = ss;
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int t = wave + i * NW;
+            const float ss = wave_sum(ssr[i]);
+            if (t < TS * 16 && lane == 0) inv_s[t] = rsqrt_exact(ss / (float)p.K + p.eps);
         }
     }
     U4 wa[CH], wb[CH], xa[TS][CH], xb[TS][CH], ga[CH], gb[CH];
