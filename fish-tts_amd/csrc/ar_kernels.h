@@ -321,10 +321,20 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedP p) {
     for (int d = blockIdx.x * 256 + threadIdx.x; d < p.D; d += gridDim.x * 256) {
         float vq = 0.f;
         if (is_vq) {
-            for (int i = 0; i < p.ncb; ++i) {
-                int c = tk[(size_t)(i + 1) * p.tok_row_stride];
-                c = min(max(c, 0), p.cbsize - 1);
-                vq += ld_elem(cbe, (size_t)(c + i * p.cbsize) * p.D + d);
+            // codes first, then all rows (two memory round trips instead of two per codebook); summed in codebook order
+            constexpr int MAXCB = 16;
+            for (int i0 = 0; i0 < p.ncb; i0 += MAXCB) {
+                int c[MAXCB];
+                float e[MAXCB];
+#pragma unroll
+                for (int i = 0; i < MAXCB; ++i) c[i] = i0 + i < p.ncb ? tk[(size_t)(i0 + i + 1) * p.tok_row_stride] : 0;
+#pragma unroll
+                for (int i = 0; i < MAXCB; ++i) {
+                    const int cc = min(max(c[i], 0), p.cbsize - 1);
+                    e[i] = i0 + i < p.ncb ? ld_elem(cbe, (size_t)(cc + (i0 + i) * p.cbsize) * p.D + d) : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < MAXCB; ++i) if (i0 + i < p.ncb) vq += e[i];
             }
             vq = rb<ROUND>(vq);
         }
