@@ -1456,8 +1456,6 @@ struct SampCut {
     int all_kept;
     int argmax;       // lowest index is not tracked here; filled by samp_race when needed
     float Lmax, Mt, Z2, Tc;
-    int degenerate;   // samp_cut_kernel: a class held >= 65536 logits (its packed counters wrapped): the global-histogram
-                      // kernels redo the row; 0 in every realistic case
 };
 
 constexpr int SAMP_REP = 8;                        // histogram replicas (spreads same-class atomics)
@@ -1472,7 +1470,6 @@ struct SampBigP {
     float* part_score;   // [M][nchunk]
     int* part_idx;       // [M][nchunk]
     int nchunk;
-    int fallback_only;   // samp_hist / samp_threshold: run only for rows samp_cut_kernel marked degenerate (no edits)
 };
 
 __device__ __forceinline__ float key16_value(unsigned k16) {
@@ -1494,8 +1491,7 @@ static __global__ __launch_bounds__(256) void samp_hist_kernel(SampBigP b) {
     const int nfv = p.nf[m];
     const int R = p.ncb + 1;
     const int* seq = p.seq + (size_t)m * R * p.cap;
-    if (b.fallback_only && !b.cut[m].degenerate) return;   // settled by samp_cut_kernel (which also edited the row)
-    if (nfv > 0 && !b.fallback_only) {
+    if (nfv > 0) {
         const int it = nfv - 1;
         const int ws = it < 16 ? 0 : it - 16;
         const int npen = p.cb == 0 ? R : 16;
@@ -1511,7 +1507,7 @@ static __global__ __launch_bounds__(256) void samp_hist_kernel(SampBigP b) {
         __syncthreads();
         if (tid < npen && pen_id[tid] >= 0) L[pen_id[tid]] = pen_val[tid];
     }
-    if (!b.fallback_only && p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end >= c0 && p.im_end < c0 + 1024 && p.im_end < V)
+    if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end >= c0 && p.im_end < c0 + 1024 && p.im_end < V)
         L[p.im_end] = -INFINITY;
     __syncthreads();
     unsigned* hist = b.hist + (size_t)m * SAMP_HIST_STRIDE + (size_t)(blockIdx.x % SAMP_REP) * SAMP_REP_STRIDE;
@@ -1679,7 +1675,7 @@ __device__ __forceinline__ void samp_cut_from_image(const SampBigP& b, const int
     if (tid == 0) {
         SampCut o;
         o.kstar = kstar; o.nk = nk; o.all_kept = all_kept; o.argmax = 0;
-        o.Lmax = Lmax; o.Mt = Mt; o.Z2 = Z2; o.Tc = Tc; o.degenerate = 0;
+        o.Lmax = Lmax; o.Mt = Mt; o.Z2 = Z2; o.Tc = Tc;
         b.cut[m] = o;
     }
 }
@@ -1689,7 +1685,7 @@ static __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b)
     __shared__ SampThShared sh;
     const SampP& p = b.s;
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (b.fallback_only && !b.cut[m].degenerate) return;   // samp_cut_kernel already settled this row
+    const RowCtl ctl = p.ctl[m];
     unsigned* hist0 = b.hist + (size_t)m * SAMP_HIST_STRIDE;
     if (tid == 0) sh.ovf_n = 0;
     __syncthreads();
@@ -1739,8 +1735,8 @@ static __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b)
 // Histogram and cut search of one row in ONE block: the 65 536 class counters live in LDS as packed u16 pairs (the
 // image samp_cut_from_image reads), filled with LDS atomics, so neither the ~V global atomics of samp_hist_kernel nor the
 // replica read-back of samp_threshold_kernel happen.  A packed counter wraps only if >= 65 536 logits of the row share
-// one bf16 value; the check sum(counts) == V catches that (any wrap changes the total) and hands the row to the
-// global-histogram pair, which otherwise returns at once.  Also applies the repetition penalty / EOS ban to the row.
+// one bf16 value; the check sum(counts) == V catches that (any wrap changes the total) and the row is recounted exactly
+// with saturating updates.  Also applies the repetition penalty / EOS ban to the row.
 static __global__ __launch_bounds__(1024) void samp_cut_kernel(SampBigP b) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cimg[];
     __shared__ SampThShared sh;

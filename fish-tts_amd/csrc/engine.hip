@@ -750,7 +750,6 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
         // histogram + cut search of a row in one block (LDS counters); FT_SAMPLER_GLOBAL_HIST selects the first
         // implementation (global-atomic histogram, then the cut search on its read-back)
         const bool global_hist = getenv("FT_SAMPLER_GLOBAL_HIST") != nullptr;   // read per enqueue: tests toggle it
-        b.fallback_only = 0;
         if (!global_hist) {
             samp_cut_kernel<<<L.M, SAMP_TH_THREADS, SAMP_TH_LDS, L.s>>>(b);
         } else {
