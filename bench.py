@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch-probe", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
     a = ap.parse_args()
 
@@ -184,6 +185,27 @@ def main():
         "codec_ms_per_step": round(cod_s / a.steps * 1e3, 3) if codec is not None else None,
         "roofline": roof,
     }
+    # extra, outside the timed region and never part of `value`: BASELINE configs[2]'s lock-step batch on this GPU
+    out["lockstep_batch32_tokens_per_s"] = None
+    if world == 1 and not a.no_batch_probe:
+        try:
+            from fish_tts_amd.config import s1_mini_args as _s1
+            eng.close()
+            beng = ARHipEngine(_s1(max_seq_len=1024), tok.semantic_begin_id, tok.semantic_end_id, im_end, precision="bf16",
+                               device=local_rank, max_batch=32, max_new_tokens=160)
+            beng.load_state_dict(sd)
+            sps = [beng._sampling(0.7, 0.8, 1.1, seed=i, ban_eos=True) for i in range(32)]
+            for rep in range(2):
+                for b in range(32):
+                    beng.prefill(prompt, sps[b], slot=b)
+                beng.sync()
+                t0 = time.perf_counter()
+                _, nb = beng.decode(128, sps, poll=128)
+                dtb = time.perf_counter() - t0
+            out["lockstep_batch32_tokens_per_s"] = round(float(nb.sum()) / dtb, 1)
+            beng.close()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] batch probe skipped: {e}", file=sys.stderr)
     if not a.no_cpu_baseline and world == 1:
         cpu_sd = {k: v.cpu() for k, v in sd.items()}
         out["cpu_baseline"] = cpu_baseline(args.__dict__, cpu_sd, prompt, tok, frames=a.cpu_frames)
