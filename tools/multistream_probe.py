@@ -15,7 +15,8 @@ from fish_tts_amd.config import s1_mini_args  # noqa: E402
 from fish_tts_amd.tokenizer import ByteTokenizer  # noqa: E402
 from fish_tts_amd.weights import random_state_dict  # noqa: E402
 
-Ns = [int(x) for x in sys.argv[1:]] or [1, 2, 4]
+# arguments: N (streams of one utterance each) or NxB (N streams, each a lock-step batch of B)
+specs = [tuple(int(v) for v in (x.split("x") + ["1"])[:2]) for x in (sys.argv[1:] or ["1", "2", "4"])]
 args = s1_mini_args(max_seq_len=1024)
 tok = ByteTokenizer()
 sd = random_state_dict(args, seed=0)
@@ -23,23 +24,24 @@ frames = 128
 rng = np.random.default_rng(0)
 prompt = np.zeros((11, 48), dtype=np.int32)
 prompt[0] = rng.integers(0, tok.n_ranks, 48)
-engines = []
-for N in Ns:
-    while len(engines) < N:
+for N, B in specs:
+    engines = []
+    for _ in range(N):
         e = ARHipEngine(args, tok.semantic_begin_id, tok.semantic_end_id, tok.get_token_id("<|im_end|>"), precision="bf16",
-                        max_batch=1, max_new_tokens=frames + 8)
+                        max_batch=B, max_new_tokens=frames + 8)
         e.load_state_dict(sd)
         engines.append(e)
     for rep in range(2):
-        sps = [e._sampling(0.7, 0.8, 1.1, seed=i, ban_eos=True) for i, e in enumerate(engines[:N])]
-        for e, sp in zip(engines[:N], sps):
-            e.prefill(prompt, sp)
+        sps = [[e._sampling(0.7, 0.8, 1.1, seed=100 * i + b, ban_eos=True) for b in range(B)] for i, e in enumerate(engines)]
+        for e, sp in zip(engines, sps):
+            for b in range(B):
+                e.prefill(prompt, sp[b], slot=b)
             e.sync()
         out = [0] * N
 
         def work(i):
-            _, n = engines[i].decode(frames, [sps[i]], poll=frames)
-            out[i] = int(n[0])
+            _, n = engines[i].decode(frames, sps[i], poll=frames)
+            out[i] = int(n.sum())
         ths = [threading.Thread(target=work, args=(i,)) for i in range(N)]
         t0 = time.perf_counter()
         for t in ths:
@@ -47,6 +49,6 @@ for N in Ns:
         for t in ths:
             t.join()
         dt = time.perf_counter() - t0
-    print(f"{N} independent B=1 streams: {sum(out) / dt:8.1f} tok/s aggregate ({dt / frames * 1e3:.3f} ms per frame each)")
-for e in engines:
-    e.close()
+    print(f"{N} independent streams x lock-step batch {B}: {sum(out) / dt:8.1f} tok/s aggregate ({dt / frames * 1e3:.3f} ms per frame each)")
+    for e in engines:
+        e.close()
