@@ -262,3 +262,74 @@ def test_stream_does_not_deadlock_when_ar_outruns_codec(monkeypatch):
     frames = np.frombuffer(b"".join(out), dtype=np.int16)
     assert np.array_equal(frames, np.arange(131))                 # every frame, in order
     assert [len(c) // 2 for c in out] == [4] + [10] * 12 + [7]
+
+
+def test_batch_scheduler_on_a_fake_engine():
+    """fish_tts_amd.batch.run_batch without a GPU: a fake engine that emits frame counters checks the host policy -
+    longest budget first into the lowest slots, one lock-step pass for the initial first frames, refill of finished
+    slots, idle slots parked, burst width = 1 + highest active slot, budgets and <|im_end|> respected."""
+    from fish_tts_amd.batch import Utterance, run_batch
+
+    class FakeEngine:
+        max_batch, R, im_end_id, max_new_tokens = 3, 11, 99, 64
+
+        def __init__(self):
+            self.slot_utt, self.count, self.widths, self.parked, self.prefills = {}, {}, [], [], []
+
+        def _sampling(self, *a):
+            return a
+
+        def _clamp_new(self, T, n):
+            return min(n, self.max_new_tokens)
+
+        def _frame(self, slot):
+            self.count[slot] += 1
+            uid, eos_at = self.slot_utt[slot]
+            f = np.full(self.R, 1000 * uid + self.count[slot], dtype=np.int32)
+            if eos_at and self.count[slot] == eos_at:
+                f[0] = self.im_end_id
+            return f
+
+        def _start(self, prompt, sp, prefix, slot):
+            self.prefills.append((int(prompt[0, 0]), slot))
+            self.slot_utt[slot], self.count[slot] = (int(prompt[0, 0]), int(prompt[0, 1])), 0
+            return self._frame(slot)
+
+        def prefill_many(self, prompts, sps, slot0, prefixes):
+            return np.stack([self._start(p, s, None, slot0 + i) for i, (p, s) in enumerate(zip(prompts, sps))])
+
+        def park(self, slot):
+            self.parked.append(slot)
+            self.slot_utt.pop(slot, None)
+
+        def decode(self, k, sps, poll):
+            self.widths.append(len(sps))
+            frames = np.zeros((len(sps), k, self.R), dtype=np.int32)
+            n = np.zeros(len(sps), dtype=np.int32)
+            for s in range(len(sps)):
+                if s not in self.slot_utt:
+                    continue
+                for j in range(k):
+                    frames[s, j] = self._frame(s)
+                    n[s] = j + 1
+                    if frames[s, j, 0] == self.im_end_id:
+                        self.slot_utt.pop(s)
+                        break
+            return frames, n
+
+    def utt(uid, budget, eos_at=0):
+        p = np.zeros((11, 4), dtype=np.int32)
+        p[0, 0], p[0, 1] = uid, eos_at
+        return Utterance(p, budget)
+    eng = FakeEngine()
+    utts = [utt(1, 5), utt(2, 30), utt(3, 12, eos_at=7), utt(4, 9), utt(5, 20)]
+    seen = []
+    run_batch(eng, utts, burst=4, on_frames=lambda i, blk: seen.append((i, blk.shape[1])))
+    got = [u.columns().shape[1] for u in utts]
+    assert got == [5, 30, 7, 9, 20]                                  # budgets, and utterance 3 stops at its <|im_end|>
+    assert [u.columns()[1, -1] % 1000 for u in utts] == got           # frames arrive in order, none lost or repeated
+    assert eng.prefills[:3] == [(2, 0), (5, 1), (3, 2)]               # longest budgets first, into the lowest slots
+    assert {uid for uid, _ in eng.prefills[3:]} == {4, 1}             # the rest refill whatever frees up
+    assert eng.widths[0] == 3 and eng.widths[-1] == 1                 # the lock-step width narrows while the queue drains
+    assert sorted(set(eng.parked)) == [0, 1, 2] and sum(n for _, n in seen) == sum(got)   # every slot ends parked
+    run_batch(eng, [], burst=4)                                       # nothing to do: every slot parked, no decode
