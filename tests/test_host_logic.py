@@ -333,3 +333,41 @@ def test_batch_scheduler_on_a_fake_engine():
     assert eng.widths[0] == 3 and eng.widths[-1] == 1                 # the lock-step width narrows while the queue drains
     assert sorted(set(eng.parked)) == [0, 1, 2] and sum(n for _, n in seen) == sum(got)   # every slot ends parked
     run_batch(eng, [], burst=4)                                       # nothing to do: every slot parked, no decode
+
+
+def test_prefix_cache_is_lru_and_keyed_by_content():
+    """generation.PrefixCache without a GPU: one K/V build per distinct prefix, hits move to the back of the eviction
+    order, the least recently used entry is freed beyond the capacity, freed handles are rebuilt."""
+    from fish_tts_amd.generation import PrefixCache
+
+    class Handle:
+        def __init__(self, owner, cols):
+            self.owner, self.handle, self.n_pos = owner, object(), cols.shape[1]
+
+        def free(self):
+            self.handle = None
+            self.owner.freed += 1
+
+    class FakeEngine:
+        def __init__(self):
+            self.built, self.freed = 0, 0
+
+        def build_prefix(self, cols):
+            self.built += 1
+            return Handle(self, cols)
+    eng = FakeEngine()
+    cache = PrefixCache(capacity=2, min_positions=4)
+    a, b, c = (np.full((11, 6), v, dtype=np.int32) for v in (1, 2, 3))
+    ha = cache.get(eng, a)
+    assert cache.get(eng, a.copy()) is ha and eng.built == 1            # same content, another array: a hit
+    cache.get(eng, b)
+    cache.get(eng, a)                                                   # a is now the most recent
+    cache.get(eng, c)                                                   # evicts b
+    assert eng.built == 3 and eng.freed == 1 and len(cache) == 2
+    assert cache.get(eng, a) is ha and eng.built == 3
+    cache.get(eng, b)                                                   # rebuilt, evicts c
+    assert eng.built == 4 and eng.freed == 2
+    ha.free()                                                           # freed behind the cache's back (engine closed)
+    assert cache.get(eng, a) is not ha and eng.built == 5
+    cache.clear()
+    assert len(cache) == 0
