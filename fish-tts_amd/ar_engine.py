@@ -232,6 +232,12 @@ class ARHipEngine:
             None if qq is None else qq.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), "ft_test_sample")
         return int(out[0])
 
+    def engine_state(self):
+        """(flags, aborted, where) of the persistent frame engine: flags bit 0 = slow stack, bit 1 = fast loop."""
+        f, a, w = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.ft_ar_engine_state(self._h, C.byref(f), C.byref(a), C.byref(w)), "ft_ar_engine_state")
+        return f.value, a.value, w.value
+
     def sync(self):
         self._check(self.lib.ft_sync(self._h), "ft_sync")
 

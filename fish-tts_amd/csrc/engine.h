@@ -12,6 +12,7 @@
 namespace ft {
 struct RowCtl;
 struct SampCut;
+struct EngLayer;
 }  // namespace ft (kernels live in ar_kernels.h, included by engine.hip only)
 
 struct FtTensor {
@@ -97,6 +98,17 @@ struct ft_ctx {
     bool force_block_sampler = false, wave_sampler = false;
     int nt_weights = 1;
     int batch_rows = 4;  // utterance rows per weight pass in lock-step batches (1 disables)
+
+    // persistent frame engine (frame_engine.h): batch-1 decode frames as two launches of one workgroup per CU
+    bool eng_on = false;          // shapes fit the instantiated engine and FT_NO_ENGINE is unset
+    bool eng_fast_on = false;
+    int eng_nb = 0;               // workgroups = CUs of the device
+    ft::EngLayer *eng_layers = nullptr, *eng_flayers = nullptr;   // device tables
+    unsigned *eng_gx = nullptr, *eng_gqkv = nullptr, *eng_gy = nullptr, *eng_gxb = nullptr, *eng_gg = nullptr;
+    unsigned long long* eng_gpart = nullptr;
+    unsigned* eng_fast_g = nullptr;   // granule buffers of the fast stack (one allocation)
+    unsigned* eng_ctl = nullptr;
+    size_t eng_lds_slow = 0, eng_lds_fast = 0;
 
     std::map<int, hipGraphExec_t> graphs;
 

@@ -2,6 +2,7 @@
 // frame step) and the C ABI declared in include/fishtts_hip.h.
 #include "engine.h"
 #include "ar_kernels.h"
+#include "frame_engine.h"
 #include "codec_kernels.h"
 
 #include <math.h>
@@ -282,6 +283,8 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     if (ctx->samp_chunk_cnt) hipFree(ctx->samp_chunk_cnt);
     if (ctx->samp_part_score) hipFree(ctx->samp_part_score);
     if (ctx->samp_part_idx) hipFree(ctx->samp_part_idx);
+    { void* eb[] = {ctx->eng_layers, ctx->eng_flayers, ctx->eng_gx, ctx->eng_gqkv, ctx->eng_gy, ctx->eng_gxb, ctx->eng_gg,
+                    ctx->eng_gpart, ctx->eng_fast_g, ctx->eng_ctl}; for (void* q : eb) if (q) hipFree(q); }
     if (ctx->h_pin) hipHostFree(ctx->h_pin);
     for (auto e : ctx->prof_ev) hipEventDestroy(e);
     codec_destroy(ctx);
@@ -347,6 +350,8 @@ static void* wp(ft_ctx* ctx, const std::string& n) {
     return it == ctx->expected.end() ? nullptr : it->second.p;
 }
 
+static ft_status eng_setup(ft_ctx* ctx);
+
 static ft_status ar_finalize(ft_ctx* ctx) {
     const ft_ar_config& c = ctx->c;
     ctx->emb = wp(ctx, "embeddings.weight");
@@ -405,6 +410,60 @@ static ft_status ar_finalize(ft_ctx* ctx) {
         FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     FT_TRY(fill(ctx->flayers, "fast_layers.", c.fast_intermediate_size, c.fast_dim));
+    FT_TRY(eng_setup(ctx));
+    return FT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ frame engine (host side)
+// The engine is an instantiation for one shape class (dim = 1024, heads 16/8 x 128, ffn 3072 in bf16: openaudio-s1-mini's
+// widths at any depth); every other configuration keeps the launch path.  It needs every workgroup resident at once:
+// one per CU, sized by the device's CU count.
+static ft_status eng_setup(ft_ctx* ctx) {
+    const ft_ar_config& c = ctx->c;
+    ctx->eng_on = false;
+    if (getenv("FT_NO_ENGINE") || c.dtype != FT_BF16) return FT_OK;
+    hipDeviceProp_t prop;
+    FT_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    const int nb = prop.multiProcessorCount;
+    const int HD = c.n_head * c.head_dim;
+    const int qkvN = (c.n_head + 2 * c.n_local_heads) * c.head_dim;
+    auto per = [&](int units) { return (units + nb - 1) / nb; };
+    const bool shape_ok = c.dim == 1024 && HD == 2048 && c.intermediate_size == 3072 && c.head_dim == 128 &&
+                          c.n_head == 2 * c.n_local_heads && c.fast_dim == c.dim && c.n_layer >= 1 &&
+                          per(qkvN) <= ENG_SQ * ENG_CW && per(c.dim) <= ENG_SO * ENG_CW && per(c.intermediate_size) <= ENG_SF * ENG_CW &&
+                          c.n_local_heads * ctx->nsplit_max <= nb && c.head_dim % (4 * ctx->nsplit_max) == 0 &&
+                          (size_t)prop.sharedMemPerBlock >= 0 && nb >= 64;
+    if (!shape_ok) return FT_OK;
+    ctx->eng_nb = nb;
+    std::vector<EngLayer> h(c.n_layer);
+    for (int i = 0; i < c.n_layer; ++i) {
+        const FtLayer& l = ctx->layers[i];
+        h[i] = EngLayer{(const bf16_t*)l.wqkv, (const bf16_t*)l.bqkv, (const bf16_t*)l.attn_norm, (const bf16_t*)l.qn,
+                        (const bf16_t*)l.kn, (const bf16_t*)l.wo, (const bf16_t*)l.bo, (const bf16_t*)l.ffn_norm,
+                        (const bf16_t*)l.w13, (const bf16_t*)l.w2, (bf16_t*)l.kc, (bf16_t*)l.vc};
+    }
+    FT_HIP(ctx, hipMalloc((void**)&ctx->eng_layers, h.size() * sizeof(EngLayer)));
+    FT_HIP(ctx, hipMemcpy(ctx->eng_layers, h.data(), h.size() * sizeof(EngLayer), hipMemcpyHostToDevice));
+    auto zalloc = [&](void** q, size_t bytes) -> ft_status {
+        FT_HIP(ctx, hipMalloc(q, bytes));
+        FT_HIP(ctx, hipMemset(*q, 0, bytes));
+        return FT_OK;
+    };
+    const size_t L = c.n_layer;
+    FT_TRY(zalloc((void**)&ctx->eng_gx, (L + 1) * c.dim * 4));
+    FT_TRY(zalloc((void**)&ctx->eng_gqkv, L * qkvN * 4));
+    FT_TRY(zalloc((void**)&ctx->eng_gy, L * HD * 4));
+    FT_TRY(zalloc((void**)&ctx->eng_gxb, L * c.dim * 4));
+    FT_TRY(zalloc((void**)&ctx->eng_gg, L * c.intermediate_size * 4));
+    FT_TRY(zalloc((void**)&ctx->eng_gpart, L * c.n_head * ctx->nsplit_max * (size_t)(c.head_dim + 2) * 8));
+    FT_TRY(zalloc((void**)&ctx->eng_ctl, ENG_CTL_WORDS * 4));
+    const int G = c.n_head / c.n_local_heads, hd = c.head_dim, NSLOT = 4 * (64 / (hd >> 3));
+    size_t fl = (size_t)c.dim * 2 + HD + c.intermediate_size + (size_t)(G + 2) * hd + (size_t)G * hd + 2 * hd +
+                (size_t)NSLOT * G * 2 + (size_t)NSLOT * G * hd + 64 * 6 + 4;
+    ctx->eng_lds_slow = std::max(fl * sizeof(float), (size_t)82 * 1024);   // > half the CU's LDS: one workgroup per CU
+    FT_HIP(ctx, hipFuncSetAttribute((const void*)slow_engine_kernel<2, 4, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)ctx->eng_lds_slow));
+    ctx->eng_on = true;
     return FT_OK;
 }
 
@@ -445,6 +504,34 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
 static bool wide_batch(const Launch& L) {
     return L.ctx->wide_ok && L.ctx->c.dtype == FT_BF16 && L.M >= L.ctx->wide_min && !L.gemv_only && !L.ctx->prof;
 }
+
+static bool eng_slow_ok(const Launch& L) {
+    const ft_ctx* ctx = L.ctx;
+    return ctx->eng_on && L.M == 1 && !L.gemv_only && !ctx->prof && ctx->c.n_local_heads * ctx->nsplit <= ctx->eng_nb &&
+           ctx->c.head_dim % (4 * ctx->nsplit) == 0;
+}
+
+static void enqueue_slow_engine(Launch& L, const int* toks, long tok_row_stride, long tok_m_stride, int col) {
+    ft_ctx* ctx = L.ctx;
+    const ft_ar_config& c = ctx->c;
+    const int m0 = L.m0;
+    SlowEngP p{};
+    p.layers = ctx->eng_layers; p.n_layer = c.n_layer;
+    p.D = c.dim; p.H = c.n_head; p.Hkv = c.n_local_heads; p.hd = c.head_dim; p.F = c.intermediate_size;
+    p.qkvN = (c.n_head + 2 * c.n_local_heads) * c.head_dim;
+    p.eps = c.norm_eps; p.scale = 1.0f / sqrtf((float)c.head_dim);
+    p.emb = (const bf16_t*)ctx->emb; p.cb_emb = (const bf16_t*)ctx->cb_emb;
+    p.toks = toks + (size_t)m0 * tok_m_stride + col; p.tok_row_stride = tok_row_stride;
+    p.ncb = c.num_codebooks; p.cbsize = c.codebook_size; p.vocab = c.vocab_size; p.sem_begin = c.semantic_begin_id;
+    p.sem_end = c.semantic_end_id; p.scale_cb = c.scale_codebook_embeddings; p.inv_div = (float)sqrt((double)(c.num_codebooks + 1));
+    p.rope = ctx->rope; p.pos = ctx->d_pos + m0; p.pos_off = L.pos_off; p.n_slots = ctx->n_slots; p.nsplit = ctx->nsplit;
+    p.cache_off = (size_t)m0 * ctx->cache_m_stride;
+    p.gx = ctx->eng_gx; p.gqkv = ctx->eng_gqkv; p.gpart = ctx->eng_gpart; p.gy = ctx->eng_gy; p.gxb = ctx->eng_gxb; p.gg = ctx->eng_gg;
+    p.ctl = ctx->eng_ctl; p.x_out = ctx->x + (size_t)m0 * c.dim; p.nt = ctx->nt_weights;
+    slow_engine_kernel<2, 4, 6, 2><<<ctx->eng_nb, ENG_THREADS, ctx->eng_lds_slow, L.s>>>(p);
+    L.chk();
+}
+
 
 template <typename WT, bool ROUND, int R>
 static void gemv_nt(Launch& L, const GemvP& p, int nt) {
@@ -886,7 +973,8 @@ static void enqueue_frame_tail(Launch& L);
 
 template <typename WT, bool ROUND>
 static void enqueue_frame_t(Launch& L, const int* toks, long trs, long tms, int col) {
-    enqueue_slow<WT, ROUND>(L, toks, trs, tms, col, true);
+    if (ROUND && eng_slow_ok(L)) enqueue_slow_engine(L, toks, trs, tms, col);
+    else enqueue_slow<WT, ROUND>(L, toks, trs, tms, col, true);
     enqueue_frame_tail<WT, ROUND>(L);
 }
 
@@ -929,6 +1017,7 @@ static void enqueue_slow_only(Launch& L, const int* toks, long trs, long tms, in
 }
 
 // ------------------------------------------------------------------------------------------ AR API
+static ft_status eng_check(ft_ctx* ctx);
 static ft_status ar_ready(ft_ctx* ctx) {
     if (!ctx) return FT_ERR_ARG;
     if (!ctx->has_ar) return ft_fail(ctx, FT_ERR_STATE, "context was created without an AR config");
@@ -1302,6 +1391,7 @@ extern "C" ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames,
         for (int m = 0; m < nslots; ++m) all = all && h[m];
         if (all) break;
     }
+    if (nslots == 1) FT_TRY(eng_check(ctx));
     // collect: frames [nf0, nf0+done_frames) of each slot, cut after the first <|im_end|>.  Only the columns
     // [nf0-1, nf0+done_frames) of the frame store travel (one strided copy per slot, all issued before the wait).
     const int W = done_frames + 1;
@@ -1331,6 +1421,33 @@ extern "C" ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames,
         }
         out_n[m] = n;
     }
+    return FT_OK;
+}
+
+// hand-off time-outs of the frame engine surface as an error of the call that ran the frames
+static ft_status eng_check(ft_ctx* ctx) {
+    if (!ctx->eng_ctl) return FT_OK;
+    unsigned w[4] = {0, 0, 0, 0};
+    FT_HIP(ctx, hipMemcpyAsync(w, ctx->eng_ctl, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (w[ENG_CTL_ABORT]) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "frame engine: a hand-off timed out (phase %u); results of this call are invalid", w[ENG_CTL_WHERE]);
+        return ft_fail(ctx, FT_ERR_HIP, buf);
+    }
+    return FT_OK;
+}
+
+extern "C" ft_status ft_ar_engine_state(ft_ctx* ctx, int32_t* flags, int32_t* aborted, int32_t* where) {
+    FT_TRY(ar_ready(ctx));
+    unsigned w[4] = {0, 0, 0, 0};
+    if (ctx->eng_ctl) {
+        FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FT_HIP(ctx, hipMemcpy(w, ctx->eng_ctl, sizeof w, hipMemcpyDeviceToHost));
+    }
+    if (flags) *flags = (ctx->eng_on ? 1 : 0) | (ctx->eng_fast_on ? 2 : 0);
+    if (aborted) *aborted = (int32_t)w[ENG_CTL_ABORT];
+    if (where) *where = (int32_t)w[ENG_CTL_WHERE];
     return FT_OK;
 }
 

@@ -1,0 +1,618 @@
+// Persistent frame engine for the batch-1 decode step (gfx950): the whole slow stack, and the whole fast
+// codebook loop, each as ONE launch of one 512-thread workgroup per CU.
+//
+// Why: at batch 1 a frame is ~300 dependent matrix-vector phases; as separate launches each phase costs
+// 4.5-5 us (launch boundary + first-byte latency), 10x the time its weights need on HBM.  Inside one launch a
+// phase hands its output vector to every CU as 4-byte granules {16-bit tag, bf16 value} written with sc1
+// (write-through) stores and polled with sc1 (L1-bypassing) loads: the data is the flag, no fence, no
+// barrier, no atomics (tools/mb_edge2.hip: 0.8 us from "last producer stored" to "every CU has the vector").
+// Every CU takes part in every matrix-vector phase with its slice of the rows; weights for the next phase
+// are requested before the wave waits for its input.
+//
+// Arithmetic: every phase reproduces the per-row operation order of the launch-path kernels in
+// ar_kernels.h (one wave per weight row, lanes stride K in 16-byte pieces, the same fma chain, DPP wave
+// reduction, rounding points and epilogues), so a frame from the engine is bit-identical to a frame from the
+// launches (tests/test_engine_gpu.py) and a lock-step batch row still reproduces its single run.
+//   reference: fish_tts/models/llama.py:400-453 (slow pass), 561-580 (fast pass), 193-331 (block),
+//   fish_tts/models/inference.py:83-155 (one frame), 24-80 (sampling).
+//
+// Hand-off rules followed (MI355X guide, "Inter-workgroup communication"): a granule is ONE aligned 4- or 8-byte
+// sc1 store; every load of handed-off bytes is an sc1 vector load to registers (never scalar, never plain);
+// tags are derived from an epoch word in device memory that the last workgroup to leave advances, never from a
+// kernel argument (frozen under graph replay); every spin is bounded by s_memrealtime and raises a global
+// abort word that all spinners poll.
+#pragma once
+#include "ar_kernels.h"
+
+namespace ft {
+
+constexpr int ENG_WAVES = 8;             // waves per workgroup (one workgroup per CU; 256 VGPRs per wave)
+constexpr int ENG_THREADS = ENG_WAVES * 64;
+constexpr int ENG_CW = 4;                // waves 0..3 own weight rows
+constexpr int ENG_GW = 4;                // waves 4..7 gather the input vector of a phase
+constexpr int ENG_EPOCH_STEP = 16;       // tags used per launch (>= num_codebooks)
+constexpr unsigned long long ENG_TIMEOUT_TICKS = 20000000ull;   // 200 ms of s_memrealtime (100 MHz)
+
+typedef __attribute__((address_space(1))) unsigned eng_gu32;
+typedef __attribute__((address_space(1))) unsigned long long eng_gu64;
+#define ENG_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// control words (device memory, zeroed at creation)
+enum { ENG_CTL_EPOCH = 0, ENG_CTL_ABORT = 1, ENG_CTL_EXIT = 2, ENG_CTL_WHERE = 3, ENG_CTL_WORDS = 16 };
+
+struct EngLayer {   // device-resident table, one entry per transformer block
+    const bf16_t *wqkv, *bqkv, *attn_norm, *qn, *kn, *wo, *bo, *ffn_norm, *w13, *w2;
+    bf16_t *kc, *vc;   // KV cache of the slot this launch serves (slow stack only)
+};
+
+__device__ __forceinline__ unsigned eng_tag16(unsigned e) { return (e & 0x7fffu) | 0x8000u; }
+__device__ __forceinline__ unsigned eng_tag32(unsigned e) { return e | 0x80000000u; }
+__device__ __forceinline__ unsigned long long eng_rt() { return __builtin_amdgcn_s_memrealtime(); }
+
+// publish one bf16-representable value as a granule
+__device__ __forceinline__ void eng_put(unsigned* g, int i, float v, unsigned tag16) {
+    __hip_atomic_store((eng_gu32*)(g + i), (tag16 << 16) | (__float_as_uint(v) >> 16), ENG_RLX);
+}
+__device__ __forceinline__ void eng_put_raw(unsigned* g, int i, unsigned v16, unsigned tag16) {
+    __hip_atomic_store((eng_gu32*)(g + i), (tag16 << 16) | (v16 & 0xffffu), ENG_RLX);
+}
+// publish one f32 as an 8-byte granule {value, tag}
+__device__ __forceinline__ void eng_put64(unsigned long long* g, size_t i, float v, unsigned tag32) {
+    __hip_atomic_store((eng_gu64*)(g + i), ((unsigned long long)tag32 << 32) | __float_as_uint(v), ENG_RLX);
+}
+
+__device__ __forceinline__ void eng_ld3_sc1(const void* p0, const void* p1, const void* p2, U4& a, U4& b, U4& c) {
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+}
+__device__ __forceinline__ void eng_ld1_sc1(const void* p0, U4& a) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(p0) : "memory");
+}
+__device__ __forceinline__ bool eng_tags_ok(const U4& v, unsigned tag) {
+    return (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
+}
+__device__ __forceinline__ void eng_unpack_to_lds(float* dst, const U4& v) {
+    float4 f;
+    f.x = __uint_as_float(v.x << 16); f.y = __uint_as_float(v.y << 16);
+    f.z = __uint_as_float(v.z << 16); f.w = __uint_as_float(v.w << 16);
+    *reinterpret_cast<float4*>(dst) = f;
+}
+
+// Spin bookkeeping shared by every poll loop: the clock and the abort word are looked at every 256 polls only.
+struct EngSpin {
+    unsigned* ctl;
+    int* dead;          // LDS word: this workgroup gives up
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    int where;
+    __device__ __forceinline__ bool give_up(int lane) {
+        if ((++spins & 255u) != 0u) return false;
+        const unsigned long long t = eng_rt();
+        if (t0 == 0) t0 = t;
+        if (t - t0 > ENG_TIMEOUT_TICKS || __hip_atomic_load((eng_gu32*)(ctl + ENG_CTL_ABORT), ENG_RLX)) {
+            if (lane == 0) {
+                if (!__hip_atomic_load((eng_gu32*)(ctl + ENG_CTL_ABORT), ENG_RLX))
+                    __hip_atomic_store((eng_gu32*)(ctl + ENG_CTL_WHERE), (unsigned)where, ENG_RLX);
+                __hip_atomic_store((eng_gu32*)(ctl + ENG_CTL_ABORT), 1u, ENG_RLX);
+                *dead = 1;
+            }
+            return true;
+        }
+        return false;
+    }
+};
+
+// Gather n granules (n % 4 == 0) starting at g into LDS dst as f32; called by ngw waves (gw = 0..ngw-1).
+// 1 KiB pieces (256 granules) are dealt round-robin to the waves, at most three per wave and pass.
+__device__ __forceinline__ void eng_gather(const unsigned* g, int n, unsigned tag, float* dst, int gw, int ngw, int lane,
+                                           unsigned* ctl, int* dead, int where) {
+    const int npiece = (n + 255) >> 8;
+    EngSpin sp{ctl, dead, 0, 0, where};
+    for (int p0 = gw; p0 < npiece; p0 += 3 * ngw) {
+        const int c0 = p0;
+        const int c1 = p0 + ngw < npiece ? p0 + ngw : c0;
+        const int c2 = p0 + 2 * ngw < npiece ? p0 + 2 * ngw : c0;
+        // lanes beyond the end of a short last piece re-read the piece's first granules (always in range)
+        const int o0 = c0 * 256 + lane * 4 < n ? c0 * 256 + lane * 4 : c0 * 256;
+        const int o1 = c1 * 256 + lane * 4 < n ? c1 * 256 + lane * 4 : c1 * 256;
+        const int o2 = c2 * 256 + lane * 4 < n ? c2 * 256 + lane * 4 : c2 * 256;
+        U4 a, b, c;
+        for (;;) {
+            if (c1 == c0) { eng_ld1_sc1(g + o0, a); b = a; c = a; }
+            else eng_ld3_sc1(g + o0, g + o1, g + o2, a, b, c);
+            if (__all(eng_tags_ok(a, tag) && eng_tags_ok(b, tag) && eng_tags_ok(c, tag))) break;
+            if (sp.give_up(lane)) return;
+        }
+        if (c0 * 256 + lane * 4 < n) eng_unpack_to_lds(dst + c0 * 256 + lane * 4, a);
+        if (c1 != c0 && c1 * 256 + lane * 4 < n) eng_unpack_to_lds(dst + c1 * 256 + lane * 4, b);
+        if (c2 != c0 && c2 * 256 + lane * 4 < n) eng_unpack_to_lds(dst + c2 * 256 + lane * 4, c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// One matrix-vector phase on this workgroup's units [u_lo, u_hi) of a weight matrix [N][K] (a unit is RPU
+// consecutive rows: 1, or 2 for the interleaved (w1_i, w3_i) pairs).  Unit u_lo + cw + s * ENG_CW belongs to
+// compute wave cw (s < MAXS).  eng_issue requests the rows (and the norm gains) into registers, eng_gemv
+// consumes them with the arithmetic of gemv_finish (ar_kernels.h).
+// ------------------------------------------------------------------------------------------
+template <int NT, int RPU, int MAXS>
+struct EngW {
+    U4 w[MAXS][RPU][NT];
+    U4 gain[NT];
+};
+
+template <int NT, int RPU, int MAXS>
+__device__ __forceinline__ void eng_issue(EngW<NT, RPU, MAXS>& r, const bf16_t* W, const bf16_t* gain, int K, int u_lo, int u_hi,
+                                          int cw, int lane, int nt) {
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        const int u = u_lo + cw + s * ENG_CW;
+#pragma unroll
+        for (int rr = 0; rr < RPU; ++rr)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (cw < ENG_CW && u < u_hi) {
+                    const U4* src = reinterpret_cast<const U4*>(W + (size_t)(u * RPU + rr) * K + t * 512 + lane * 8);
+                    r.w[s][rr][t] = nt ? __builtin_nontemporal_load(src) : *src;
+                } else {
+                    r.w[s][rr][t] = U4{0u, 0u, 0u, 0u};
+                }
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        r.gain[t] = (gain && cw < ENG_CW) ? *reinterpret_cast<const U4*>(gain + t * 512 + lane * 8) : U4{0u, 0u, 0u, 0u};
+}
+
+// xs: the input vector in LDS (f32).  resid: LDS vector the residual epilogue adds (indexed by row), or nullptr.
+// gout: granules of the output vector, plain: optional plain f32 copy (last phase of a launch).
+template <int NT, int RPU, int MAXS, int PRO, int EPI>
+__device__ __forceinline__ void eng_gemv(const EngW<NT, RPU, MAXS>& r, const float* xs, int K, float eps, const bf16_t* bias,
+                                         const float* resid, unsigned* gout, unsigned tag, float* plain, int u_lo, int u_hi,
+                                         int cw, int lane) {
+    if (cw >= ENG_CW || u_lo + cw >= u_hi) return;
+    float xv[NT][8];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float4 f0 = *reinterpret_cast<const float4*>(xs + t * 512 + lane * 8);
+        const float4 f1 = *reinterpret_cast<const float4*>(xs + t * 512 + lane * 8 + 4);
+        xv[t][0] = f0.x; xv[t][1] = f0.y; xv[t][2] = f0.z; xv[t][3] = f0.w;
+        xv[t][4] = f1.x; xv[t][5] = f1.y; xv[t][6] = f1.z; xv[t][7] = f1.w;
+    }
+    if (PRO == PRO_RMSNORM) {
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss = fmaf(xv[t][j], xv[t][j], ss);
+        ss = wave_sum(ss);
+        const float inv = rsqrt_exact(ss / (float)K + eps);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float gv[8];
+            Vec<bf16_t>::unpack(r.gain[t], gv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[t][j] = round_bf16(round_bf16(xv[t][j] * inv) * gv[j]);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        const int u = u_lo + cw + s * ENG_CW;
+        if (u >= u_hi) break;
+        float acc[RPU];
+#pragma unroll
+        for (int rr = 0; rr < RPU; ++rr) {
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float wv[8];
+                Vec<bf16_t>::unpack(r.w[s][rr][t], wv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a = fmaf(wv[j], xv[t][j], a);
+            }
+            acc[rr] = wave_sum(a);
+        }
+        if (EPI == EPI_SWIGLU) {
+            if (lane == 0) {
+                const float a = round_bf16(acc[0]);
+                const float b = round_bf16(acc[RPU - 1]);
+                const float sg = round_bf16(a / (1.0f + expf(-a)));
+                const float o = round_bf16(sg * b);
+                eng_put(gout, u, o, tag);
+                if (plain) plain[u] = o;
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < RPU; ++rr) {
+                const int row = u * RPU + rr;
+                if (lane == rr) {
+                    float v = acc[rr];
+                    if (bias) v += ld_elem(bias, row);
+                    v = round_bf16(v);
+                    if (EPI == EPI_RESID) v = round_bf16(resid[row] + v);
+                    eng_put(gout, row, v, tag);
+                    if (plain) plain[row] = v;
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void eng_units(int U, int b, int nb, int& lo, int& hi) {
+    lo = (int)((long)U * b / nb);
+    hi = (int)((long)U * (b + 1) / nb);
+}
+
+// ------------------------------------------------------------------------------------------
+// Slow stack: embedding + n_layer blocks for ONE utterance row (llama.py:400-453 at S = 1).
+// Per layer: [x] -> QKV -> split-KV attention on Hkv*nsplit workgroups -> split merge on the same workgroups
+// -> [y] -> Wo + residual -> [x'] -> W13 + SwiGLU -> [g] -> W2 + residual -> [x''].
+// ------------------------------------------------------------------------------------------
+struct SlowEngP {
+    const EngLayer* layers;
+    int n_layer;
+    int D, H, Hkv, hd, F, qkvN;
+    float eps, scale;
+    // embedding (llama.py:409-429)
+    const bf16_t* emb; const bf16_t* cb_emb; const int* toks; long tok_row_stride;
+    int ncb, cbsize, vocab, sem_begin, sem_end, scale_cb; float inv_div;
+    // attention
+    const float* rope; const int* pos; int pos_off; int n_slots, nsplit;
+    size_t cache_off;             // elements from the layer's cache base to this slot's rows
+    // granule buffers
+    unsigned* gx;                 // [n_layer + 1][D]   layer inputs (entry n_layer = the stack's output)
+    unsigned* gqkv;               // [n_layer][qkvN]
+    unsigned long long* gpart;    // [n_layer][H][nsplit][hd + 2]  split-KV partials (O, then m, l)
+    unsigned* gy;                 // [n_layer][H * hd]
+    unsigned* gxb;                // [n_layer][D]
+    unsigned* gg;                 // [n_layer][F]
+    unsigned* ctl;
+    float* x_out;                 // plain f32 [D]: input of the vocabulary head launch and of the fast stack
+    int nt;
+};
+
+// LDS carve of the slow kernel (floats): xA[D] yS[H*hd] xB[D] gS[F] qkvS[(G+2)*hd] k_new.. see kernel
+// units per compute wave and matrix at 256 workgroups: QKV 16 rows -> 4, W13 12 pairs -> 3, Wo / W2 4 rows -> 1
+constexpr int ENG_SQ = 4, ENG_SF = 3, ENG_SO = 1;
+
+template <int NTD, int NTA, int NTF, int G>
+__global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
+    constexpr int SQ = ENG_SQ, SF = ENG_SF, SO = ENG_SO;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, nb = gridDim.x;
+    const int cw = wave;                  // compute-wave index (valid when < ENG_CW)
+    const int gw = wave - ENG_CW;         // gather-wave index (valid when >= 0)
+    const int D = p.D, F = p.F, hd = p.hd, hp = hd >> 1, HD = p.H * hd;
+    float* xA = smem;                     // layer input
+    float* yS = xA + D;                   // attention output
+    float* xB = yS + HD;                  // x' = x + Wo y
+    float* gS = xB + D;                   // SwiGLU output
+    float* qS = gS + F;                   // this workgroup's q heads, new k, new v : [(G + 2) * hd]
+    float* q_s = qS + (G + 2) * hd;       // [G][hd] normalised, rotated
+    float* k_new = q_s + G * hd;          // [hd]
+    float* v_new = k_new + hd;            // [hd]
+    const int LPP = hd >> 3, PPW = 64 / LPP, NSLOT = 4 * PPW;
+    float* ml_s = v_new + hd;             // [NSLOT][G][2]
+    float* acc_s = ml_s + NSLOT * G * 2;  // [NSLOT][G][hd]
+    float* mscr = acc_s + NSLOT * G * hd; // [64][6] split-merge exchange
+    int* dead = reinterpret_cast<int*>(mscr + 64 * 6);
+    if (tid == 0) *dead = 0;
+    const unsigned epoch = __hip_atomic_load((eng_gu32*)(p.ctl + ENG_CTL_EPOCH), ENG_RLX);
+    const unsigned tag = eng_tag16(epoch), tag32 = eng_tag32(epoch);
+    const int pos = p.pos[0] + p.pos_off;
+
+    // ---- embedding of the input column, every workgroup for itself (embed_kernel's arithmetic)
+    {
+        const int* tk = p.toks;
+        int t0 = tk[0];
+        const bool is_vq = t0 >= p.sem_begin && t0 <= p.sem_end;
+        t0 = min(max(t0, 0), p.vocab - 1);
+        for (int d = tid; d < D; d += ENG_THREADS) {
+            float vq = 0.f;
+            if (is_vq) {
+                constexpr int MAXCB = 16;
+                for (int i0 = 0; i0 < p.ncb; i0 += MAXCB) {
+                    int c[MAXCB];
+                    float e[MAXCB];
+#pragma unroll
+                    for (int i = 0; i < MAXCB; ++i) c[i] = i0 + i < p.ncb ? tk[(size_t)(i0 + i + 1) * p.tok_row_stride] : 0;
+#pragma unroll
+                    for (int i = 0; i < MAXCB; ++i) {
+                        const int cc = min(max(c[i], 0), p.cbsize - 1);
+                        e[i] = i0 + i < p.ncb ? ld_elem(p.cb_emb, (size_t)(cc + (i0 + i) * p.cbsize) * D + d) : 0.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < MAXCB; ++i) if (i0 + i < p.ncb) vq += e[i];
+                }
+                vq = round_bf16(vq);
+            }
+            float x = round_bf16(ld_elem(p.emb, (size_t)t0 * D + d) + vq);
+            if (p.scale_cb && is_vq) x = round_bf16(x / p.inv_div);
+            xA[d] = x;
+        }
+    }
+    // rows of this workgroup in each matrix
+    int q_lo, q_hi, o_lo, o_hi, f_lo, f_hi, d_lo, d_hi;
+    eng_units(p.qkvN, b, nb, q_lo, q_hi);
+    eng_units(D, b, nb, o_lo, o_hi);
+    eng_units(F, b, nb, f_lo, f_hi);     // (w1_i, w3_i) pairs
+    eng_units(D, b, nb, d_lo, d_hi);
+    EngW<NTD, 1, SQ> wq;
+    EngW<NTA, 1, SO> wo;
+    EngW<NTD, 2, SF> wf;
+    EngW<NTF, 1, SO> wd;
+    eng_issue(wq, p.layers[0].wqkv, p.layers[0].attn_norm, D, q_lo, q_hi, cw, lane, p.nt);
+    __syncthreads();
+
+    for (int li = 0; li < p.n_layer; ++li) {
+        const EngLayer& l = p.layers[li];
+        // ---- QKV
+        if (li > 0) {
+            if (gw >= 0) eng_gather(p.gx + (size_t)li * D, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 0);
+            __syncthreads();
+            if (*dead) break;
+        }
+        eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, p.gqkv + (size_t)li * p.qkvN, tag, nullptr,
+                                                    q_lo, q_hi, cw, lane);
+        eng_issue(wo, l.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, p.nt);
+
+        // ---- attention: workgroup (li * Hkv * nsplit + kvh * nsplit + split) % nb takes (kvh, split)
+        {
+            const int natt = p.Hkv * p.nsplit;
+            int a = b - (int)(((long)li * natt) % nb);
+            if (a < 0) a += nb;
+            const bool is_att = a < natt;
+            const int kvh = a / p.nsplit, split = a % p.nsplit;
+            // the launch path's attn_decode_kernel, waves 0..3 of this workgroup standing in for its 256 threads
+            const int chunk = (pos + p.nsplit) / p.nsplit;
+            const int lo = split * chunk;
+            const int hi = min(lo + chunk, pos + 1);
+            bf16_t* kc = l.kc + p.cache_off + (size_t)kvh * p.n_slots * hd;
+            bf16_t* vc = l.vc + p.cache_off + (size_t)kvh * p.n_slots * hd;
+            const int grp = lane / LPP, gl = lane % LPP;
+            const int slot = wave * PPW + grp;
+            float kpre[8], vpre[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kpre[e] = 0.f; vpre[e] = 0.f; }
+            if (is_att && wave < 4) {
+                const int j = lo + wave * PPW + grp;
+                if (j < hi && j != pos) {
+                    Vec<bf16_t>::load(kc + (size_t)j * hd + gl * 8, kpre);
+                    Vec<bf16_t>::load(vc + (size_t)j * hd + gl * 8, vpre);
+                }
+            }
+            if (is_att) {
+                const unsigned* gq = p.gqkv + (size_t)li * p.qkvN;
+                // q heads of the group (G*hd granules), new k, new v (hd each): one gathering wave per piece
+                if (gw == 0) eng_gather(gq + (size_t)kvh * G * hd, G * hd, tag, qS, 0, 1, lane, p.ctl, dead, li * 8 + 1);
+                if (gw == 1) eng_gather(gq + (size_t)(p.H + kvh) * hd, hd, tag, qS + G * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
+                if (gw == 2) eng_gather(gq + (size_t)(p.H + p.Hkv + kvh) * hd, hd, tag, qS + (G + 1) * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
+            }
+            if (is_att) {     // (workgroup-uniform)
+                __syncthreads();
+                if (*dead) break;
+                if (wave < 4) {
+                    for (int item = wave; item < G + 2; item += 4) {
+                        const float* src = qS + item * hd;
+                        const bf16_t* gain = item < G ? l.qn : (item == G ? l.kn : nullptr);
+                        float* dst = item < G ? q_s + item * hd : (item == G ? k_new : v_new);
+                        if (item == G + 1) {
+                            for (int e = lane; e < hd; e += 64) dst[e] = src[e];
+                        } else {
+                            float x0 = 0.f, x1 = 0.f;
+                            if (lane < hp) { x0 = src[2 * lane]; x1 = src[2 * lane + 1]; }
+                            if (gain) {
+                                const float ss = wave_sum(x0 * x0 + x1 * x1);
+                                const float inv = rsqrt_exact(ss / (float)hd + p.eps);
+                                if (lane < hp) {
+                                    x0 = round_bf16((x0 * inv) * ld_elem(gain, 2 * lane));
+                                    x1 = round_bf16((x1 * inv) * ld_elem(gain, 2 * lane + 1));
+                                }
+                            }
+                            if (lane < hp) {
+                                const float c = p.rope[((size_t)pos * hp + lane) * 2];
+                                const float s = p.rope[((size_t)pos * hp + lane) * 2 + 1];
+                                dst[2 * lane] = round_bf16(x0 * c - x1 * s);
+                                dst[2 * lane + 1] = round_bf16(x1 * c + x0 * s);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                if (wave < 4) {
+                    if (pos >= lo && pos < hi) {
+                        for (int e = tid; e < hd; e += 256) {
+                            st_elem(kc, (size_t)pos * hd + e, k_new[e]);
+                            st_elem(vc, (size_t)pos * hd + e, v_new[e]);
+                        }
+                    }
+                    float qr[G][8];
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) qr[g][e] = q_s[g * hd + gl * 8 + e];
+                    float mrun[G], lrun[G], acc[G][8];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        mrun[g] = -INFINITY; lrun[g] = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+                    }
+                    bool first = true;
+                    for (int base = lo + wave * PPW; base < hi; base += NSLOT) {
+                        const int j = base + grp;
+                        const bool valid = j < hi;
+                        float kv[8], vv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { kv[e] = kpre[e]; vv[e] = vpre[e]; }
+                        if (valid) {
+                            if (j == pos) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) { kv[e] = k_new[gl * 8 + e]; vv[e] = v_new[gl * 8 + e]; }
+                            } else if (!first) {
+                                Vec<bf16_t>::load(kc + (size_t)j * hd + gl * 8, kv);
+                                Vec<bf16_t>::load(vc + (size_t)j * hd + gl * 8, vv);
+                            }
+                        }
+                        first = false;
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            float d = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) d = fmaf(qr[g][e], kv[e], d);
+                            if (LPP > 1) d = group_sum_rt(d, LPP);
+                            if (valid) {
+                                const float s = d * p.scale;
+                                const float mn = fmaxf(mrun[g], s);
+                                const float corr = expf(mrun[g] - mn);
+                                const float pj = expf(s - mn);
+                                lrun[g] = lrun[g] * corr + pj;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) acc[g][e] = acc[g][e] * corr + pj * vv[e];
+                                mrun[g] = mn;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        if (gl == 0) { ml_s[(slot * G + g) * 2] = mrun[g]; ml_s[(slot * G + g) * 2 + 1] = lrun[g]; }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc_s[(size_t)(slot * G + g) * hd + gl * 8 + e] = acc[g][e];
+                    }
+                }
+                __syncthreads();
+                if (wave < 4) {
+                    for (int idx = tid; idx < G * hd; idx += 256) {
+                        const int g = idx / hd, e = idx % hd;
+                        float M = -INFINITY;
+                        for (int s = 0; s < NSLOT; ++s) M = fmaxf(M, ml_s[(s * G + g) * 2]);
+                        float L = 0.f, O = 0.f;
+                        if (M > -INFINITY) {
+                            for (int s = 0; s < NSLOT; ++s) {
+                                const float w = expf(ml_s[(s * G + g) * 2] - M);
+                                L += ml_s[(s * G + g) * 2 + 1] * w;
+                                O += acc_s[(size_t)(s * G + g) * hd + e] * w;
+                            }
+                        }
+                        const int head = kvh * G + g;
+                        if (p.nsplit == 1) {
+                            eng_put(p.gy + (size_t)li * HD, head * hd + e, round_bf16(O / L), tag);
+                        } else {
+                            unsigned long long* gp = p.gpart + (((size_t)li * p.H + head) * p.nsplit + split) * (hd + 2);
+                            eng_put64(gp, e, O, tag32);
+                            if (e == 0) { eng_put64(gp, hd, M, tag32); eng_put64(gp, hd + 1, L, tag32); }
+                        }
+                    }
+                }
+                // ---- merge of the split partials (merge_splits4's arithmetic): this workgroup merges elements
+                // [split * hd / nsplit, (split + 1) * hd / nsplit) of its G heads.  An item = 4 consecutive elements of
+                // one head; lane 8 * i + s polls split c0 + s of item i (O[0..3], m, l = three 16-byte loads), the
+                // values cross to the item's first lane through LDS, which merges in split order.
+                if (p.nsplit > 1 && wave == 4) {
+                    const int epb = hd / p.nsplit;            // elements per workgroup and head (multiple of 4)
+                    const int e4n = epb >> 2;
+                    const int nitem = G * e4n;
+                    EngSpin sp{p.ctl, dead, 0, 0, li * 8 + 2};
+                    bool alive = true;
+                    for (int ib = 0; ib < nitem && alive; ib += 8) {
+                        const int it = ib + (lane >> 3), s8 = lane & 7;
+                        const bool item_on = it < nitem;
+                        const int g = item_on ? it / e4n : 0;
+                        const int e = split * epb + (item_on ? (it % e4n) * 4 : 0);
+                        const int head = kvh * G + g;
+                        const unsigned long long* gp = p.gpart + ((size_t)li * p.H + head) * p.nsplit * (hd + 2);
+                        float M = -INFINITY, L = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                        for (int c0 = 0; c0 < p.nsplit && alive; c0 += 8) {
+                            const bool son = item_on && c0 + s8 < p.nsplit;
+                            const unsigned long long* gs = gp + (size_t)(son ? c0 + s8 : 0) * (hd + 2);
+                            U4 A, B, C;
+                            for (;;) {
+                                eng_ld3_sc1(gs + e, gs + e + 2, gs + hd, A, B, C);
+                                const bool ok = !son || (A.y == tag32 && A.w == tag32 && B.y == tag32 && B.w == tag32 &&
+                                                         C.y == tag32 && C.w == tag32);
+                                if (__all(ok)) break;
+                                if (sp.give_up(lane)) { alive = false; break; }
+                            }
+                            if (!alive) break;
+                            float* ms = mscr + lane * 6;
+                            ms[0] = son ? __uint_as_float(C.x) : -INFINITY;
+                            ms[1] = son ? __uint_as_float(C.z) : 0.f;
+                            ms[2] = __uint_as_float(A.x); ms[3] = __uint_as_float(A.z);
+                            ms[4] = __uint_as_float(B.x); ms[5] = __uint_as_float(B.z);
+                            __builtin_amdgcn_wave_barrier();
+                            if (s8 == 0 && item_on) {
+                                const float* mi = mscr + lane * 6;
+                                float Mc = -INFINITY;
+#pragma unroll
+                                for (int s = 0; s < 8; ++s) Mc = fmaxf(Mc, mi[s * 6]);
+                                if (Mc > -INFINITY) {
+                                    const float Mn = fmaxf(M, Mc);
+                                    if (c0 > 0 && M > -INFINITY) {
+                                        const float rr = expf(M - Mn);
+                                        L *= rr; a0 *= rr; a1 *= rr; a2 *= rr; a3 *= rr;
+                                    }
+                                    M = Mn;
+#pragma unroll
+                                    for (int s = 0; s < 8; ++s) {
+                                        const float m_ = mi[s * 6];
+                                        const float w = m_ > -INFINITY ? expf(m_ - M) : 0.f;
+                                        L += mi[s * 6 + 1] * w;
+                                        a0 += mi[s * 6 + 2] * w; a1 += mi[s * 6 + 3] * w;
+                                        a2 += mi[s * 6 + 4] * w; a3 += mi[s * 6 + 5] * w;
+                                    }
+                                }
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        if (alive && s8 == 0 && item_on) {
+                            unsigned* gy = p.gy + (size_t)li * HD + head * hd + e;
+                            eng_put(gy, 0, round_bf16(a0 / L), tag);
+                            eng_put(gy, 1, round_bf16(a1 / L), tag);
+                            eng_put(gy, 2, round_bf16(a2 / L), tag);
+                            eng_put(gy, 3, round_bf16(a3 / L), tag);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- Wo + residual
+        if (gw >= 0) eng_gather(p.gy + (size_t)li * HD, HD, tag, yS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 3);
+        __syncthreads();
+        if (*dead) break;
+        eng_gemv<NTA, 1, SO, PRO_NONE, EPI_RESID>(wo, yS, HD, p.eps, l.bo, xA, p.gxb + (size_t)li * D, tag, nullptr, o_lo, o_hi, cw, lane);
+        eng_issue(wf, l.w13, l.ffn_norm, D, f_lo, f_hi, cw, lane, p.nt);
+
+        // ---- W13 + SwiGLU
+        if (gw >= 0) eng_gather(p.gxb + (size_t)li * D, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 4);
+        __syncthreads();
+        if (*dead) break;
+        eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, D, p.eps, nullptr, nullptr, p.gg + (size_t)li * F, tag, nullptr, f_lo, f_hi, cw, lane);
+        eng_issue(wd, l.w2, (const bf16_t*)nullptr, F, d_lo, d_hi, cw, lane, p.nt);
+
+        // ---- W2 + residual
+        if (gw >= 0) eng_gather(p.gg + (size_t)li * F, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 5);
+        __syncthreads();
+        if (*dead) break;
+        eng_gemv<NTF, 1, SO, PRO_NONE, EPI_RESID>(wd, gS, F, p.eps, nullptr, xB, p.gx + (size_t)(li + 1) * D, tag,
+                                                 li == p.n_layer - 1 ? p.x_out : nullptr, d_lo, d_hi, cw, lane);
+        if (li + 1 < p.n_layer)
+            eng_issue(wq, p.layers[li + 1].wqkv, p.layers[li + 1].attn_norm, D, q_lo, q_hi, cw, lane, p.nt);
+        // (the next layer's gather waits for a barrier before anyone overwrites xA: the residual reads above are done)
+        __syncthreads();
+    }
+
+    // ---- leave: the last workgroup out advances the epoch for the next launch
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = atomicAdd(p.ctl + ENG_CTL_EXIT, 1u);
+        if (old + 1 == (unsigned)nb) {
+            __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_EXIT), 0u, ENG_RLX);
+            __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_EPOCH), epoch + ENG_EPOCH_STEP, ENG_RLX);
+        }
+    }
+}
+
+}  // namespace ft

@@ -158,6 +158,12 @@ ft_status ft_codec_rvq_encode(ft_ctx* ctx, const float* z, int32_t T, int32_t* c
 ft_status ft_ar_profile_gemv(ft_ctx* ctx, int32_t frames, const ft_sampling* sp, double* ms,
                              int64_t* launches, int64_t* bytes);
 ft_status ft_sync(ft_ctx* ctx);
+/* State of the persistent frame engine (csrc/frame_engine.h), the batch-1 form of the decode step
+ * (fish_tts/models/inference.py:83-155 as two launches of one workgroup per CU instead of ~325 launches).
+ * flags bit 0: the slow stack runs on it, bit 1: the fast codebook loop runs on it (0 = this configuration keeps the
+ * launch path: other widths, f32 precision, FT_NO_ENGINE set).  aborted != 0: a hand-off inside it timed out (ft_ar_decode
+ * then returns FT_ERR_HIP); where = the phase that gave up first.  Any pointer may be NULL. */
+ft_status ft_ar_engine_state(ft_ctx* ctx, int32_t* flags, int32_t* aborted, int32_t* where);
 /* Test hook: one draw of the sampling kernel (inference.py:30-80) on caller-supplied logits.
  * cb = 0 draws from `vocab_size` logits, cb >= 1 from min(1024, codebook_size); window is the
  * (num_codebooks+1) x 16 penalty window of inference.py:187-191 or NULL (no penalty); q the Exp(1)

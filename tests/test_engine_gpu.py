@@ -1,0 +1,83 @@
+"""The persistent frame engine (csrc/frame_engine.h) against the launch path it replaces: same weights, same prompt,
+same sampling -> the token matrices, the vocabulary logits and the hidden state must be equal BIT FOR BIT (every phase
+of the engine reproduces the per-row arithmetic of the launch-path kernels), and both are pinned to the oracle by
+tests/test_ar_gpu.py.  A stale hand-off inside the engine shows up here as a difference.
+
+reference path: fish_tts/models/inference.py:83-155 (one frame), llama.py:400-453, 561-580."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from tests.hip_util import NoiseTape, make_pair
+from tests.shapes import make_prompt, s1mini_shape
+from tests.test_ar_gpu import medium_shape
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(monkeypatch, shape, engine_on, prompt, n_new, kw, tape=None, precision="bf16"):
+    if engine_on:
+        monkeypatch.delenv("FT_NO_ENGINE", raising=False)
+    else:
+        monkeypatch.setenv("FT_NO_ENGINE", "1")
+    eng, _ = make_pair(shape, precision, max_new_tokens=n_new + 8)
+    flags, _, _ = eng.engine_state()
+    if tape is not None:
+        eng.set_noise(tape.table())
+    seq = eng.generate(prompt, n_new, **kw)
+    logits, hidden = eng.debug_state()
+    _, aborted, where = eng.engine_state()
+    eng.close()
+    assert aborted == 0, where
+    return flags, seq, logits, hidden
+
+
+@pytest.mark.parametrize("max_seq_len,Lp", [(512, 40), (1024, 40), (1024, 300), (4096, 900)])
+def test_engine_frames_equal_launch_frames_greedy(monkeypatch, max_seq_len, Lp):
+    """2+2 layers at the s1-mini widths.  max_seq_len 512 -> one KV split per head, 1024 -> 8 splits merged by the
+    attention workgroups, 4096 with a 900-token prompt -> 16 splits (two merge chunks)."""
+    shape = dataclasses.replace(medium_shape(), max_seq_len=max_seq_len)
+    prompt = make_prompt(shape, Lp, seed=4, n_vq=4).numpy()
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    fa, a, la, ha = _run(monkeypatch, shape, False, prompt, 24, kw)
+    fb, b, lb, hb = _run(monkeypatch, shape, True, prompt, 24, kw)
+    assert fa == 0 and (fb & 1) == 1, (fa, fb)          # the second run really took the engine
+    assert np.array_equal(a, b)
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    assert np.array_equal(ha.view(np.uint32), hb.view(np.uint32))
+
+
+def test_engine_frames_equal_launch_frames_sampled(monkeypatch):
+    shape = dataclasses.replace(medium_shape(), max_seq_len=1024)
+    prompt = make_prompt(shape, 24, seed=6, n_vq=3).numpy()
+    kw = dict(temperature=0.7, top_p=0.8, repetition_penalty=1.1)
+    tape = NoiseTape(shape, 40, seed=3)
+    _, a, la, _ = _run(monkeypatch, shape, False, prompt, 32, kw, tape)
+    fb, b, lb, _ = _run(monkeypatch, shape, True, prompt, 32, kw, tape)
+    assert (fb & 1) == 1
+    assert np.array_equal(a, b)
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+
+
+def test_engine_full_depth_equals_launch_path(monkeypatch):
+    """28 + 4 layers, vocabulary 155 776 (BASELINE configs[1] shapes), sampled: 16 frames."""
+    shape = s1mini_shape(max_seq_len=1024)
+    prompt = make_prompt(shape, 48, seed=1, n_vq=0).numpy()
+    kw = dict(temperature=0.7, top_p=0.8, repetition_penalty=1.1)
+    _, a, la, ha = _run(monkeypatch, shape, False, prompt, 16, kw)
+    fb, b, lb, hb = _run(monkeypatch, shape, True, prompt, 16, kw)
+    assert (fb & 1) == 1
+    assert np.array_equal(a, b)
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    assert np.array_equal(ha.view(np.uint32), hb.view(np.uint32))
+
+
+def test_other_configurations_keep_the_launch_path(monkeypatch):
+    """f32 precision and the tiny widths are outside the engine's shape class: flags stay 0 and nothing changes."""
+    from tests.shapes import tiny_shape
+    monkeypatch.delenv("FT_NO_ENGINE", raising=False)
+    for shape, precision in ((tiny_shape(), "bf16"), (medium_shape(), "fp32")):
+        eng, _ = make_pair(shape, precision)
+        assert eng.engine_state()[0] == 0
+        eng.close()
