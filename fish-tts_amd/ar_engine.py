@@ -4,6 +4,7 @@ of the C ABI (include/fishtts_hip.h).  torch is used only to hold weight tensors
 from __future__ import annotations
 
 import ctypes as C
+import logging
 from typing import Dict, Iterator, List, Optional, Sequence
 
 import numpy as np
@@ -15,6 +16,9 @@ from .config import DualARModelArgs
 
 class HipError(RuntimeError):
     pass
+
+
+logger = logging.getLogger(__name__)
 
 
 def _rope_table(n_pos: int, n_elem: int, base: float) -> torch.Tensor:
@@ -102,15 +106,22 @@ class ARHipEngine:
         raise HipError(f"{what} failed ({st}): {msg}")
 
     # ------------------------------------------------------------------ weights
-    def load_tensor(self, name: str, t: torch.Tensor):
+    def load_tensor(self, name: str, t: torch.Tensor, strict: bool = True) -> bool:
+        """Copies one tensor into the library's HBM.  strict=False mirrors the reference's
+        load_state_dict(strict=False, assign=True) (llama.py:498) for EXTRA keys only: a name the model does not
+        have is skipped (returns False); a wrong shape or rank still raises."""
         t = t.detach()
         if t.dtype not in (torch.float32, torch.bfloat16):
             t = t.float()
         t = t.contiguous()
         shape = (C.c_int64 * t.dim())(*t.shape)
         dt = L.FT_F32 if t.dtype == torch.float32 else L.FT_BF16
-        self._check(self.lib.ft_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), dt, shape, t.dim()),
-                    f"ft_load_weight({name})")
+        st = self.lib.ft_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), dt, shape, t.dim())
+        if not strict and st == L.FT_ERR_ARG and self.lib.ft_last_error(self._h).startswith(b"unknown weight name"):
+            logger.debug("checkpoint key %s is not a weight of this model: skipped", name)
+            return False
+        self._check(st, f"ft_load_weight({name})")
+        return True
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], finalize: bool = True):
         a = self.args
@@ -118,7 +129,10 @@ class ARHipEngine:
         for k, v in sd.items():
             if k.endswith(("freqs_cis", "causal_mask")) or "kv_cache" in k:
                 continue
-            self.load_tensor(k, v)
+            # extras (an `output.weight` saved beside tied embeddings, `fast_project_in.*` when fast_dim == dim,
+            # training-only tensors) are ignored like the reference's strict=False load; a MISSING weight still
+            # fails in ft_finalize_weights, a mis-shaped one here
+            self.load_tensor(k, v, strict=False)
         self.load_tensor("rope.slow", _rope_table(a.max_seq_len, a.head_dim, a.rope_base))
         self.load_tensor("rope.fast", _rope_table(a.num_codebooks, a.fast_head_dim, a.rope_base))
         if finalize:

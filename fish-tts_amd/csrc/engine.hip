@@ -431,6 +431,7 @@ static ft_status eng_setup(ft_ctx* ctx) {
     const bool shape_ok = c.dim == 1024 && HD == 2048 && c.intermediate_size == 3072 && c.head_dim == 128 &&
                           c.n_head == 2 * c.n_local_heads && c.fast_dim == c.dim && c.n_layer >= 1 &&
                           per(qkvN) <= ENG_SQ * ENG_CW && per(c.dim) <= ENG_SO * ENG_CW && per(c.intermediate_size) <= ENG_SF * ENG_CW &&
+                          qkvN % (4 * nb) == 0 && c.dim % (4 * nb) == 0 && c.intermediate_size % (4 * nb) == 0 && per(qkvN) <= ENG_LINE &&
                           c.n_local_heads * ctx->nsplit_max <= nb && c.head_dim % (4 * ctx->nsplit_max) == 0 &&
                           (size_t)prop.sharedMemPerBlock >= 0 && nb >= 64;
     if (!shape_ok) return FT_OK;
@@ -450,16 +451,17 @@ static ft_status eng_setup(ft_ctx* ctx) {
         return FT_OK;
     };
     const size_t L = c.n_layer;
-    FT_TRY(zalloc((void**)&ctx->eng_gx, (L + 1) * c.dim * 4));
-    FT_TRY(zalloc((void**)&ctx->eng_gqkv, L * qkvN * 4));
+    const size_t VB = (size_t)nb * ENG_LINE * 4;   // a hand-off buffer holds one 128-byte line per producing workgroup
+    FT_TRY(zalloc((void**)&ctx->eng_gx, (L + 1) * VB));
+    FT_TRY(zalloc((void**)&ctx->eng_gqkv, L * VB));
     FT_TRY(zalloc((void**)&ctx->eng_gy, L * HD * 4));
-    FT_TRY(zalloc((void**)&ctx->eng_gxb, L * c.dim * 4));
-    FT_TRY(zalloc((void**)&ctx->eng_gg, L * c.intermediate_size * 4));
+    FT_TRY(zalloc((void**)&ctx->eng_gxb, L * VB));
+    FT_TRY(zalloc((void**)&ctx->eng_gg, L * VB));
     FT_TRY(zalloc((void**)&ctx->eng_gpart, L * c.n_head * ctx->nsplit_max * (size_t)(c.head_dim + 2) * 8));
     FT_TRY(zalloc((void**)&ctx->eng_ctl, ENG_CTL_WORDS * 4));
     const int G = c.n_head / c.n_local_heads, hd = c.head_dim, NSLOT = 4 * (64 / (hd >> 3));
     size_t fl = (size_t)c.dim * 2 + HD + c.intermediate_size + (size_t)(G + 2) * hd + (size_t)G * hd + 2 * hd +
-                (size_t)NSLOT * G * 2 + (size_t)NSLOT * G * hd + 64 * 6 + 4;
+                (size_t)NSLOT * G * 2 + (size_t)NSLOT * G * hd + 64 * 6 + ENG_MAX_OUT + 8;
     ctx->eng_lds_slow = std::max(fl * sizeof(float), (size_t)82 * 1024);   // > half the CU's LDS: one workgroup per CU
     FT_HIP(ctx, hipFuncSetAttribute((const void*)slow_engine_kernel<2, 4, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)ctx->eng_lds_slow));

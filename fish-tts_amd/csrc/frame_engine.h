@@ -31,6 +31,12 @@ constexpr int ENG_THREADS = ENG_WAVES * 64;
 constexpr int ENG_CW = 4;                // waves 0..3 own weight rows
 constexpr int ENG_GW = 4;                // waves 4..7 gather the input vector of a phase
 constexpr int ENG_EPOCH_STEP = 16;       // tags used per launch (>= num_codebooks)
+#ifndef ENG_ISSUE_LATE
+#define ENG_ISSUE_LATE 0                   // 1: a matrix's next rows are requested one barrier later than its last use
+#endif
+#ifndef ENG_POLL_SLEEP
+#define ENG_POLL_SLEEP 0                   // s_sleep units (64 clocks each) between two polls of a hand-off
+#endif
 constexpr unsigned long long ENG_TIMEOUT_TICKS = 20000000ull;   // 200 ms of s_memrealtime (100 MHz)
 
 typedef __attribute__((address_space(1))) unsigned eng_gu32;
@@ -45,16 +51,66 @@ struct EngLayer {   // device-resident table, one entry per transformer block
     bf16_t *kc, *vc;   // KV cache of the slot this launch serves (slow stack only)
 };
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would wait for every
+// prefetched weight row at every phase.
+__device__ __forceinline__ void eng_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// The per-layer pointer table is read through the constant address space: scalar loads (s_load), which do not sit
+// in the vector-memory counter the prefetched weight rows are counted in (a global_load of a table entry would
+// force vmcnt(0) at every phase).  The table is written once by the host before any launch.
+// Pointers that come out of the table are generic; loads through them must be global_load (counted in vmcnt, in
+// order), not flat_load (vmcnt AND lgkmcnt, out of order: the compiler then waits for everything at every use).
+typedef const __attribute__((address_space(1))) U4* eng_gU4;
+// (a run-time choice between the two forms collapses into ONE plain load: the hint has to be a compile-time one)
+template <bool NT> __device__ __forceinline__ U4 eng_ldg16(const void* p) {
+    if constexpr (NT) return __builtin_nontemporal_load((eng_gU4)p);
+    else return *(eng_gU4)p;
+}
+__device__ __forceinline__ float eng_ldg_bf16(const bf16_t* p, size_t i) {
+    return bf16_bits_to_f32(((const __attribute__((address_space(1))) bf16_t*)p)[i]);
+}
+typedef const __attribute__((address_space(4))) unsigned long long* eng_c64;
+__device__ __forceinline__ EngLayer eng_layer(const EngLayer* table, int i) {
+    static_assert(sizeof(EngLayer) == 12 * sizeof(unsigned long long), "EngLayer is twelve pointers");
+    eng_c64 q = (eng_c64)(unsigned long long)(table + i);
+    EngLayer l;
+    l.wqkv = (const bf16_t*)q[0]; l.bqkv = (const bf16_t*)q[1]; l.attn_norm = (const bf16_t*)q[2]; l.qn = (const bf16_t*)q[3];
+    l.kn = (const bf16_t*)q[4]; l.wo = (const bf16_t*)q[5]; l.bo = (const bf16_t*)q[6]; l.ffn_norm = (const bf16_t*)q[7];
+    l.w13 = (const bf16_t*)q[8]; l.w2 = (const bf16_t*)q[9]; l.kc = (bf16_t*)q[10]; l.vc = (bf16_t*)q[11];
+    return l;
+}
+
 __device__ __forceinline__ unsigned eng_tag16(unsigned e) { return (e & 0x7fffu) | 0x8000u; }
 __device__ __forceinline__ unsigned eng_tag32(unsigned e) { return e | 0x80000000u; }
 __device__ __forceinline__ unsigned long long eng_rt() { return __builtin_amdgcn_s_memrealtime(); }
 
 // publish one bf16-representable value as a granule
+#ifndef ENG_PUT_MODE
+#define ENG_PUT_MODE 0
+#endif
 __device__ __forceinline__ void eng_put(unsigned* g, int i, float v, unsigned tag16) {
-    __hip_atomic_store((eng_gu32*)(g + i), (tag16 << 16) | (__float_as_uint(v) >> 16), ENG_RLX);
+    const unsigned w = (tag16 << 16) | (__float_as_uint(v) >> 16);
+#if ENG_PUT_MODE == 0
+    __hip_atomic_store((eng_gu32*)(g + i), w, ENG_RLX);
+#elif ENG_PUT_MODE == 1
+    (void)__hip_atomic_exchange((eng_gu32*)(g + i), w, ENG_RLX);     // executes at the memory side, not in a write buffer
+#else
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(g + i), "v"(w) : "memory");
+#endif
 }
 __device__ __forceinline__ void eng_put_raw(unsigned* g, int i, unsigned v16, unsigned tag16) {
     __hip_atomic_store((eng_gu32*)(g + i), (tag16 << 16) | (v16 & 0xffffu), ENG_RLX);
+}
+// four consecutive granules in one 16-byte store (every dword carries its own tag, so a torn store is harmless)
+__device__ __forceinline__ void eng_put4(unsigned* g, float v0, float v1, float v2, float v3, unsigned tag16) {
+    U4 w;
+    w.x = (tag16 << 16) | (__float_as_uint(v0) >> 16); w.y = (tag16 << 16) | (__float_as_uint(v1) >> 16);
+    w.z = (tag16 << 16) | (__float_as_uint(v2) >> 16); w.w = (tag16 << 16) | (__float_as_uint(v3) >> 16);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(g), "v"(w) : "memory");
 }
 // publish one f32 as an 8-byte granule {value, tag}
 __device__ __forceinline__ void eng_put64(unsigned long long* g, size_t i, float v, unsigned tag32) {
@@ -103,31 +159,52 @@ struct EngSpin {
     }
 };
 
-// Gather n granules (n % 4 == 0) starting at g into LDS dst as f32; called by ngw waves (gw = 0..ngw-1).
-// 1 KiB pieces (256 granules) are dealt round-robin to the waves, at most three per wave and pass.
-__device__ __forceinline__ void eng_gather(const unsigned* g, int n, unsigned tag, float* dst, int gw, int ngw, int lane,
-                                           unsigned* ctl, int* dead, int where) {
+// Layout of a vector in its hand-off buffer.  ENG_LINE: every producing workgroup owns one 128-byte line and writes its
+// `per` consecutive units there with ONE store instruction, so a line is written once per phase (the memory side serves
+// the accesses to one line one after the other, and every write of a polled line also recalls its copies from the
+// XCDs' L2s: 32 four-byte writes per line cost 2.5-3 us per hand-off, 8 cost 1.6-2, one costs about 1).
+constexpr int ENG_LINE = 32;   // dwords
+struct EngLayout {
+    int per;        // units per producing workgroup (0: the vector is stored linearly)
+    __device__ __forceinline__ int off(int u) const { return per ? (u / per) * ENG_LINE + (u % per) : u; }
+};
+struct EngIdent { __device__ __forceinline__ int operator()(int i) const { return i; } };
+
+// Gather units [u0, u0 + n) (n % 4 == 0, u0 % 4 == 0, per % 4 == 0) of the vector at g into LDS: unit u0 + i lands at
+// dst[dmap(i)] (dmap is given the first of 4 consecutive units and must keep them consecutive).  Called by ngw waves
+// (gw = 0..ngw-1); pieces of 256 units are dealt round-robin to the waves, at most three per wave and pass.
+template <typename DMap = EngIdent>
+__device__ __forceinline__ void eng_gather(const unsigned* g, EngLayout lay, int u0, int n, unsigned tag, float* dst, int gw, int ngw,
+                                           int lane, unsigned* ctl, int* dead, int where, DMap dmap = DMap(),
+                                           unsigned long long* dbg = nullptr) {
     const int npiece = (n + 255) >> 8;
     EngSpin sp{ctl, dead, 0, 0, where};
+    unsigned long long n_full = 0, t_first = 0;
     for (int p0 = gw; p0 < npiece; p0 += 3 * ngw) {
         const int c0 = p0;
         const int c1 = p0 + ngw < npiece ? p0 + ngw : c0;
         const int c2 = p0 + 2 * ngw < npiece ? p0 + 2 * ngw : c0;
-        // lanes beyond the end of a short last piece re-read the piece's first granules (always in range)
-        const int o0 = c0 * 256 + lane * 4 < n ? c0 * 256 + lane * 4 : c0 * 256;
-        const int o1 = c1 * 256 + lane * 4 < n ? c1 * 256 + lane * 4 : c1 * 256;
-        const int o2 = c2 * 256 + lane * 4 < n ? c2 * 256 + lane * 4 : c2 * 256;
+        // lanes beyond the end of a short last piece re-read the piece's first units (always in range)
+        const int i0 = c0 * 256 + lane * 4 < n ? c0 * 256 + lane * 4 : c0 * 256;
+        const int i1 = c1 * 256 + lane * 4 < n ? c1 * 256 + lane * 4 : c1 * 256;
+        const int i2 = c2 * 256 + lane * 4 < n ? c2 * 256 + lane * 4 : c2 * 256;
+        const int o0 = lay.off(u0 + i0), o1 = lay.off(u0 + i1), o2 = lay.off(u0 + i2);
         U4 a, b, c;
         for (;;) {
             if (c1 == c0) { eng_ld1_sc1(g + o0, a); b = a; c = a; }
             else eng_ld3_sc1(g + o0, g + o1, g + o2, a, b, c);
-            if (__all(eng_tags_ok(a, tag) && eng_tags_ok(b, tag) && eng_tags_ok(c, tag))) break;
+            const bool oa = eng_tags_ok(a, tag), ob = eng_tags_ok(b, tag), oc = eng_tags_ok(c, tag);
+            if (dbg && n_full == 0) t_first = eng_rt();
+            ++n_full;
+            if (__all(oa && ob && oc)) break;
             if (sp.give_up(lane)) return;
+            if (ENG_POLL_SLEEP) __builtin_amdgcn_s_sleep(ENG_POLL_SLEEP);
         }
-        if (c0 * 256 + lane * 4 < n) eng_unpack_to_lds(dst + c0 * 256 + lane * 4, a);
-        if (c1 != c0 && c1 * 256 + lane * 4 < n) eng_unpack_to_lds(dst + c1 * 256 + lane * 4, b);
-        if (c2 != c0 && c2 * 256 + lane * 4 < n) eng_unpack_to_lds(dst + c2 * 256 + lane * 4, c);
+        if (c0 * 256 + lane * 4 < n) eng_unpack_to_lds(dst + dmap(i0), a);
+        if (c1 != c0 && c1 * 256 + lane * 4 < n) eng_unpack_to_lds(dst + dmap(i1), b);
+        if (c2 != c0 && c2 * 256 + lane * 4 < n) eng_unpack_to_lds(dst + dmap(i2), c);
     }
+    if (dbg && lane == 0) { dbg[0] = t_first; dbg[1] = n_full; dbg[2] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -145,96 +222,118 @@ struct EngW {
 template <int NT, int RPU, int MAXS>
 __device__ __forceinline__ void eng_issue(EngW<NT, RPU, MAXS>& r, const bf16_t* W, const bf16_t* gain, int K, int u_lo, int u_hi,
                                           int cw, int lane, int nt) {
+    // every compute wave issues the same number of loads on every path (units past the workgroup's last one re-read
+    // it), so the counted vmcnt waits the compiler derives stay exact
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) {
-        const int u = u_lo + cw + s * ENG_CW;
+        int u = u_lo + cw + s * ENG_CW;
+        u = u < u_hi ? u : u_hi - 1;
 #pragma unroll
         for (int rr = 0; rr < RPU; ++rr)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (cw < ENG_CW && u < u_hi) {
-                    const U4* src = reinterpret_cast<const U4*>(W + (size_t)(u * RPU + rr) * K + t * 512 + lane * 8);
-                    r.w[s][rr][t] = nt ? __builtin_nontemporal_load(src) : *src;
-                } else {
-                    r.w[s][rr][t] = U4{0u, 0u, 0u, 0u};
-                }
+                r.w[s][rr][t] = (nt & 2) ? U4{0u, 0u, 0u, 0u} : eng_ldg16<true>(W + (size_t)(u * RPU + rr) * K + t * 512 + lane * 8);
             }
     }
+    if (gain) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-        r.gain[t] = (gain && cw < ENG_CW) ? *reinterpret_cast<const U4*>(gain + t * 512 + lane * 8) : U4{0u, 0u, 0u, 0u};
+        for (int t = 0; t < NT; ++t) r.gain[t] = eng_ldg16<false>(gain + t * 512 + lane * 8);
+    }
 }
 
+// Collection point of a workgroup's outputs of one phase: the compute waves leave their values in LDS and count in; the
+// wave that arrives last publishes ALL of the workgroup's outputs with ONE store instruction (consecutive lanes,
+// consecutive granules).  One coalesced write per workgroup instead of one partial write per row: every 128-byte line
+// of the vector is written by 2-8 stores instead of 32, and the memory side serves the writes of a line one after
+// the other (measured: acknowledgements of the 4-byte stores of a phase spread over 2.5 us).
+struct EngOut {
+    float* vals;     // LDS [ENG_MAX_OUT]
+    int* count;      // LDS arrival counter (never reset: phase k is complete at (k + 1) * ENG_CW)
+    int seq;         // phases done so far (per-wave copy, all compute waves agree)
+};
+constexpr int ENG_MAX_OUT = 64;
+typedef __attribute__((address_space(3))) int* eng_lds_int;
+
 // xs: the input vector in LDS (f32).  resid: LDS vector the residual epilogue adds (indexed by row), or nullptr.
-// gout: granules of the output vector, plain: optional plain f32 copy (last phase of a launch).
+// gout: this workgroup's line of the output vector's hand-off buffer, plain: optional plain f32 copy of the whole
+// vector (last phase of a launch).
+// Called by EVERY compute wave (also one without rows in this matrix).
 template <int NT, int RPU, int MAXS, int PRO, int EPI>
 __device__ __forceinline__ void eng_gemv(const EngW<NT, RPU, MAXS>& r, const float* xs, int K, float eps, const bf16_t* bias,
                                          const float* resid, unsigned* gout, unsigned tag, float* plain, int u_lo, int u_hi,
-                                         int cw, int lane) {
-    if (cw >= ENG_CW || u_lo + cw >= u_hi) return;
-    float xv[NT][8];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float4 f0 = *reinterpret_cast<const float4*>(xs + t * 512 + lane * 8);
-        const float4 f1 = *reinterpret_cast<const float4*>(xs + t * 512 + lane * 8 + 4);
-        xv[t][0] = f0.x; xv[t][1] = f0.y; xv[t][2] = f0.z; xv[t][3] = f0.w;
-        xv[t][4] = f1.x; xv[t][5] = f1.y; xv[t][6] = f1.z; xv[t][7] = f1.w;
-    }
-    if (PRO == PRO_RMSNORM) {
-        float ss = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ss = fmaf(xv[t][j], xv[t][j], ss);
-        ss = wave_sum(ss);
-        const float inv = rsqrt_exact(ss / (float)K + eps);
+                                         int cw, int lane, EngOut& eo) {
+    static_assert(EPI == EPI_SWIGLU ? RPU == 2 : RPU == 1, "a unit is a (w1, w3) pair for SwiGLU, one row otherwise");
+    if (u_lo + cw < u_hi) {
+        float xv[NT][8];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            float gv[8];
-            Vec<bf16_t>::unpack(r.gain[t], gv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xv[t][j] = round_bf16(round_bf16(xv[t][j] * inv) * gv[j]);
+            const float4 f0 = *reinterpret_cast<const float4*>(xs + t * 512 + lane * 8);
+            const float4 f1 = *reinterpret_cast<const float4*>(xs + t * 512 + lane * 8 + 4);
+            xv[t][0] = f0.x; xv[t][1] = f0.y; xv[t][2] = f0.z; xv[t][3] = f0.w;
+            xv[t][4] = f1.x; xv[t][5] = f1.y; xv[t][6] = f1.z; xv[t][7] = f1.w;
         }
-    }
+        if (PRO == PRO_RMSNORM) {
+            float ss = 0.f;
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) {
-        const int u = u_lo + cw + s * ENG_CW;
-        if (u >= u_hi) break;
-        float acc[RPU];
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int rr = 0; rr < RPU; ++rr) {
-            float a = 0.f;
+                for (int j = 0; j < 8; ++j) ss = fmaf(xv[t][j], xv[t][j], ss);
+            ss = wave_sum(ss);
+            const float inv = rsqrt_exact(ss / (float)K + eps);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                float wv[8];
-                Vec<bf16_t>::unpack(r.w[s][rr][t], wv);
+                float gv[8];
+                Vec<bf16_t>::unpack(r.gain[t], gv);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a = fmaf(wv[j], xv[t][j], a);
+                for (int j = 0; j < 8; ++j) xv[t][j] = round_bf16(round_bf16(xv[t][j] * inv) * gv[j]);
             }
-            acc[rr] = wave_sum(a);
         }
-        if (EPI == EPI_SWIGLU) {
-            if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const int u = u_lo + cw + s * ENG_CW;
+            if (u >= u_hi) break;
+            float acc[RPU];
+#pragma unroll
+            for (int rr = 0; rr < RPU; ++rr) {
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float wv[8];
+                    Vec<bf16_t>::unpack(r.w[s][rr][t], wv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a = fmaf(wv[j], xv[t][j], a);
+                }
+                acc[rr] = wave_sum(a);
+            }
+            float o;
+            if (EPI == EPI_SWIGLU) {
                 const float a = round_bf16(acc[0]);
                 const float b = round_bf16(acc[RPU - 1]);
                 const float sg = round_bf16(a / (1.0f + expf(-a)));
-                const float o = round_bf16(sg * b);
-                eng_put(gout, u, o, tag);
-                if (plain) plain[u] = o;
+                o = round_bf16(sg * b);
+            } else {
+                float v = acc[0];
+                if (bias) v += eng_ldg_bf16(bias, u);
+                v = round_bf16(v);
+                if (EPI == EPI_RESID) v = round_bf16(resid[u] + v);
+                o = v;
             }
-        } else {
-#pragma unroll
-            for (int rr = 0; rr < RPU; ++rr) {
-                const int row = u * RPU + rr;
-                if (lane == rr) {
-                    float v = acc[rr];
-                    if (bias) v += ld_elem(bias, row);
-                    v = round_bf16(v);
-                    if (EPI == EPI_RESID) v = round_bf16(resid[row] + v);
-                    eng_put(gout, row, v, tag);
-                    if (plain) plain[row] = v;
-                }
-            }
+            if (lane == 0) eo.vals[u - u_lo] = o;
+        }
+    }
+    // count in; the last wave of the workgroup to arrive publishes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add((eng_lds_int)eo.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    eo.seq += 1;
+    if (old + 1 == eo.seq * ENG_CW) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        const int n = u_hi - u_lo;
+        if (lane < n) {
+            const float o = eo.vals[lane];
+            eng_put(gout, lane, o, tag);
+            if (plain) plain[u_lo + lane] = o;
         }
     }
 }
@@ -269,13 +368,27 @@ struct SlowEngP {
     unsigned* gg;                 // [n_layer][F]
     unsigned* ctl;
     float* x_out;                 // plain f32 [D]: input of the vocabulary head launch and of the fast stack
-    int nt;
+    int nt;                       // bit 1 (timing experiments only): skip the weight loads
+    unsigned long long* stamps;   // diagnostic builds only (tools/mb_engine.hip): [workgroup][layer][16] s_memrealtime ticks, or nullptr
 };
+#define ENG_STAMP(k) do { if (p.stamps && tid == 0) p.stamps[((size_t)b * p.n_layer + li) * 16 + (k)] = eng_rt(); } while (0)
 
-// LDS carve of the slow kernel (floats): xA[D] yS[H*hd] xB[D] gS[F] qkvS[(G+2)*hd] k_new.. see kernel
 // units per compute wave and matrix at 256 workgroups: QKV 16 rows -> 4, W13 12 pairs -> 3, Wo / W2 4 rows -> 1
 constexpr int ENG_SQ = 4, ENG_SF = 3, ENG_SO = 1;
+constexpr int ENG_KVST = 6;   // K/V steps of an attention workgroup held in registers (16 positions each at hd = 128)
 
+// which (kv head, split) workgroup b takes in layer li, or -1: the Hkv * nsplit attention workgroups rotate with the layer
+__device__ __forceinline__ int eng_att_role(int b, int nb, int li, int natt) {
+    int a = b - (int)(((long)li * natt) % nb);
+    if (a < 0) a += nb;
+    return a < natt ? a : -1;
+}
+
+// Waves 0..3 (compute waves) keep this workgroup's rows of ALL FOUR matrices of the next layer in registers and
+// re-request a matrix the moment its rows have been used, so ~120 KB per CU are always in flight and HBM streams
+// continuously instead of in one burst per phase (a CU sustains ~24 GB/s only while requests are outstanding).
+// Waves 4..7 gather the input vectors, and run the attention of the layers in which this workgroup holds a
+// (kv head, split) role, with the cached K/V rows of their next turn prefetched into registers.
 template <int NTD, int NTA, int NTF, int G>
 __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     constexpr int SQ = ENG_SQ, SF = ENG_SF, SO = ENG_SO;
@@ -284,6 +397,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     const int b = blockIdx.x, nb = gridDim.x;
     const int cw = wave;                  // compute-wave index (valid when < ENG_CW)
     const int gw = wave - ENG_CW;         // gather-wave index (valid when >= 0)
+    const int atid = tid - ENG_CW * 64;   // thread index inside the attention group (waves 4..7 = 256 threads)
     const int D = p.D, F = p.F, hd = p.hd, hp = hd >> 1, HD = p.H * hd;
     float* xA = smem;                     // layer input
     float* yS = xA + D;                   // attention output
@@ -297,13 +411,24 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     float* ml_s = v_new + hd;             // [NSLOT][G][2]
     float* acc_s = ml_s + NSLOT * G * 2;  // [NSLOT][G][hd]
     float* mscr = acc_s + NSLOT * G * hd; // [64][6] split-merge exchange
-    int* dead = reinterpret_cast<int*>(mscr + 64 * 6);
-    if (tid == 0) *dead = 0;
+    float* outS = mscr + 64 * 6;          // [ENG_MAX_OUT] this workgroup's outputs of the current phase
+    int* dead = reinterpret_cast<int*>(outS + ENG_MAX_OUT);
+    int* out_count = dead + 1;
+    if (tid == 0) { *dead = 0; *out_count = 0; }
     const unsigned epoch = __hip_atomic_load((eng_gu32*)(p.ctl + ENG_CTL_EPOCH), ENG_RLX);
     const unsigned tag = eng_tag16(epoch), tag32 = eng_tag32(epoch);
     const int pos = p.pos[0] + p.pos_off;
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (p.stamps) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = eng_rt(); }
+    const size_t VSTR = (size_t)nb * ENG_LINE;       // dwords per padded vector buffer (one line per workgroup)
+    const EngLayout layD{D / nb}, layF{F / nb}, layQ{p.qkvN / nb}, layLin{0};
+    const int natt = p.Hkv * p.nsplit;
+    const int chunk = (pos + p.nsplit) / p.nsplit;   // positions per KV split (attn_decode_kernel's rule)
+    const int grp = lane / LPP, gl = lane % LPP;
 
-    // ---- embedding of the input column, every workgroup for itself (embed_kernel's arithmetic)
+    // ---- embedding of the input column, every workgroup for itself (embed_kernel's arithmetic), all threads; then the
+    // two wave roles part ways.  Both roles execute the same sequence of workgroup barriers (B0; per layer: B1 from
+    // layer 1 on, BA BB BC in an attention turn, B2 B3 B4) and leave at the same barrier when the workgroup gives up.
     {
         const int* tk = p.toks;
         int t0 = tk[0];
@@ -333,68 +458,151 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             xA[d] = x;
         }
     }
-    // rows of this workgroup in each matrix
-    int q_lo, q_hi, o_lo, o_hi, f_lo, f_hi, d_lo, d_hi;
-    eng_units(p.qkvN, b, nb, q_lo, q_hi);
-    eng_units(D, b, nb, o_lo, o_hi);
-    eng_units(F, b, nb, f_lo, f_hi);     // (w1_i, w3_i) pairs
-    eng_units(D, b, nb, d_lo, d_hi);
-    EngW<NTD, 1, SQ> wq;
-    EngW<NTA, 1, SO> wo;
-    EngW<NTD, 2, SF> wf;
-    EngW<NTF, 1, SO> wd;
-    eng_issue(wq, p.layers[0].wqkv, p.layers[0].attn_norm, D, q_lo, q_hi, cw, lane, p.nt);
-    __syncthreads();
 
-    for (int li = 0; li < p.n_layer; ++li) {
-        const EngLayer& l = p.layers[li];
-        // ---- QKV
-        if (li > 0) {
-            if (gw >= 0) eng_gather(p.gx + (size_t)li * D, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 0);
-            __syncthreads();
-            if (*dead) break;
-        }
-        eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, p.gqkv + (size_t)li * p.qkvN, tag, nullptr,
-                                                    q_lo, q_hi, cw, lane);
-        eng_issue(wo, l.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, p.nt);
-
-        // ---- attention: workgroup (li * Hkv * nsplit + kvh * nsplit + split) % nb takes (kvh, split)
+    if (wave < ENG_CW) {
+        // =============================== compute waves: rows of the four matrices ===============================
+        int q_lo, q_hi, o_lo, o_hi, f_lo, f_hi, d_lo, d_hi;
+        eng_units(p.qkvN, b, nb, q_lo, q_hi);
+        eng_units(D, b, nb, o_lo, o_hi);
+        eng_units(F, b, nb, f_lo, f_hi);     // (w1_i, w3_i) pairs
+        eng_units(D, b, nb, d_lo, d_hi);
+        EngW<NTD, 1, SQ> wq;
+        EngW<NTA, 1, SO> wo;
+        EngW<NTD, 2, SF> wf;
+        EngW<NTF, 1, SO> wd;
+        EngOut eo{outS, out_count, 0};
         {
-            const int natt = p.Hkv * p.nsplit;
-            int a = b - (int)(((long)li * natt) % nb);
-            if (a < 0) a += nb;
-            const bool is_att = a < natt;
-            const int kvh = a / p.nsplit, split = a % p.nsplit;
-            // the launch path's attn_decode_kernel, waves 0..3 of this workgroup standing in for its 256 threads
-            const int chunk = (pos + p.nsplit) / p.nsplit;
-            const int lo = split * chunk;
-            const int hi = min(lo + chunk, pos + 1);
-            bf16_t* kc = l.kc + p.cache_off + (size_t)kvh * p.n_slots * hd;
-            bf16_t* vc = l.vc + p.cache_off + (size_t)kvh * p.n_slots * hd;
-            const int grp = lane / LPP, gl = lane % LPP;
-            const int slot = wave * PPW + grp;
-            float kpre[8], vpre[8];
+            const EngLayer l0 = eng_layer(p.layers, 0);
+            eng_issue(wq, l0.wqkv, l0.attn_norm, D, q_lo, q_hi, cw, lane, p.nt);
+            eng_issue(wo, l0.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, p.nt);
+            eng_issue(wf, l0.w13, l0.ffn_norm, D, f_lo, f_hi, cw, lane, p.nt);
+            eng_issue(wd, l0.w2, (const bf16_t*)nullptr, F, d_lo, d_hi, cw, lane, p.nt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        eng_barrier();                                              // B0
+        for (int li = 0; li < p.n_layer; ++li) {
+            const EngLayer l = eng_layer(p.layers, li);
+            const bool more = li + 1 < p.n_layer;
+            const EngLayer ln = eng_layer(p.layers, more ? li + 1 : li);
+            if (li > 0) { eng_barrier(); if (*dead) break; }        // B1
+#if ENG_ISSUE_LATE
+            if (li > 0) { eng_issue(wd, l.w2, (const bf16_t*)nullptr, F, d_lo, d_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
+#endif
+            ENG_STAMP(0);
+            eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, p.gqkv + (size_t)li * VSTR + (size_t)b * ENG_LINE, tag, nullptr,
+                                                         q_lo, q_hi, cw, lane, eo);
+            __builtin_amdgcn_sched_barrier(0);
+            ENG_STAMP(1);
+#if !ENG_ISSUE_LATE
+            if (more) eng_issue(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, p.nt);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (eng_att_role(b, nb, li, natt) >= 0) {
+                eng_barrier(); if (*dead) break;                    // BA
+                eng_barrier();                                      // BB
+                eng_barrier();                                      // BC
+            }
+            ENG_STAMP(2);
+            eng_barrier(); if (*dead) break;                        // B2
+#if ENG_ISSUE_LATE
+            if (more) { eng_issue(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
+#endif
+            ENG_STAMP(3);
+            eng_gemv<NTA, 1, SO, PRO_NONE, EPI_RESID>(wo, yS, HD, p.eps, l.bo, xA, p.gxb + (size_t)li * VSTR + (size_t)b * ENG_LINE, tag, nullptr, o_lo, o_hi, cw, lane, eo);
+            __builtin_amdgcn_sched_barrier(0);
+            ENG_STAMP(4);
+            if (p.stamps && (p.nt & 2)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ENG_STAMP(9); }   // write-through acknowledged
+#if !ENG_ISSUE_LATE
+            if (more) eng_issue(wo, ln.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, p.nt);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            eng_barrier(); if (*dead) break;                        // B3
+#if ENG_ISSUE_LATE
+            if (more) { eng_issue(wo, ln.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
+#endif
+            ENG_STAMP(5);
+            eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, D, p.eps, nullptr, nullptr, p.gg + (size_t)li * VSTR + (size_t)b * ENG_LINE, tag, nullptr, f_lo, f_hi, cw, lane, eo);
+            __builtin_amdgcn_sched_barrier(0);
+            ENG_STAMP(6);
+#if !ENG_ISSUE_LATE
+            if (more) eng_issue(wf, ln.w13, ln.ffn_norm, D, f_lo, f_hi, cw, lane, p.nt);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            eng_barrier(); if (*dead) break;                        // B4
+#if ENG_ISSUE_LATE
+            if (more) { eng_issue(wf, ln.w13, ln.ffn_norm, D, f_lo, f_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
+#endif
+            ENG_STAMP(7);
+            eng_gemv<NTF, 1, SO, PRO_NONE, EPI_RESID>(wd, gS, F, p.eps, nullptr, xB, p.gx + (size_t)(li + 1) * VSTR + (size_t)b * ENG_LINE, tag,
+                                                      li == p.n_layer - 1 ? p.x_out : nullptr, d_lo, d_hi, cw, lane, eo);
+            __builtin_amdgcn_sched_barrier(0);
+            ENG_STAMP(8);
+#if !ENG_ISSUE_LATE
+            if (more) eng_issue(wd, ln.w2, (const bf16_t*)nullptr, F, d_lo, d_hi, cw, lane, p.nt);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (!(p.nt & 2)) ENG_STAMP(9);
+        }
+    } else {
+        // ====================== gathering waves: input vectors, attention turns, split merge ======================
+        // K/V rows of this workgroup's next attention turn: step st covers positions lo + st * NSLOT + ..
+        U4 kpf[ENG_KVST], vpf[ENG_KVST];
+        float gq0 = 1.f, gq1 = 1.f, gk0 = 1.f, gk1 = 1.f;   // q / k norm gains (elements 2 lane, 2 lane + 1) of that layer
+        int att_next = -1;    // the layer those rows belong to
+        auto kv_prefetch = [&](int from_layer) {
+            att_next = -1;
+            for (int l2 = from_layer; l2 < p.n_layer; ++l2)
+                if (eng_att_role(b, nb, l2, natt) >= 0) { att_next = l2; break; }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { kpre[e] = 0.f; vpre[e] = 0.f; }
-            if (is_att && wave < 4) {
-                const int j = lo + wave * PPW + grp;
+            for (int st = 0; st < ENG_KVST; ++st) { kpf[st] = U4{0u, 0u, 0u, 0u}; vpf[st] = U4{0u, 0u, 0u, 0u}; }
+            if (att_next < 0) return;
+            const int a = eng_att_role(b, nb, att_next, natt);
+            const int kvh = a / p.nsplit, split = a % p.nsplit;
+            const int lo = split * chunk, hi = min(lo + chunk, pos + 1);
+            const EngLayer l2 = eng_layer(p.layers, att_next);
+            if (lane < hp) {
+                if (l2.qn) { gq0 = eng_ldg_bf16(l2.qn, 2 * lane); gq1 = eng_ldg_bf16(l2.qn, 2 * lane + 1); }
+                if (l2.kn) { gk0 = eng_ldg_bf16(l2.kn, 2 * lane); gk1 = eng_ldg_bf16(l2.kn, 2 * lane + 1); }
+            }
+            const bf16_t* kc = l2.kc + p.cache_off + (size_t)kvh * p.n_slots * hd;
+            const bf16_t* vc = l2.vc + p.cache_off + (size_t)kvh * p.n_slots * hd;
+#pragma unroll
+            for (int st = 0; st < ENG_KVST; ++st) {
+                const int j = lo + st * NSLOT + gw * PPW + grp;
                 if (j < hi && j != pos) {
-                    Vec<bf16_t>::load(kc + (size_t)j * hd + gl * 8, kpre);
-                    Vec<bf16_t>::load(vc + (size_t)j * hd + gl * 8, vpre);
+                    kpf[st] = eng_ldg16<false>(kc + (size_t)j * hd + gl * 8);
+                    vpf[st] = eng_ldg16<false>(vc + (size_t)j * hd + gl * 8);
                 }
             }
-            if (is_att) {
-                const unsigned* gq = p.gqkv + (size_t)li * p.qkvN;
-                // q heads of the group (G*hd granules), new k, new v (hd each): one gathering wave per piece
-                if (gw == 0) eng_gather(gq + (size_t)kvh * G * hd, G * hd, tag, qS, 0, 1, lane, p.ctl, dead, li * 8 + 1);
-                if (gw == 1) eng_gather(gq + (size_t)(p.H + kvh) * hd, hd, tag, qS + G * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
-                if (gw == 2) eng_gather(gq + (size_t)(p.H + p.Hkv + kvh) * hd, hd, tag, qS + (G + 1) * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
+        };
+        kv_prefetch(0);
+        // rotation entries of this position (the same for every layer)
+        float rope_c = 1.f, rope_s = 0.f;
+        if (lane < hp) { rope_c = p.rope[((size_t)pos * hp + lane) * 2]; rope_s = p.rope[((size_t)pos * hp + lane) * 2 + 1]; }
+        eng_barrier();                                              // B0
+        for (int li = 0; li < p.n_layer; ++li) {
+            const EngLayer l = eng_layer(p.layers, li);
+            if (li > 0) {
+                eng_gather(p.gx + (size_t)li * VSTR, layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 0);
+                eng_barrier(); if (*dead) break;                    // B1
             }
-            if (is_att) {     // (workgroup-uniform)
-                __syncthreads();
-                if (*dead) break;
-                if (wave < 4) {
-                    for (int item = wave; item < G + 2; item += 4) {
+            // ---- attention (attn_decode_kernel's arithmetic; these four waves stand in for its 256 threads)
+            const int a = eng_att_role(b, nb, li, natt);
+            if (a >= 0) {     // (workgroup-uniform)
+                const int kvh = a / p.nsplit, split = a % p.nsplit;
+                const int lo = split * chunk;
+                const int hi = min(lo + chunk, pos + 1);
+                bf16_t* kc = l.kc + p.cache_off + (size_t)kvh * p.n_slots * hd;
+                bf16_t* vc = l.vc + p.cache_off + (size_t)kvh * p.n_slots * hd;
+                const int slot = gw * PPW + grp;
+                const unsigned* gq = p.gqkv + (size_t)li * VSTR;
+                // q heads of the group (G*hd granules), new k, new v (hd each): one gathering wave per piece
+                if (gw == 0) eng_gather(gq, layQ, kvh * G * hd, G * hd, tag, qS, 0, 1, lane, p.ctl, dead, li * 8 + 1);
+                if (gw == 1) eng_gather(gq, layQ, (p.H + kvh) * hd, hd, tag, qS + G * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
+                if (gw == 2) eng_gather(gq, layQ, (p.H + p.Hkv + kvh) * hd, hd, tag, qS + (G + 1) * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
+                eng_barrier(); if (*dead) break;                    // BA
+                if (gw >= 0) {
+                    for (int item = gw; item < G + 2; item += 4) {
                         const float* src = qS + item * hd;
                         const bf16_t* gain = item < G ? l.qn : (item == G ? l.kn : nullptr);
                         float* dst = item < G ? q_s + item * hd : (item == G ? k_new : v_new);
@@ -407,23 +615,24 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                                 const float ss = wave_sum(x0 * x0 + x1 * x1);
                                 const float inv = rsqrt_exact(ss / (float)hd + p.eps);
                                 if (lane < hp) {
-                                    x0 = round_bf16((x0 * inv) * ld_elem(gain, 2 * lane));
-                                    x1 = round_bf16((x1 * inv) * ld_elem(gain, 2 * lane + 1));
+                                    const bool have = att_next == li;     // the gains came with the prefetched rows
+                                    const float g0 = have ? (item < G ? gq0 : gk0) : eng_ldg_bf16(gain, 2 * lane);
+                                    const float g1 = have ? (item < G ? gq1 : gk1) : eng_ldg_bf16(gain, 2 * lane + 1);
+                                    x0 = round_bf16((x0 * inv) * g0);
+                                    x1 = round_bf16((x1 * inv) * g1);
                                 }
                             }
                             if (lane < hp) {
-                                const float c = p.rope[((size_t)pos * hp + lane) * 2];
-                                const float s = p.rope[((size_t)pos * hp + lane) * 2 + 1];
-                                dst[2 * lane] = round_bf16(x0 * c - x1 * s);
-                                dst[2 * lane + 1] = round_bf16(x1 * c + x0 * s);
+                                dst[2 * lane] = round_bf16(x0 * rope_c - x1 * rope_s);
+                                dst[2 * lane + 1] = round_bf16(x1 * rope_c + x0 * rope_s);
                             }
                         }
                     }
                 }
-                __syncthreads();
-                if (wave < 4) {
+                eng_barrier();
+                if (gw >= 0) {
                     if (pos >= lo && pos < hi) {
-                        for (int e = tid; e < hd; e += 256) {
+                        for (int e = atid; e < hd; e += 256) {
                             st_elem(kc, (size_t)pos * hd + e, k_new[e]);
                             st_elem(vc, (size_t)pos * hd + e, v_new[e]);
                         }
@@ -440,23 +649,8 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
                     }
-                    bool first = true;
-                    for (int base = lo + wave * PPW; base < hi; base += NSLOT) {
-                        const int j = base + grp;
+                    auto step = [&](const int j, const float (&kv)[8], const float (&vv)[8]) {
                         const bool valid = j < hi;
-                        float kv[8], vv[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { kv[e] = kpre[e]; vv[e] = vpre[e]; }
-                        if (valid) {
-                            if (j == pos) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) { kv[e] = k_new[gl * 8 + e]; vv[e] = v_new[gl * 8 + e]; }
-                            } else if (!first) {
-                                Vec<bf16_t>::load(kc + (size_t)j * hd + gl * 8, kv);
-                                Vec<bf16_t>::load(vc + (size_t)j * hd + gl * 8, vv);
-                            }
-                        }
-                        first = false;
 #pragma unroll
                         for (int g = 0; g < G; ++g) {
                             float d = 0.f;
@@ -474,6 +668,44 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                                 mrun[g] = mn;
                             }
                         }
+                    };
+                    const bool pre = att_next == li;     // the registers hold this layer's rows
+#pragma unroll
+                    for (int st = 0; st < ENG_KVST; ++st) {
+                        const int base = lo + gw * PPW + st * NSLOT;
+                        if (base < hi) {                 // wave-uniform
+                            const int j = base + grp;
+                            float kv[8], vv[8];
+                            if (j < hi && j == pos) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) { kv[e] = k_new[gl * 8 + e]; vv[e] = v_new[gl * 8 + e]; }
+                            } else if (pre) {
+                                Vec<bf16_t>::unpack(kpf[st], kv); Vec<bf16_t>::unpack(vpf[st], vv);
+                            } else if (j < hi) {
+                                Vec<bf16_t>::unpack(eng_ldg16<false>(kc + (size_t)j * hd + gl * 8), kv);
+                                Vec<bf16_t>::unpack(eng_ldg16<false>(vc + (size_t)j * hd + gl * 8), vv);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) { kv[e] = 0.f; vv[e] = 0.f; }
+                            }
+                            step(j, kv, vv);
+                        }
+                    }
+                    for (int base = lo + gw * PPW + ENG_KVST * NSLOT; base < hi; base += NSLOT) {   // long contexts
+                        const int j = base + grp;
+                        float kv[8], vv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { kv[e] = 0.f; vv[e] = 0.f; }
+                        if (j < hi) {
+                            if (j == pos) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) { kv[e] = k_new[gl * 8 + e]; vv[e] = v_new[gl * 8 + e]; }
+                            } else {
+                                Vec<bf16_t>::unpack(eng_ldg16<false>(kc + (size_t)j * hd + gl * 8), kv);
+                                Vec<bf16_t>::unpack(eng_ldg16<false>(vc + (size_t)j * hd + gl * 8), vv);
+                            }
+                        }
+                        step(j, kv, vv);
                     }
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
@@ -482,9 +714,9 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                         for (int e = 0; e < 8; ++e) acc_s[(size_t)(slot * G + g) * hd + gl * 8 + e] = acc[g][e];
                     }
                 }
-                __syncthreads();
-                if (wave < 4) {
-                    for (int idx = tid; idx < G * hd; idx += 256) {
+                eng_barrier();
+                if (gw >= 0) {
+                    for (int idx = atid; idx < G * hd; idx += 256) {
                         const int g = idx / hd, e = idx % hd;
                         float M = -INFINITY;
                         for (int s = 0; s < NSLOT; ++s) M = fmaxf(M, ml_s[(s * G + g) * 2]);
@@ -510,7 +742,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 // [split * hd / nsplit, (split + 1) * hd / nsplit) of its G heads.  An item = 4 consecutive elements of
                 // one head; lane 8 * i + s polls split c0 + s of item i (O[0..3], m, l = three 16-byte loads), the
                 // values cross to the item's first lane through LDS, which merges in split order.
-                if (p.nsplit > 1 && wave == 4) {
+                if (p.nsplit > 1 && gw == 3) {
                     const int epb = hd / p.nsplit;            // elements per workgroup and head (multiple of 4)
                     const int e4n = epb >> 2;
                     const int nitem = G * e4n;
@@ -534,6 +766,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                                                          C.y == tag32 && C.w == tag32);
                                 if (__all(ok)) break;
                                 if (sp.give_up(lane)) { alive = false; break; }
+                                __builtin_amdgcn_s_sleep(ENG_POLL_SLEEP);
                             }
                             if (!alive) break;
                             float* ms = mscr + lane * 6;
@@ -567,45 +800,43 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                             __builtin_amdgcn_wave_barrier();
                         }
                         if (alive && s8 == 0 && item_on) {
-                            unsigned* gy = p.gy + (size_t)li * HD + head * hd + e;
-                            eng_put(gy, 0, round_bf16(a0 / L), tag);
-                            eng_put(gy, 1, round_bf16(a1 / L), tag);
-                            eng_put(gy, 2, round_bf16(a2 / L), tag);
-                            eng_put(gy, 3, round_bf16(a3 / L), tag);
+                            unsigned* gy = p.gy + (size_t)li * HD + (size_t)a * (G * epb) + g * epb + (e - split * epb);
+                            eng_put4(gy, round_bf16(a0 / L), round_bf16(a1 / L), round_bf16(a2 / L), round_bf16(a3 / L), tag);
                         }
                     }
                 }
             }
+            {
+                // y is stored per attention workgroup: [kvh][split][g][hd / nsplit] (each 128-byte line written by one of them)
+                const int epb = hd / p.nsplit, ns = p.nsplit;
+                auto ymap = [=](int i) { const int a2 = i / (G * epb), r2 = i % (G * epb), g2 = r2 / epb, eo = r2 % epb;
+                                         return ((a2 / ns) * G + g2) * hd + (a2 % ns) * epb + eo; };
+                eng_gather(p.gy + (size_t)li * HD, layLin, 0, HD, tag, yS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 3, ymap);
+            }
+            eng_barrier(); if (*dead) break;                        // B2
+            // the K/V rows (and norm gains) of this workgroup's next attention turn start their trip now: the polls
+            // for x' wait at least a Wo phase anyway (vmcnt is in order: requested right after the partials they would
+            // sit in front of the merge polls and of the y polls)
+            if (a >= 0) kv_prefetch(li + 1);
+            const unsigned long long t_poll0 = p.stamps ? eng_rt() : 0ull;   // kept in a register: a store here would sit in front of the polls
+            eng_gather(p.gxb + (size_t)li * VSTR, layD, 0, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 4, EngIdent(),
+                       (p.stamps && gw == 0) ? p.stamps + ((size_t)b * p.n_layer + li) * 16 + 13 : nullptr);
+            const unsigned long long t_poll1 = p.stamps ? eng_rt() : 0ull;
+            eng_barrier(); if (*dead) break;                        // B3
+            if (p.stamps && tid == ENG_CW * 64) {
+                unsigned long long* q = p.stamps + ((size_t)b * p.n_layer + li) * 16;
+                q[10] = t_poll0; q[11] = t_poll1; q[12] = eng_rt();
+            }
+            eng_gather(p.gg + (size_t)li * VSTR, layF, 0, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 5);
+            eng_barrier(); if (*dead) break;                        // B4
         }
-
-        // ---- Wo + residual
-        if (gw >= 0) eng_gather(p.gy + (size_t)li * HD, HD, tag, yS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 3);
-        __syncthreads();
-        if (*dead) break;
-        eng_gemv<NTA, 1, SO, PRO_NONE, EPI_RESID>(wo, yS, HD, p.eps, l.bo, xA, p.gxb + (size_t)li * D, tag, nullptr, o_lo, o_hi, cw, lane);
-        eng_issue(wf, l.w13, l.ffn_norm, D, f_lo, f_hi, cw, lane, p.nt);
-
-        // ---- W13 + SwiGLU
-        if (gw >= 0) eng_gather(p.gxb + (size_t)li * D, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 4);
-        __syncthreads();
-        if (*dead) break;
-        eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, D, p.eps, nullptr, nullptr, p.gg + (size_t)li * F, tag, nullptr, f_lo, f_hi, cw, lane);
-        eng_issue(wd, l.w2, (const bf16_t*)nullptr, F, d_lo, d_hi, cw, lane, p.nt);
-
-        // ---- W2 + residual
-        if (gw >= 0) eng_gather(p.gg + (size_t)li * F, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 5);
-        __syncthreads();
-        if (*dead) break;
-        eng_gemv<NTF, 1, SO, PRO_NONE, EPI_RESID>(wd, gS, F, p.eps, nullptr, xB, p.gx + (size_t)(li + 1) * D, tag,
-                                                 li == p.n_layer - 1 ? p.x_out : nullptr, d_lo, d_hi, cw, lane);
-        if (li + 1 < p.n_layer)
-            eng_issue(wq, p.layers[li + 1].wqkv, p.layers[li + 1].attn_norm, D, q_lo, q_hi, cw, lane, p.nt);
-        // (the next layer's gather waits for a barrier before anyone overwrites xA: the residual reads above are done)
-        __syncthreads();
     }
 
     // ---- leave: the last workgroup out advances the epoch for the next launch
-    __syncthreads();
+    eng_barrier();
+    if (p.stamps && tid == 0 && b == 0) {   // shader clock of this launch = d(s_memtime) / d(s_memrealtime) x 100 MHz
+        p.stamps[14] = __builtin_amdgcn_s_memtime() - clk0; p.stamps[15] = eng_rt() - rt0;
+    }
     if (tid == 0) {
         const unsigned old = atomicAdd(p.ctl + ENG_CTL_EXIT, 1u);
         if (old + 1 == (unsigned)nb) {

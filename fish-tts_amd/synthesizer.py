@@ -303,9 +303,32 @@ class FishTTS:
 
         worker = threading.Thread(target=decoder_worker, daemon=True)
         worker.start()
+
+        def worker_gone() -> bool:
+            # the worker records its exception BEFORE its final put(None) (which may itself wait for queue space)
+            return bool(error_holder) or not worker.is_alive()
+
+        pending: List[Optional[bytes]] = []   # audio taken off the queue while a put was waiting, in order
+
+        def hand_over(item) -> bool:
+            """Puts item on the bounded codes queue without ever blocking on a stuck or dead worker: keeps draining
+            the audio queue meanwhile.  False = the worker is gone (its error is raised at the end)."""
+            while True:
+                if worker_gone():
+                    return False
+                try:
+                    codes_queue.put(item, timeout=0.005)
+                    return True
+                except queue.Full:
+                    pass
+                try:
+                    pending.append(audio_queue.get_nowait())
+                except queue.Empty:
+                    pass
+
         try:
             buffer, is_first_chunk, total_tokens = [], True, 0
-            tail_chunk, leftovers = None, []
+            tail_chunk, worker_ok = None, True
             with self._gen_lock:
                 for response in generate_long(engine=self._engine, tokenizer=self._tokenizer, text=text,
                                               max_new_tokens=kwargs.get("max_tokens", 2048),
@@ -322,17 +345,16 @@ class FishTTS:
                             buffer, total_tokens, is_first_chunk = [], 0, False
                             # Both queues are bounded.  The reference blocks in put() here and joins the worker before
                             # draining (synthesizer.py:556-578): harmless when the AR loop is the slow side, a deadlock
-                            # once it is faster than the codec (worker stuck on a full audio queue).  Keep draining.
-                            while True:
-                                try:
-                                    codes_queue.put(chunk, timeout=0.005)
-                                    break
-                                except queue.Full:
-                                    pass
-                                while not audio_queue.empty():
-                                    audio = audio_queue.get_nowait()
-                                    if audio is not None:
-                                        yield audio
+                            # once it is faster than the codec (worker stuck on a full audio queue).  Keep draining; and
+                            # stop generating when the worker has died (its exception is re-raised below, as the
+                            # reference does at synthesizer.py:583-584).
+                            worker_ok = hand_over(chunk)
+                            while pending:
+                                audio = pending.pop(0)
+                                if audio is not None:
+                                    yield audio
+                            if not worker_ok:
+                                break
                             while not audio_queue.empty():
                                 audio = audio_queue.get_nowait()
                                 if audio is not None:
@@ -342,24 +364,24 @@ class FishTTS:
                             tail_chunk = np.concatenate(buffer, axis=1)
                         break
         finally:
-            # hand over the tail and the stop mark without ever blocking on a stuck worker (the consumer may have
-            # abandoned the generator: then pending audio is dropped)
+            # hand over the tail and the stop mark (the consumer may have abandoned the generator: then pending audio
+            # is dropped); a dead worker takes nothing more
             for item in ([tail_chunk] if tail_chunk is not None else []) + [None]:
-                while True:
-                    try:
-                        codes_queue.put(item, timeout=0.005)
-                        break
-                    except queue.Full:
-                        pass
-                    try:
-                        leftovers.append(audio_queue.get_nowait())
-                    except queue.Empty:
-                        pass
-        for audio in leftovers:               # drained while handing over, in order
-            if audio is not None:
+                if not hand_over(item):
+                    break
+        got_end = False
+        for audio in pending:                 # drained while handing over, in order
+            if audio is None:
+                got_end = True
+            else:
                 yield audio
-        while None not in leftovers:          # the worker always ends with a None
-            audio = audio_queue.get()
+        while not got_end:                    # the worker always ends with a None
+            try:
+                audio = audio_queue.get(timeout=0.05)
+            except queue.Empty:
+                if not worker.is_alive():
+                    break
+                continue
             if audio is None:
                 break
             yield audio

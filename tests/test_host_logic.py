@@ -264,6 +264,53 @@ def test_stream_does_not_deadlock_when_ar_outruns_codec(monkeypatch):
     assert [len(c) // 2 for c in out] == [4] + [10] * 12 + [7]
 
 
+def test_stream_raises_and_frees_the_lock_when_the_decoder_worker_dies(monkeypatch):
+    """The decoder thread's exception must stop generation and reach the caller (synthesizer.py:522-523, 583-584)
+    instead of leaving the producer spinning on a queue nobody drains, and the generation lock must be free after."""
+    import threading
+    import fish_tts_amd as ft
+    import fish_tts_amd.generation as gen
+    from fish_tts_amd.synthesizer import _PrefillCache
+
+    produced = []
+
+    def fake_generate_long(**kw):
+        for i in range(2000):
+            produced.append(i)
+            yield gen.GenerateResponse(action="sample", codes=np.full((10, 1), i, dtype=np.int32), text=kw["text"])
+        yield gen.GenerateResponse(action="next")
+
+    synth = ft.FishTTS.__new__(ft.FishTTS)
+    synth._engine = synth._tokenizer = object()
+    synth._prefix_cache = None
+    synth._prefill_cache, synth._prefill_lock, synth._gen_lock = _PrefillCache(), threading.Lock(), threading.Lock()
+    calls = []
+
+    def failing_decode(codes):
+        calls.append(1)
+        if len(calls) == 2:
+            raise RuntimeError("codec exploded")
+        return np.asarray(codes)[0].astype(np.int16).tobytes()
+    synth._decode_to_pcm = failing_decode
+    monkeypatch.setattr(gen, "generate_long", fake_generate_long)
+    out, err = [], []
+
+    def run():
+        try:
+            out.extend(synth.synthesize_stream("x", chunk_tokens=10, min_first_chunk=4))
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(20)
+    assert not t.is_alive(), "synthesize_stream hangs after the decoder worker died"
+    assert len(err) == 1 and isinstance(err[0], RuntimeError) and "codec exploded" in str(err[0])
+    assert len(produced) < 200                      # generation stopped soon after the failure
+    assert synth._gen_lock.acquire(timeout=1)       # released
+    synth._gen_lock.release()
+    assert b"".join(out) == np.arange(4, dtype=np.int16).tobytes()   # the first chunk came through
+
+
 def test_batch_scheduler_on_a_fake_engine():
     """fish_tts_amd.batch.run_batch without a GPU: a fake engine that emits frame counters checks the host policy -
     longest budget first into the lowest slots, one lock-step pass for the initial first frames, refill of finished

@@ -117,6 +117,10 @@ __global__ __launch_bounds__(NW * 64) void edge_kernel(Params q) {
                 v.w = ntag | ((s * 2654435761u + (unsigned)(i + 3) + (unsigned)p) & 0xffffu);
                 asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(out + i), "v"(v) : "memory");
             }
+        } else if (q.wide_store == 2) {
+            // one granule per store instruction, from lane 0 of successive waves (what a row-per-wave epilogue does)
+            for (int i = lo + wave; i < hi; i += NW)
+                if (lane == 0) __hip_atomic_store((gu32*)(out + i), ntag | ((s * 2654435761u + (unsigned)i + (unsigned)p) & 0xffffu), RLX_AGENT);
         } else {
             for (int i = lo + tid; i < hi; i += NW * 64)
                 __hip_atomic_store((gu32*)(out + i), ntag | ((s * 2654435761u + (unsigned)i + (unsigned)p) & 0xffffu), RLX_AGENT);
@@ -223,14 +227,14 @@ int main() {
         fflush(stdout);
     };
 
-    for (int NW : {4, 8}) for (int sl : {0}) for (int ws : {0, 1}) {
+    for (int NW : {8}) for (int sl : {0}) for (int ws : {0, 2}) {
         char nm[128];
         Params q{}; q.sleep = sl; q.wide_store = ws;
         q.npat = 4;
         q.ph[0] = {0, 64, 1024, 2048}; q.ph[1] = {64, 96, 2048, 1024}; q.ph[2] = {96, 192, 1024, 3072}; q.ph[3] = {192, 256, 3072, 1024};
         snprintf(nm, sizeof nm, "roles 64/32/96/64 NW=%d sleep=%d wide_store=%d", NW, sl, ws); run(nm, q, NW);
         q.ph[0] = {0, 256, 1024, 2048}; q.ph[1] = {0, 256, 2048, 1024}; q.ph[2] = {0, 256, 1024, 3072}; q.ph[3] = {0, 256, 3072, 1024};
-        if (!ws) { snprintf(nm, sizeof nm, "all 256 CUs       NW=%d sleep=%d wide_store=%d", NW, sl, ws); run(nm, q, NW); }
+        if (ws != 1) { snprintf(nm, sizeof nm, "all 256 CUs       NW=%d sleep=%d wide_store=%d", NW, sl, ws); run(nm, q, NW); }
         q.ph[0] = {0, 16, 1024, 2048}; q.ph[1] = {16, 32, 2048, 1024}; q.ph[2] = {32, 48, 1024, 3072}; q.ph[3] = {48, 64, 3072, 1024};
         snprintf(nm, sizeof nm, "roles 16/16/16/16 NW=%d sleep=%d wide_store=%d", NW, sl, ws); run(nm, q, NW);
         q.npat = 1; q.ph[0] = {0, 64, 1024, 1024};

@@ -1,0 +1,136 @@
+// Timing harness for the persistent slow-stack engine (csrc/frame_engine.h) on synthetic weights at the s1-mini widths:
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -std=c++17 -Ifish-tts_amd/csrc tools/mb_engine.hip -o tools/bin/mb_engine
+//   tools/bin/mb_engine [n_layer=28] [pos=150] [nsplit=8]
+// Prints the kernel time per launch and, from the in-kernel s_memrealtime stamps of workgroup 0 and of one attention
+// workgroup, where a layer's time goes.  Correctness is NOT checked here (tests/test_engine_gpu.py does that).
+#include "frame_engine.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("ERR %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+using namespace ft;
+
+__global__ void fill_bf16(bf16_t* p, size_t n, unsigned seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = f32_to_bf16_bits(((float)(h & 0xffff) / 65536.0f - 0.5f) * scale);
+    }
+}
+__global__ void fill_rope(float* r, int n_pos, int hp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_pos * hp) { const int pos = i / hp, k = i % hp; const float a = pos * powf(1e6f, -(float)k / hp); r[2 * i] = round_bf16(cosf(a)); r[2 * i + 1] = round_bf16(sinf(a)); }
+}
+
+int main(int argc, char** argv) {
+    const int n_layer = argc > 1 ? atoi(argv[1]) : 28;
+    const int pos0 = argc > 2 ? atoi(argv[2]) : 150;
+    const int nsplit = argc > 3 ? atoi(argv[3]) : 8;
+    const int D = 1024, H = 16, Hkv = 8, hd = 128, F = 3072, HD = H * hd, qkvN = (H + 2 * Hkv) * hd, n_slots = 1024, V = 8192, ncb = 10, cbs = 4096;
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int nb = prop.multiProcessorCount;
+    printf("device %s, %d CUs; %d layers, pos %d, nsplit %d\n", prop.name, nb, n_layer, pos0, nsplit);
+    hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    auto balloc = [&](size_t n, unsigned seed, float scale) { bf16_t* p; CK(hipMalloc(&p, n * 2 + 64)); fill_bf16<<<1024, 256, 0, s>>>(p, n, seed, scale); return p; };
+    std::vector<EngLayer> hl(n_layer);
+    for (int i = 0; i < n_layer; ++i) {
+        EngLayer& l = hl[i];
+        l.wqkv = balloc((size_t)qkvN * D, 11 * i + 1, 0.06f); l.bqkv = nullptr; l.attn_norm = balloc(D, 11 * i + 2, 2.0f);
+        l.qn = balloc(hd, 11 * i + 3, 2.0f); l.kn = balloc(hd, 11 * i + 4, 2.0f); l.wo = balloc((size_t)D * HD, 11 * i + 5, 0.04f); l.bo = nullptr;
+        l.ffn_norm = balloc(D, 11 * i + 6, 2.0f); l.w13 = balloc((size_t)2 * F * D, 11 * i + 7, 0.06f); l.w2 = balloc((size_t)D * F, 11 * i + 8, 0.04f);
+        l.kc = balloc((size_t)Hkv * n_slots * hd, 11 * i + 9, 1.0f); l.vc = balloc((size_t)Hkv * n_slots * hd, 11 * i + 10, 1.0f);
+    }
+    EngLayer* dl; CK(hipMalloc(&dl, hl.size() * sizeof(EngLayer))); CK(hipMemcpy(dl, hl.data(), hl.size() * sizeof(EngLayer), hipMemcpyHostToDevice));
+    SlowEngP p{};
+    p.layers = dl; p.n_layer = n_layer; p.D = D; p.H = H; p.Hkv = Hkv; p.hd = hd; p.F = F; p.qkvN = qkvN; p.eps = 1e-6f; p.scale = 1.0f / sqrtf((float)hd);
+    p.emb = balloc((size_t)V * D, 901, 1.0f); p.cb_emb = balloc((size_t)ncb * cbs * D, 902, 1.0f);
+    int htok[11] = {5000, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10};
+    int* dtok; CK(hipMalloc(&dtok, sizeof htok)); CK(hipMemcpy(dtok, htok, sizeof htok, hipMemcpyHostToDevice));
+    p.toks = dtok; p.tok_row_stride = 1; p.ncb = ncb; p.cbsize = cbs; p.vocab = V; p.sem_begin = 4000; p.sem_end = 8095; p.scale_cb = 1; p.inv_div = sqrtf(11.f);
+    float* rope; CK(hipMalloc(&rope, (size_t)n_slots * hd * 4)); fill_rope<<<(n_slots * hd / 2 + 255) / 256, 256, 0, s>>>(rope, n_slots, hd / 2);
+    p.rope = rope;
+    int* dpos; CK(hipMalloc(&dpos, 4)); CK(hipMemcpy(dpos, &pos0, 4, hipMemcpyHostToDevice));
+    p.pos = dpos; p.pos_off = 0; p.n_slots = n_slots; p.nsplit = nsplit; p.cache_off = 0;
+    auto zalloc = [&](size_t bytes) { void* q; CK(hipMalloc(&q, bytes)); CK(hipMemset(q, 0, bytes)); return q; };
+    // every hand-off buffer out of ONE large allocation (one TLB fragment instead of six small mappings)
+    char* pool = (char*)zalloc((size_t)64 << 20);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { char* q = pool + off; off += (bytes + 4095) & ~(size_t)4095; return q; };
+    const size_t VB = (size_t)nb * ENG_LINE * 4;   // bytes per padded vector buffer
+    p.gx = (unsigned*)carve((size_t)(n_layer + 1) * VB); p.gqkv = (unsigned*)carve((size_t)n_layer * VB);
+    p.gy = (unsigned*)carve((size_t)n_layer * HD * 4); p.gxb = (unsigned*)carve((size_t)n_layer * VB); p.gg = (unsigned*)carve((size_t)n_layer * VB);
+    p.gpart = (unsigned long long*)carve((size_t)n_layer * H * 32 * (hd + 2) * 8);
+    p.ctl = (unsigned*)carve(ENG_CTL_WORDS * 4);
+    float* xo; CK(hipMalloc(&xo, D * 4)); p.x_out = xo; p.nt = 1;
+    unsigned long long* stamps = (unsigned long long*)zalloc((size_t)nb * n_layer * 16 * 8);
+    const size_t lds = 82 * 1024;
+    CK(hipFuncSetAttribute((const void*)slow_engine_kernel<2, 4, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int stamp_mode = argc > 4 ? atoi(argv[4]) : 1;    // which mode's stamps are analysed: 1 = with weights, 2 = without
+    for (int mode = 0; mode < 3; ++mode) {
+        p.stamps = mode == stamp_mode ? stamps : nullptr;
+        p.nt = mode == 2 ? 3 : 1;
+        float best = 1e9f, sum = 0.f; const int reps = 20;
+        for (int r = 0; r < reps + 3; ++r) {
+            CK(hipEventRecord(e0, s));
+            slow_engine_kernel<2, 4, 6, 2><<<nb, ENG_THREADS, lds, s>>>(p);
+            CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 3) { best = std::min(best, ms); sum += ms; }
+        }
+        unsigned h[4]; CK(hipMemcpy(h, p.ctl, 16, hipMemcpyDeviceToHost));
+        printf("%-22s: %.1f us per launch (best %.1f) = %.2f us per layer%s\n", mode == 0 ? "plain" : mode == 1 ? "with stamps" : "NO weight loads", sum / reps * 1e3, best * 1e3,
+               sum / reps * 1e3 / n_layer, h[ENG_CTL_ABORT] ? "  ABORTED" : "");
+        if (h[ENG_CTL_ABORT]) { printf("abort at phase %u\n", h[ENG_CTL_WHERE]); return 1; }
+    }
+    std::vector<unsigned long long> st((size_t)nb * n_layer * 16);
+    CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
+    const char* names[13] = {"x gathered", "QKV rows done", "attention section left", "y gathered", "Wo rows done", "x' gathered", "W13 rows done", "g gathered", "W2 rows done", "W2 re-issued (mode 2: Wo granule stores acknowledged)", "gw0: starts polling x'", "gw0: x' pieces seen", "gw0: past barrier B3"};
+    for (int b : {0, 100, nb - 1}) {
+        double seg[9] = {0};
+        int cnt = 0;
+        for (int li = 2; li < n_layer; ++li) {
+            const unsigned long long* a = &st[((size_t)b * n_layer + li) * 16];
+            const unsigned long long prev = st[((size_t)b * n_layer + li - 1) * 16 + 8];
+            seg[0] += (double)(a[0] - prev);
+            for (int k = 1; k < 9; ++k) seg[k] += (double)(a[k] - a[k - 1]);
+            ++cnt;
+        }
+        if (!cnt) continue;
+        printf("workgroup %3d, average over layers 2.. (us since the previous stamp):\n", b);
+        double tot = 0;
+        for (int k = 0; k < 9; ++k) { printf("   %-24s %6.2f\n", names[k], seg[k] / cnt / 100.0); tot += seg[k] / cnt / 100.0; }
+        printf("   %-24s %6.2f\n", "layer", tot);
+    }
+    // chip-wide view (s_memrealtime is one clock for all CUs): per stamp, the earliest / median / latest workgroup,
+    // relative to the moment the LAST workgroup finished the previous layer's W2
+    {
+        double lo[13] = {0}, md[13] = {0}, hi[13] = {0};
+        int cnt = 0;
+        std::vector<unsigned long long> v(nb);
+        for (int li = 4; li < n_layer; ++li) {
+            unsigned long long t0 = 0;
+            for (int b = 0; b < nb; ++b) t0 = std::max(t0, st[((size_t)b * n_layer + li - 1) * 16 + 8]);
+            for (int k = 0; k < 13; ++k) {
+                for (int b = 0; b < nb; ++b) v[b] = st[((size_t)b * n_layer + li) * 16 + k];
+                std::sort(v.begin(), v.end());
+                lo[k] += (double)v[0] - (double)t0; md[k] += (double)v[nb / 2] - (double)t0; hi[k] += (double)v[nb - 1] - (double)t0;
+            }
+            ++cnt;
+        }
+        printf("chip-wide, us after the last workgroup finished the previous layer (earliest / median / latest workgroup):\n");
+        for (int k = 0; k < 13; ++k) printf("   %-24s %7.2f %7.2f %7.2f\n", names[k], lo[k] / cnt / 100.0, md[k] / cnt / 100.0, hi[k] / cnt / 100.0);
+    }
+    printf("shader clock during the launch: %.2f GHz\n", (double)st[14] / (double)st[15] * 0.1);
+    {   // the x' gather of gw0: first-pass round trip, passes needed
+        double rtt = 0, nf = 0, nl = 0; int cnt = 0;
+        for (int li = 4; li < n_layer; ++li) for (int b = 0; b < nb; ++b) {
+            const unsigned long long* a = &st[((size_t)b * n_layer + li) * 16];
+            if (b == 0) continue; rtt += (double)(a[13] - a[10]); nf += (double)a[14]; nl += (double)a[15]; ++cnt;
+        }
+        printf("x' gather by gw0: first full pass returned %.2f us after polling began; %.2f full passes, %.2f single-piece polls per gather\n",
+               rtt / cnt / 100.0, nf / cnt, nl / cnt);
+    }
+    return 0;
+}
