@@ -108,7 +108,7 @@ struct ft_ctx {
     unsigned long long* eng_gpart = nullptr;
     unsigned* eng_fast_g = nullptr;   // granule buffers of the fast stack (one allocation)
     unsigned* eng_ctl = nullptr;
-    size_t eng_lds_slow = 0, eng_lds_fast = 0;
+    size_t eng_lds_slow = 0, eng_lds_fast = 0, eng_fast_words = 0;
 
     std::map<int, hipGraphExec_t> graphs;
 

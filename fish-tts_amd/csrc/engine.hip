@@ -466,6 +466,37 @@ static ft_status eng_setup(ft_ctx* ctx) {
     FT_HIP(ctx, hipFuncSetAttribute((const void*)slow_engine_kernel<2, 4, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)ctx->eng_lds_slow));
     ctx->eng_on = true;
+
+    // ---- fast codebook loop
+    const int HDf = c.fast_n_head * c.fast_head_dim;
+    const int fqkvN = (c.fast_n_head + 2 * c.fast_n_local_heads) * c.fast_head_dim;
+    const bool fast_ok = !getenv("FT_NO_FAST_ENGINE") && c.fast_dim == 1024 && HDf == 1024 && c.fast_intermediate_size == 3072 &&
+                         c.fast_head_dim <= 128 && c.fast_n_head % c.fast_n_local_heads == 0 && c.n_fast_layer >= 1 &&
+                         c.num_codebooks >= 2 && c.num_codebooks <= 10 && fqkvN % (4 * nb) == 0 && ctx->fastV % (4 * nb) == 0 &&
+                         per(fqkvN) <= ENG_FQ * ENG_CW && per(c.fast_dim) <= ENG_FO * ENG_CW && per(c.fast_intermediate_size) <= ENG_FF * ENG_CW &&
+                         per(ctx->fastV) <= ENG_FO * ENG_CW && per(fqkvN) <= ENG_LINE && ctx->fastV <= 1024 && c.codebook_size <= 65536 &&
+                         !ctx->force_block_sampler && !ctx->wave_sampler;
+    if (!fast_ok) return FT_OK;
+    std::vector<EngLayer> hf(c.n_fast_layer);
+    for (int i = 0; i < c.n_fast_layer; ++i) {
+        const FtLayer& l = ctx->flayers[i];
+        hf[i] = EngLayer{(const bf16_t*)l.wqkv, (const bf16_t*)l.bqkv, (const bf16_t*)l.attn_norm, (const bf16_t*)l.qn,
+                         (const bf16_t*)l.kn, (const bf16_t*)l.wo, (const bf16_t*)l.bo, (const bf16_t*)l.ffn_norm,
+                         (const bf16_t*)l.w13, (const bf16_t*)l.w2, nullptr, nullptr};
+    }
+    FT_HIP(ctx, hipMalloc((void**)&ctx->eng_flayers, hf.size() * sizeof(EngLayer)));
+    FT_HIP(ctx, hipMemcpy(ctx->eng_flayers, hf.data(), hf.size() * sizeof(EngLayer), hipMemcpyHostToDevice));
+    const size_t nLf = c.n_fast_layer;
+    // [2 parities]: gx (nLf + 1), gqkv, gxb, gg (nLf each), glog (1); then one line per codebook for the drawn codes
+    ctx->eng_fast_words = (2 * ((nLf + 1) + 3 * nLf + 1)) * (VB / 4) + (size_t)c.num_codebooks * ENG_LINE;
+    FT_TRY(zalloc((void**)&ctx->eng_fast_g, ctx->eng_fast_words * 4));
+    size_t ff = (size_t)c.fast_dim * 2 + fqkvN + HDf + c.fast_intermediate_size + ctx->fastV + ENG_MAX_OUT + 8 + 32 + 32 + 12 + 2048 + 4 + 4 + 16;
+    ctx->eng_lds_fast = ff * sizeof(float) + (size_t)nLf * 2 * c.num_codebooks * c.fast_n_local_heads * c.fast_head_dim * 2 + 64;
+    if (ctx->eng_lds_fast > 160 * 1024) return FT_OK;
+    ctx->eng_lds_fast = std::max(ctx->eng_lds_fast, (size_t)82 * 1024);
+    FT_HIP(ctx, hipFuncSetAttribute((const void*)fast_engine_kernel<2, 2, 6, 10>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)ctx->eng_lds_fast));
+    ctx->eng_fast_on = true;
     return FT_OK;
 }
 
@@ -511,6 +542,48 @@ static bool eng_slow_ok(const Launch& L) {
     const ft_ctx* ctx = L.ctx;
     return ctx->eng_on && L.M == 1 && !L.gemv_only && !ctx->prof && ctx->c.n_local_heads * ctx->nsplit <= ctx->eng_nb &&
            ctx->c.head_dim % (4 * ctx->nsplit) == 0;
+}
+
+static bool eng_fast_ok(const Launch& L) {
+    const ft_ctx* ctx = L.ctx;
+    return ctx->eng_fast_on && L.M == 1 && !L.gemv_only && !ctx->prof && !ctx->fork_fast0;
+}
+
+// The whole codebook loop of one frame (steps 0 .. num_codebooks-1 with their draws) as one launch; runs after the
+// vocabulary head + semantic draw launches, which leave the hidden state, the first code's embedding and tokn[0..1].
+static void enqueue_fast_engine(Launch& L) {
+    ft_ctx* ctx = L.ctx;
+    const ft_ar_config& c = ctx->c;
+    const int m0 = L.m0, R = c.num_codebooks + 1, nb = ctx->eng_nb;
+    const size_t nLf = c.n_fast_layer, VW = (size_t)nb * ENG_LINE;
+    FastEngP p{};
+    p.layers = ctx->eng_flayers; p.n_layer = c.n_fast_layer; p.ncb = c.num_codebooks;
+    p.D = c.fast_dim; p.H = c.fast_n_head; p.Hkv = c.fast_n_local_heads; p.hd = c.fast_head_dim; p.F = c.fast_intermediate_size;
+    p.qkvN = (c.fast_n_head + 2 * c.fast_n_local_heads) * c.fast_head_dim; p.V = ctx->fastV;
+    p.eps = c.norm_eps; p.scale = (float)(1.0 / sqrt((double)c.fast_head_dim));
+    p.rope = ctx->frope; p.fast_norm = (const bf16_t*)ctx->fast_norm; p.fast_out = (const bf16_t*)ctx->fast_out;
+    p.fast_emb = (const bf16_t*)ctx->fast_emb;
+    p.hid = ctx->hid + (size_t)m0 * c.fast_dim; p.femb = ctx->femb + (size_t)m0 * c.fast_dim;
+    unsigned* g = ctx->eng_fast_g;
+    p.gx = g; g += 2 * (nLf + 1) * VW;
+    p.gqkv = g; g += 2 * nLf * VW;
+    p.gxb = g; g += 2 * nLf * VW;
+    p.gg = g; g += 2 * nLf * VW;
+    p.glog = g; g += 2 * VW;
+    p.gcode = g;
+    p.ctl = ctx->eng_ctl;
+    SampP s{};
+    s.logits = nullptr; s.ldl = ctx->fastV; s.V = ctx->fastV;
+    s.ctl = ctx->d_ctl + m0; s.tokn = ctx->d_tokn + (size_t)m0 * R; s.seq = ctx->d_seq + (size_t)m0 * R * ctx->cap;
+    s.cap = ctx->cap; s.nf = ctx->d_nf + m0; s.cb = 1; s.ncb = c.num_codebooks; s.sem_begin = c.semantic_begin_id;
+    s.im_end = c.im_end_id; s.cbsize = c.codebook_size; s.fast_emb = ctx->fast_emb;
+    s.femb = ctx->femb + (size_t)m0 * c.fast_dim; s.Df = c.fast_dim; s.noise = ctx->noise;
+    s.noise_row_len = ctx->noise_row_len; s.noise_rows = ctx->noise_rows; s.noise_off = 0; s.last = 0;
+    s.tok = ctx->d_tok + (size_t)m0 * R; s.pos = ctx->d_pos + m0; s.done = ctx->d_done + m0;
+    p.samp = s;
+    p.noise_cb_stride = ctx->fastV; p.noise_off1 = c.vocab_size;
+    fast_engine_kernel<2, 2, 6, 10><<<nb, ENG_THREADS, ctx->eng_lds_fast, L.s>>>(p);
+    L.chk();
 }
 
 static void enqueue_slow_engine(Launch& L, const int* toks, long tok_row_stride, long tok_m_stride, int col) {
@@ -1004,6 +1077,7 @@ static void enqueue_frame_tail(Launch& L) {
     }
     enqueue_head<WT, ROUND>(L);
     enqueue_sample<WT, ROUND>(L, 0, ncb == 1);
+    if (ROUND && !fork && eng_fast_ok(L)) { enqueue_fast_engine(L); return; }
     if (fork) hipStreamWaitEvent(L.s, ctx->ev_join, 0);
     else enqueue_fast_step<WT, ROUND>(L, 0);
     for (int cb = 1; cb < ncb; ++cb) enqueue_fast_step<WT, ROUND>(L, cb);

@@ -219,7 +219,7 @@ struct EngW {
     U4 gain[NT];
 };
 
-template <int NT, int RPU, int MAXS>
+template <bool NTL = true, int NT, int RPU, int MAXS>
 __device__ __forceinline__ void eng_issue(EngW<NT, RPU, MAXS>& r, const bf16_t* W, const bf16_t* gain, int K, int u_lo, int u_hi,
                                           int cw, int lane, int nt) {
     // every compute wave issues the same number of loads on every path (units past the workgroup's last one re-read
@@ -232,7 +232,7 @@ __device__ __forceinline__ void eng_issue(EngW<NT, RPU, MAXS>& r, const bf16_t* 
         for (int rr = 0; rr < RPU; ++rr)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                r.w[s][rr][t] = (nt & 2) ? U4{0u, 0u, 0u, 0u} : eng_ldg16<true>(W + (size_t)(u * RPU + rr) * K + t * 512 + lane * 8);
+                r.w[s][rr][t] = (nt & 2) ? U4{0u, 0u, 0u, 0u} : eng_ldg16<NTL>(W + (size_t)(u * RPU + rr) * K + t * 512 + lane * 8);
             }
     }
     if (gain) {
@@ -837,6 +837,535 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     if (p.stamps && tid == 0 && b == 0) {   // shader clock of this launch = d(s_memtime) / d(s_memrealtime) x 100 MHz
         p.stamps[14] = __builtin_amdgcn_s_memtime() - clk0; p.stamps[15] = eng_rt() - rt0;
     }
+    if (tid == 0) {
+        const unsigned old = atomicAdd(p.ctl + ENG_CTL_EXIT, 1u);
+        if (old + 1 == (unsigned)nb) {
+            __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_EXIT), 0u, ENG_RLX);
+            __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_EPOCH), epoch + ENG_EPOCH_STEP, ENG_RLX);
+        }
+    }
+}
+
+// ==========================================================================================
+// Fast codebook loop (inference.py:115-149, llama.py:561-580): num_codebooks steps of n_fast_layer blocks, the
+// 1024-row codebook head and the draw of each codebook, ONE launch.
+// Per step and layer: [x] -> QKV -> every workgroup rebuilds the (<= num_codebooks positions) attention for all heads
+// from the gathered q/k/v, its K/V history kept in its own LDS -> Wo + residual -> [x'] -> W13 + SwiGLU -> [g] ->
+// W2 + residual -> [x''].  After the last layer (steps >= 1): fast_norm + head rows -> [logits] -> ONE workgroup
+// draws the code (sample_small_kernel's arithmetic on its four gathering waves) -> [code] -> every workgroup
+// reads that code's embedding row as the next step's input.
+// Hand-off buffers are reused by the steps, double-buffered by step parity (step 1 does not wait for a draw, so a
+// fast workgroup may start it while a slow one still reads step 0's vectors); tags are epoch + step.
+// ==========================================================================================
+struct FastEngP {
+    const EngLayer* layers;       // fast layers (kc / vc unused)
+    int n_layer, ncb;
+    int D, H, Hkv, hd, F, qkvN, V;     // V = rows of the head that are used (min(1024, codebook_size))
+    float eps, scale;
+    const float* rope;            // [ncb][hd/2][2]
+    const bf16_t* fast_norm; const bf16_t* fast_out; const bf16_t* fast_emb;
+    const float* hid;             // plain f32 [D]: step 0 input (the slow stack's pre-norm hidden state)
+    const float* femb;            // plain f32 [D]: step 1 input (embedding of the semantic code, left by the slow draw)
+    // hand-off buffers, each [2 parities][...]
+    unsigned* gx;                 // [2][n_layer + 1][nb lines]  layer inputs / stack output
+    unsigned* gqkv;               // [2][n_layer][nb lines]
+    unsigned* gxb;                // [2][n_layer][nb lines]
+    unsigned* gg;                 // [2][n_layer][nb lines]
+    unsigned* glog;               // [2][nb lines]
+    unsigned* gcode;              // [ncb][ENG_LINE]
+    unsigned* ctl;
+    SampP samp;                   // sampling state (cb, noise_off, last are set per step in the kernel)
+    long noise_cb_stride;         // fastV
+    long noise_off1;              // offset of codebook 1's noise in a row (vocab_size)
+};
+
+constexpr int ENG_FQ = 2, ENG_FF = 3, ENG_FO = 1;   // units per compute wave: QKV 8 rows -> 2, W13 12 pairs -> 3, Wo / W2 / head 4 rows -> 1
+
+// barrier among the four gathering waves only (LDS counter, never reset)
+struct EngSub {
+    int* count;
+    int phase;
+    __device__ __forceinline__ void sync(int lane) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        ++phase;
+        if (lane == 0) __hip_atomic_fetch_add((eng_lds_int)count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load((eng_lds_int)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < phase * ENG_GW) __builtin_amdgcn_s_sleep(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
+};
+
+// The attention of one fast layer at codebook position c for the heads h = w, w + nw, .. (fast_attn_kernel's arithmetic:
+// one wave per head, lane d owns dimension d (and d + 64)); q/k/v of this position come from qkvS (LDS, f32), the
+// earlier positions' K/V from kvS (LDS, bf16 bits; row j of layer-local cache: [j][Hkv * hd] K then V).
+template <int MAXCB>
+__device__ __forceinline__ void eng_fast_attn(const float* qkvS, bf16_t* kS, bf16_t* vS, float* yS, const bf16_t* qn, const bf16_t* kn,
+                                              const float* rope, int c, int H, int Hkv, int hd, float eps, float scale, int w, int nw,
+                                              int lane) {
+    const int hp = hd >> 1, G = H / Hkv, KVW = Hkv * hd;
+    constexpr int EPL = 2;
+    for (int h = w; h < H; h += nw) {
+        const int kvh = h / G;
+        // (earlier positions' K/V rows are read from LDS where they are used: keeping all of them in registers beside the
+        // compute waves' weight rows does not fit)
+        auto ldk = [&](int j, int e) { const int d = lane + 64 * e; return d < hd ? bf16_bits_to_f32(kS[(size_t)j * KVW + kvh * hd + d]) : 0.f; };
+        auto ldv = [&](int j, int e) { const int d = lane + 64 * e; return d < hd ? bf16_bits_to_f32(vS[(size_t)j * KVW + kvh * hd + d]) : 0.f; };
+        float q[EPL], kx[EPL], vx[EPL], cs[EPL], sn[EPL], gq[EPL], gk[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int d = lane + 64 * e;
+            const bool on = d < hd;
+            q[e] = on ? qkvS[(size_t)h * hd + d] : 0.f;
+            kx[e] = on ? qkvS[(size_t)(H + kvh) * hd + d] : 0.f;
+            vx[e] = on ? qkvS[(size_t)(H + Hkv + kvh) * hd + d] : 0.f;
+            cs[e] = on ? rope[((size_t)c * hp + (d >> 1)) * 2] : 1.f;
+            sn[e] = on ? rope[((size_t)c * hp + (d >> 1)) * 2 + 1] : 0.f;
+            gq[e] = (on && qn) ? eng_ldg_bf16(qn, d) : 1.f;
+            gk[e] = (on && kn) ? eng_ldg_bf16(kn, d) : 1.f;
+        }
+        if (qn) {
+            const float ss = wave_sum(q[0] * q[0] + q[1] * q[1]);
+            const float inv = rsqrt_exact(ss / (float)hd + eps);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) q[e] = round_bf16((q[e] * inv) * gq[e]);
+        }
+        if (kn) {
+            const float ss = wave_sum(kx[0] * kx[0] + kx[1] * kx[1]);
+            const float inv = rsqrt_exact(ss / (float)hd + eps);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) kx[e] = round_bf16((kx[e] * inv) * gk[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const float qo = dpp_f<DPP_XOR1>(q[e]), ko = dpp_f<DPP_XOR1>(kx[e]);
+            const bool even = (lane & 1) == 0;
+            q[e] = round_bf16(even ? q[e] * cs[e] - qo * sn[e] : q[e] * cs[e] + qo * sn[e]);
+            kx[e] = round_bf16(even ? kx[e] * cs[e] - ko * sn[e] : kx[e] * cs[e] + ko * sn[e]);
+        }
+        if (h % G == 0) {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int d = lane + 64 * e;
+                if (d < hd) { kS[(size_t)c * KVW + kvh * hd + d] = f32_to_bf16_bits(kx[e]); vS[(size_t)c * KVW + kvh * hd + d] = f32_to_bf16_bits(vx[e]); }
+            }
+        }
+        float sc[MAXCB];
+#pragma unroll
+        for (int j = 0; j < MAXCB; ++j) {
+            if (j <= c) {
+                const float k0 = j == c ? kx[0] : ldk(j, 0), k1 = j == c ? kx[1] : ldk(j, 1);
+                const float d = wave_sum(fmaf(q[1], k1, q[0] * k0));
+                sc[j] = round_bf16(round_bf16(d) * scale);
+            } else {
+                sc[j] = -INFINITY;
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < MAXCB; ++j) mx = fmaxf(mx, sc[j]);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXCB; ++j) {
+            if (j <= c) { sc[j] = expf(sc[j] - mx); sum += sc[j]; } else sc[j] = 0.f;
+        }
+        float o[EPL] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < MAXCB; ++j) {
+            if (j <= c) {
+                const float pj = round_bf16(sc[j] / sum);
+                o[0] = fmaf(pj, j == c ? vx[0] : ldv(j, 0), o[0]);
+                o[1] = fmaf(pj, j == c ? vx[1] : ldv(j, 1), o[1]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int d = lane + 64 * e;
+            if (d < hd) yS[(size_t)h * hd + d] = round_bf16(o[e]);
+        }
+    }
+}
+
+// The draw of one codebook from V <= 1024 logits in LDS by the four gathering waves (256 threads): sample_small_kernel's
+// arithmetic (ar_kernels.h), its workgroup barriers replaced by the four-wave barrier.  Returns the drawn index.
+struct EngSampLds {
+    float* redbuf;   // [8]
+    int* pen_id;     // [32]
+    float* pen_val;  // [32]
+    float* amv;      // [4]
+    int* ami;        // [4]
+    int* wcnt;       // [4]
+    float* prL;      // [1024]
+    uint32_t* keyL;  // [1024]
+    uint32_t* cut;   // [3]: k, nk, all
+};
+__device__ __forceinline__ int eng_sample_small(const SampP& p, const float* L, const EngSampLds& S, EngSub& sub, int tid, int lane, int wave) {
+    const int V = p.V;
+    const RowCtl ctl = p.ctl[0];
+    const int nfv = p.nf[0];
+    const int R = p.ncb + 1;
+    const int* seq = p.seq;
+    int red_phase = 0;
+    auto red_sum = [&](float v) {
+        v = wave_sum(v);
+        float* slot = S.redbuf + 4 * (red_phase & 1);
+        ++red_phase;
+        if (lane == 0) slot[wave] = v;
+        sub.sync(lane);
+        return ((slot[0] + slot[1]) + slot[2]) + slot[3];
+    };
+    const int i0 = 4 * tid;
+    float l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) l[e] = (i0 + e) < V ? L[i0 + e] : -INFINITY;
+    if (nfv > 0) {
+        const int it = nfv - 1;
+        const int ws = it < 16 ? 0 : it - 16;
+        const int npen = p.cb == 0 ? R : 16;
+        if (tid < npen) {
+            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
+            S.pen_id[tid] = -1;
+            if (id >= 0 && id < V) {
+                const float sv = L[id];
+                S.pen_id[tid] = id;
+                S.pen_val[tid] = sv < 0.f ? round_bf16(sv * ctl.rep) : round_bf16(sv / ctl.rep);
+            }
+        }
+        sub.sync(lane);
+        for (int k = 0; k < npen; ++k) {
+            const int id = S.pen_id[k];
+            if (id >= i0 && id < i0 + 4) {
+                const float nv = S.pen_val[k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (i0 + e == id) l[e] = nv;
+            }
+        }
+    }
+    if (p.cb == 0 && ctl.ban_eos && p.im_end < V) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (i0 + e == p.im_end) l[e] = -INFINITY;
+    }
+    auto block_best = [&](ArgMax a) {
+        a = wave_argmax(a);
+        sub.sync(lane);
+        if (lane == 0) { S.amv[wave] = a.v; S.ami[wave] = a.i; }
+        sub.sync(lane);
+        ArgMax t{S.amv[0], S.ami[0]};
+        for (int w = 1; w < 4; ++w) t = better(t, ArgMax{S.amv[w], S.ami[w]});
+        return t;
+    };
+    ArgMax am{-INFINITY, 0x7fffffff};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (i0 + e < V) am = better(am, ArgMax{l[e], i0 + e});
+    am = block_best(am);
+    const float Lmax = am.v;
+    float ex[4], z = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ex[e] = (i0 + e) < V ? expf(l[e] - Lmax) : 0.f; z += ex[e]; }
+    const float Z = red_sum(z);
+    const float tp = round_bf16(ctl.top_p);
+    auto removed = [&](float cum) { return round_bf16(cum) > tp; };
+    constexpr uint32_t cmask = 0xffff0000u;
+    uint32_t key[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool v = (i0 + e) < V;
+        key[e] = v ? (order_key(l[e]) & cmask) : 0u;
+        S.prL[i0 + e] = v ? round_bf16(ex[e] / Z) : 0.f;
+        S.keyL[i0 + e] = key[e];
+    }
+    const bool only_top = removed(round_bf16(1.0f / Z));
+    int winner = am.i;
+    if (!only_top) {
+        sub.sync(lane);
+        if (wave == 0) {
+            float pr[16];
+            uint32_t ky[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { pr[e] = S.prL[lane + 64 * e]; ky[e] = S.keyL[lane + 64 * e]; }
+            float tot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tot += pr[e];
+            tot = wave_sum(tot);
+            uint32_t kstar = 0;
+            int nk = 0, all_kept = 0;
+            if (!removed(tot)) {
+                all_kept = 1;
+            } else {
+                for (int bit = 31; bit >= 16; --bit) {
+                    const uint32_t cand = kstar | (1u << bit);
+                    float ms = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) ms += ky[e] >= cand ? pr[e] : 0.f;
+                    if (removed(wave_sum(ms))) kstar = cand;
+                }
+                float above = 0.f, cnt = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (ky[e] > kstar) above += pr[e];
+                    else if (ky[e] == kstar && (lane + 64 * e) < V) cnt += 1.f;
+                }
+                above = wave_sum(above);
+                const int icnt = (int)wave_sum(cnt);
+                const uint32_t ubits = (kstar & 0x80000000u) ? (kstar & 0x7fffffffu) : ~(kstar | ~cmask);
+                const float pk = round_bf16(expf(__uint_as_float(ubits) - Lmax) / Z);
+                int lo_n = 0, hi_n = icnt;
+                while (lo_n < hi_n) {
+                    const int mid = (lo_n + hi_n + 1) >> 1;
+                    if (removed(fmaf((float)mid, pk, above))) hi_n = mid - 1; else lo_n = mid;
+                }
+                nk = lo_n;
+            }
+            if (lane == 0) { S.cut[0] = kstar; S.cut[1] = (uint32_t)nk; S.cut[2] = (uint32_t)all_kept; }
+        }
+        sub.sync(lane);
+        const uint32_t kstar = S.cut[0];
+        const int nk = (int)S.cut[1];
+        const bool all_kept = S.cut[2] != 0;
+        const float Tc = fmaxf(ctl.temperature, 1e-5f);
+        const float Mt = round_bf16(Lmax / Tc);
+        bool mem[4];
+        int mine = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { mem[e] = (i0 + e) < V && !all_kept && key[e] == kstar; mine += mem[e] ? 1 : 0; }
+        int below = 0, wtot = 0;
+        const unsigned long long lower = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int c = 1; c <= 4; ++c) {
+            const unsigned long long bal = __ballot(mine >= c);
+            below += __popcll(bal & lower);
+            wtot += __popcll(bal);
+        }
+        if (lane == 0) S.wcnt[wave] = wtot;
+        sub.sync(lane);
+        int rank = below;
+        for (int w = 0; w < wave; ++w) rank += S.wcnt[w];
+        bool keep[4];
+        float et[4], z2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            keep[e] = (i0 + e) < V && (all_kept || key[e] > kstar || (mem[e] && rank < nk));
+            rank += mem[e] ? 1 : 0;
+            et[e] = keep[e] ? expf(round_bf16(l[e] / Tc) - Mt) : 0.f;
+            z2 += et[e];
+        }
+        const float Z2 = red_sum(z2);
+        const float* qrow = nullptr;
+        if (p.noise && nfv < p.noise_rows) qrow = p.noise + (size_t)nfv * p.noise_row_len + p.noise_off;
+        float q4[4];
+        draw_noise4(p, ctl, qrow, i0, nfv, 0, V, q4);
+        ArgMax best{-1.f, 0x7fffffff};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (i0 + e < V) {
+                const float prob = keep[e] ? round_bf16(et[e] / Z2) : 0.f;
+                best = better(best, ArgMax{round_bf16(prob / round_bf16(q4[e])), i0 + e});
+            }
+        }
+        winner = block_best(best).i;
+    }
+    sub.sync(lane);
+    return winner;
+}
+
+template <int NTD, int NTA, int NTF, int MAXCB>
+__global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
+    constexpr int SQ = ENG_FQ, SF = ENG_FF, SO = ENG_FO;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, nb = gridDim.x;
+    const int cw = wave, gw = wave - ENG_CW, atid = tid - ENG_CW * 64;
+    const int D = p.D, F = p.F, hd = p.hd, HD = p.H * hd, KVW = p.Hkv * hd;
+    float* xA = smem;                          // layer input
+    float* qkvS = xA + D;                      // gathered q, k, v of this position
+    float* yS = qkvS + p.qkvN;                 // attention output
+    float* xB = yS + HD;                       // x' = x + Wo y
+    float* gS = xB + D;                        // SwiGLU output
+    float* logS = gS + F;                      // [V] logits (drawing workgroup)
+    float* outS = logS + p.V;                  // [ENG_MAX_OUT]
+    float* redbuf = outS + ENG_MAX_OUT;        // sampling scratch ...
+    int* pen_id = reinterpret_cast<int*>(redbuf + 8);
+    float* pen_val = reinterpret_cast<float*>(pen_id + 32);
+    float* amv = pen_val + 32;
+    int* ami = reinterpret_cast<int*>(amv + 4);
+    int* wcnt = ami + 4;
+    float* prL = reinterpret_cast<float*>(wcnt + 4);
+    uint32_t* keyL = reinterpret_cast<uint32_t*>(prL + 1024);
+    uint32_t* cut = keyL + 1024;
+    int* dead = reinterpret_cast<int*>(cut + 4);
+    int* out_count = dead + 1;
+    int* sub_count = dead + 2;
+    int* codes_s = dead + 4;                   // [MAXCB] codes of this frame as they become known
+    bf16_t* kvS = reinterpret_cast<bf16_t*>(codes_s + MAXCB);    // [n_layer][2][ncb][Hkv * hd] bf16 bits
+    if (tid == 0) { *dead = 0; *out_count = 0; *sub_count = 0; }
+    const unsigned epoch = __hip_atomic_load((eng_gu32*)(p.ctl + ENG_CTL_EPOCH), ENG_RLX);
+    const size_t VSTR = (size_t)nb * ENG_LINE;
+    const EngLayout layD{D / nb}, layF{F / nb}, layQ{p.qkvN / nb}, layV{p.V / nb};
+    const int nL = p.n_layer;
+    // hand-off buffers of (step parity, layer)
+    auto bx = [&](int par, int l) { return p.gx + ((size_t)par * (nL + 1) + l) * VSTR; };
+    auto bq = [&](int par, int l) { return p.gqkv + ((size_t)par * nL + l) * VSTR; };
+    auto bxb = [&](int par, int l) { return p.gxb + ((size_t)par * nL + l) * VSTR; };
+    auto bg = [&](int par, int l) { return p.gg + ((size_t)par * nL + l) * VSTR; };
+    auto blog = [&](int par) { return p.glog + (size_t)par * VSTR; };
+    auto drawer = [&](int cb) { return (cb * 37) % nb; };   // the workgroup that draws codebook cb
+    bool alive = true;
+
+    if (wave < ENG_CW) {
+        // =============================== compute waves ===============================
+        int q_lo, q_hi, o_lo, o_hi, f_lo, f_hi, h_lo, h_hi;
+        eng_units(p.qkvN, b, nb, q_lo, q_hi);
+        eng_units(D, b, nb, o_lo, o_hi);
+        eng_units(F, b, nb, f_lo, f_hi);
+        eng_units(p.V, b, nb, h_lo, h_hi);
+        EngW<NTD, 1, SQ> wq;
+        EngW<NTA, 1, SO> wo;
+        EngW<NTD, 2, SF> wf;
+        EngW<NTF, 1, SO> wd;
+        EngW<NTD, 1, SO> wh;
+        EngOut eo{outS, out_count, 0};
+        {
+            const EngLayer l0 = eng_layer(p.layers, 0);
+            eng_issue<false>(wq, l0.wqkv, l0.attn_norm, D, q_lo, q_hi, cw, lane, 0);
+            eng_issue<false>(wo, l0.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, 0);
+            eng_issue<false>(wf, l0.w13, l0.ffn_norm, D, f_lo, f_hi, cw, lane, 0);
+            eng_issue<false>(wd, l0.w2, (const bf16_t*)nullptr, F, o_lo, o_hi, cw, lane, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        eng_barrier();                                                  // B0
+        for (int cb = 0; cb < p.ncb && alive; ++cb) {
+            const int par = cb & 1;
+            const unsigned tag = eng_tag16(epoch + (unsigned)cb);
+            for (int li = 0; li < nL; ++li) {
+                const EngLayer l = eng_layer(p.layers, li);
+                const bool more = !(cb == p.ncb - 1 && li == nL - 1);
+                const EngLayer ln = eng_layer(p.layers, li + 1 < nL ? li + 1 : 0);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B1: xA
+                eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, bq(par, li) + (size_t)b * ENG_LINE, tag,
+                                                             nullptr, q_lo, q_hi, cw, lane, eo);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) eng_issue<false>(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B1b: qkvS
+                eng_fast_attn<MAXCB>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
+                                     p.rope, cb, p.H, p.Hkv, hd, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_barrier();                                          // B2: yS
+                eng_gemv<NTA, 1, SO, PRO_NONE, EPI_RESID>(wo, yS, HD, p.eps, l.bo, xA, bxb(par, li) + (size_t)b * ENG_LINE, tag, nullptr,
+                                                          o_lo, o_hi, cw, lane, eo);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) eng_issue<false>(wo, ln.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B3: xB
+                eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, D, p.eps, nullptr, nullptr, bg(par, li) + (size_t)b * ENG_LINE, tag, nullptr,
+                                                              f_lo, f_hi, cw, lane, eo);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) eng_issue<false>(wf, ln.w13, ln.ffn_norm, D, f_lo, f_hi, cw, lane, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B4: gS
+                eng_gemv<NTF, 1, SO, PRO_NONE, EPI_RESID>(wd, gS, F, p.eps, nullptr, xB, bx(par, li + 1) + (size_t)b * ENG_LINE, tag, nullptr,
+                                                          o_lo, o_hi, cw, lane, eo);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) eng_issue<false>(wd, ln.w2, (const bf16_t*)nullptr, F, o_lo, o_hi, cw, lane, 0);
+                // the head's rows are requested one hand-off before their use (held only across it)
+                if (li == nL - 1 && cb >= 1) eng_issue<false>(wh, p.fast_out, p.fast_norm, D, h_lo, h_hi, cw, lane, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!alive) break;
+            if (cb >= 1) {      // logits of position 0 are discarded (inference.py:122)
+                eng_barrier(); if (*dead) { alive = false; break; }     // B5: xA = stack output
+                eng_gemv<NTD, 1, SO, PRO_RMSNORM, EPI_STORE>(wh, xA, D, p.eps, nullptr, nullptr, blog(par) + (size_t)b * ENG_LINE, tag, nullptr,
+                                                             h_lo, h_hi, cw, lane, eo);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        // ====================== gathering waves: inputs, attention share, the draws ======================
+        EngSub sub{sub_count, 0};
+        SampP sp = p.samp;
+        eng_barrier();                                                  // B0
+        for (int cb = 0; cb < p.ncb && alive; ++cb) {
+            const int par = cb & 1;
+            const unsigned tag = eng_tag16(epoch + (unsigned)cb);
+            for (int li = 0; li < nL; ++li) {
+                const EngLayer l = eng_layer(p.layers, li);
+                if (li > 0) {
+                    eng_gather(bx(par, li), layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 0);
+                } else if (cb <= 1) {
+                    const float* src = cb == 0 ? p.hid : p.femb;        // plain f32 left by the launches before this one
+                    for (int d = atid * 4; d < D; d += ENG_GW * 64 * 4) *reinterpret_cast<float4*>(xA + d) = *reinterpret_cast<const float4*>(src + d);
+                } else {
+                    // the code the previous step drew: one granule, then that row of the codebook-embedding table
+                    const unsigned ptag = eng_tag16(epoch + (unsigned)(cb - 1));
+                    const unsigned* gc = p.gcode + (size_t)(cb - 1) * ENG_LINE;
+                    EngSpin spn{p.ctl, dead, 0, 0, 1000 + cb * 64 + 60};
+                    unsigned v = 0;
+                    bool got = true;
+                    for (;;) {
+                        v = __hip_atomic_load((eng_gu32*)gc, ENG_RLX);
+                        if ((v >> 16) == ptag) break;
+                        if (spn.give_up(lane)) { got = false; break; }
+                    }
+                    if (got) {
+                        const int code = (int)(v & 0xffffu);
+                        if (atid == 0) codes_s[cb - 1] = code;
+                        for (int d = atid * 8; d < D; d += ENG_GW * 64 * 8) {
+                            float e8[8];
+                            Vec<bf16_t>::unpack(eng_ldg16<false>(p.fast_emb + (size_t)code * D + d), e8);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) xA[d + j] = e8[j];
+                        }
+                    }
+                }
+                eng_barrier(); if (*dead) { alive = false; break; }     // B1
+                eng_gather(bq(par, li), layQ, 0, p.qkvN, tag, qkvS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 1);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B1b
+                eng_fast_attn<MAXCB>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
+                                     p.rope, cb, p.H, p.Hkv, hd, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_barrier();                                          // B2
+                eng_gather(bxb(par, li), layD, 0, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 2);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B3
+                eng_gather(bg(par, li), layF, 0, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 3);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B4
+            }
+            if (!alive) break;
+            if (cb >= 1) {
+                eng_gather(bx(par, nL), layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 56);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B5
+                if (b == drawer(cb)) {
+                    // ---- the draw of codebook cb (inference.py:134-149) and the frame bookkeeping (finish_draw)
+                    eng_gather(blog(par), layV, 0, p.V, tag, logS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 57);
+                    sub.sync(lane);
+                    if (!*dead) {
+                        sp.cb = cb;
+                        sp.noise_off = p.noise_off1 + (long)(cb - 1) * p.noise_cb_stride;
+                        const int last = cb == p.ncb - 1;
+                        const int nfv = sp.nf[0];
+                        EngSampLds S{redbuf, pen_id, pen_val, amv, ami, wcnt, prL, keyL, cut};
+                        const int code = eng_sample_small(sp, logS, S, sub, atid, lane, gw);
+                        const int R = p.ncb + 1;
+                        if (atid == 0) { sp.tokn[cb + 1] = code; codes_s[cb] = code; }
+                        if (last) {
+                            const int frozen = sp.done[0];
+                            sub.sync(lane);
+                            if (atid < R) {
+                                const int v = atid < 2 ? sp.tokn[atid] : codes_s[atid - 1];   // rows 0, 1: the slow draw's launch
+                                sp.tok[atid] = v;
+                                if (nfv < sp.cap && !frozen) sp.seq[(size_t)atid * sp.cap + nfv] = v;
+                            }
+                            if (atid == 0 && !frozen) {
+                                sp.pos[0] += 1;
+                                sp.nf[0] = nfv + 1;
+                                if (sp.tokn[0] == sp.im_end) sp.done[0] = 1;
+                            }
+                        } else if (atid == 0) {
+                            eng_put_raw(p.gcode + (size_t)cb * ENG_LINE, 0, (unsigned)code, tag);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- leave: the last workgroup out advances the epoch for the next launch
+    eng_barrier();
     if (tid == 0) {
         const unsigned old = atomicAdd(p.ctl + ENG_CTL_EXIT, 1u);
         if (old + 1 == (unsigned)nb) {

@@ -17,10 +17,13 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(monkeypatch, shape, engine_on, prompt, n_new, kw, tape=None, precision="bf16"):
-    if engine_on:
-        monkeypatch.delenv("FT_NO_ENGINE", raising=False)
-    else:
+    """engine_on: False = launch path, True = both engines, "slow" = the slow-stack engine only."""
+    monkeypatch.delenv("FT_NO_ENGINE", raising=False)
+    monkeypatch.delenv("FT_NO_FAST_ENGINE", raising=False)
+    if not engine_on:
         monkeypatch.setenv("FT_NO_ENGINE", "1")
+    elif engine_on == "slow":
+        monkeypatch.setenv("FT_NO_FAST_ENGINE", "1")
     eng, _ = make_pair(shape, precision, max_new_tokens=n_new + 8)
     flags, _, _ = eng.engine_state()
     if tape is not None:
@@ -41,11 +44,12 @@ def test_engine_frames_equal_launch_frames_greedy(monkeypatch, max_seq_len, Lp):
     prompt = make_prompt(shape, Lp, seed=4, n_vq=4).numpy()
     kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
     fa, a, la, ha = _run(monkeypatch, shape, False, prompt, 24, kw)
-    fb, b, lb, hb = _run(monkeypatch, shape, True, prompt, 24, kw)
-    assert fa == 0 and (fb & 1) == 1, (fa, fb)          # the second run really took the engine
-    assert np.array_equal(a, b)
-    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
-    assert np.array_equal(ha.view(np.uint32), hb.view(np.uint32))
+    for mode, want in (("slow", 1), (True, 3)):
+        fb, b, lb, hb = _run(monkeypatch, shape, mode, prompt, 24, kw)
+        assert fa == 0 and fb == want, (fa, fb)          # the run really took the engine(s)
+        assert np.array_equal(a, b), mode
+        assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), mode
+        assert np.array_equal(ha.view(np.uint32), hb.view(np.uint32)), mode
 
 
 def test_engine_frames_equal_launch_frames_sampled(monkeypatch):
@@ -54,10 +58,11 @@ def test_engine_frames_equal_launch_frames_sampled(monkeypatch):
     kw = dict(temperature=0.7, top_p=0.8, repetition_penalty=1.1)
     tape = NoiseTape(shape, 40, seed=3)
     _, a, la, _ = _run(monkeypatch, shape, False, prompt, 32, kw, tape)
-    fb, b, lb, _ = _run(monkeypatch, shape, True, prompt, 32, kw, tape)
-    assert (fb & 1) == 1
-    assert np.array_equal(a, b)
-    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    for mode, want in (("slow", 1), (True, 3)):
+        fb, b, lb, _ = _run(monkeypatch, shape, mode, prompt, 32, kw, tape)
+        assert fb == want
+        assert np.array_equal(a, b), mode
+        assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), mode
 
 
 def test_engine_full_depth_equals_launch_path(monkeypatch):
@@ -67,7 +72,7 @@ def test_engine_full_depth_equals_launch_path(monkeypatch):
     kw = dict(temperature=0.7, top_p=0.8, repetition_penalty=1.1)
     _, a, la, ha = _run(monkeypatch, shape, False, prompt, 16, kw)
     fb, b, lb, hb = _run(monkeypatch, shape, True, prompt, 16, kw)
-    assert (fb & 1) == 1
+    assert fb == 3
     assert np.array_equal(a, b)
     assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
     assert np.array_equal(ha.view(np.uint32), hb.view(np.uint32))
