@@ -471,7 +471,7 @@ static ft_status eng_setup(ft_ctx* ctx) {
     const int HDf = c.fast_n_head * c.fast_head_dim;
     const int fqkvN = (c.fast_n_head + 2 * c.fast_n_local_heads) * c.fast_head_dim;
     const bool fast_ok = !getenv("FT_NO_FAST_ENGINE") && c.fast_dim == 1024 && HDf == 1024 && c.fast_intermediate_size == 3072 &&
-                         c.fast_head_dim <= 128 && c.fast_n_head % c.fast_n_local_heads == 0 && c.n_fast_layer >= 1 &&
+                         c.fast_head_dim == 64 && c.fast_n_head % c.fast_n_local_heads == 0 && c.n_fast_layer >= 1 &&
                          c.num_codebooks >= 2 && c.num_codebooks <= 10 && fqkvN % (4 * nb) == 0 && ctx->fastV % (4 * nb) == 0 &&
                          per(fqkvN) <= ENG_FQ * ENG_CW && per(c.fast_dim) <= ENG_FO * ENG_CW && per(c.fast_intermediate_size) <= ENG_FF * ENG_CW &&
                          per(ctx->fastV) <= ENG_FO * ENG_CW && per(fqkvN) <= ENG_LINE && ctx->fastV <= 1024 && c.codebook_size <= 65536 &&
@@ -494,7 +494,7 @@ static ft_status eng_setup(ft_ctx* ctx) {
     ctx->eng_lds_fast = ff * sizeof(float) + (size_t)nLf * 2 * c.num_codebooks * c.fast_n_local_heads * c.fast_head_dim * 2 + 64;
     if (ctx->eng_lds_fast > 160 * 1024) return FT_OK;
     ctx->eng_lds_fast = std::max(ctx->eng_lds_fast, (size_t)82 * 1024);
-    FT_HIP(ctx, hipFuncSetAttribute((const void*)fast_engine_kernel<2, 2, 6, 10>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    FT_HIP(ctx, hipFuncSetAttribute((const void*)fast_engine_kernel<2, 2, 6, 10, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)ctx->eng_lds_fast));
     ctx->eng_fast_on = true;
     return FT_OK;
@@ -582,7 +582,7 @@ static void enqueue_fast_engine(Launch& L) {
     s.tok = ctx->d_tok + (size_t)m0 * R; s.pos = ctx->d_pos + m0; s.done = ctx->d_done + m0;
     p.samp = s;
     p.noise_cb_stride = ctx->fastV; p.noise_off1 = c.vocab_size;
-    fast_engine_kernel<2, 2, 6, 10><<<nb, ENG_THREADS, ctx->eng_lds_fast, L.s>>>(p);
+    fast_engine_kernel<2, 2, 6, 10, 64><<<nb, ENG_THREADS, ctx->eng_lds_fast, L.s>>>(p);
     L.chk();
 }
 

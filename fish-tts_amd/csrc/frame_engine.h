@@ -117,13 +117,16 @@ __device__ __forceinline__ void eng_put64(unsigned long long* g, size_t i, float
     __hip_atomic_store((eng_gu64*)(g + i), ((unsigned long long)tag32 << 32) | __float_as_uint(v), ENG_RLX);
 }
 
+#ifndef ENG_POLL_BITS
+#define ENG_POLL_BITS "sc1"
+#endif
 __device__ __forceinline__ void eng_ld3_sc1(const void* p0, const void* p1, const void* p2, U4& a, U4& b, U4& c) {
-    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\t"
-                 "global_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+    asm volatile("global_load_dwordx4 %0, %3, off " ENG_POLL_BITS "\n\tglobal_load_dwordx4 %1, %4, off " ENG_POLL_BITS "\n\t"
+                 "global_load_dwordx4 %2, %5, off " ENG_POLL_BITS "\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p0), "v"(p1), "v"(p2) : "memory");
 }
 __device__ __forceinline__ void eng_ld1_sc1(const void* p0, U4& a) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(p0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off " ENG_POLL_BITS "\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(p0) : "memory");
 }
 __device__ __forceinline__ bool eng_tags_ok(const U4& v, unsigned tag) {
     return (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
@@ -163,10 +166,18 @@ struct EngSpin {
 // `per` consecutive units there with ONE store instruction, so a line is written once per phase (the memory side serves
 // the accesses to one line one after the other, and every write of a polled line also recalls its copies from the
 // XCDs' L2s: 32 four-byte writes per line cost 2.5-3 us per hand-off, 8 cost 1.6-2, one costs about 1).
+#ifndef ENG_DRAIN
+#define ENG_DRAIN 0
+#endif
+#ifndef ENG_PAD
+#define ENG_PAD 0                          // 0 (timing experiments): vectors stored linearly, 8 workgroups share a 128-byte line
+#endif
 constexpr int ENG_LINE = 32;   // dwords
+// where workgroup b publishes its units [u_lo, ..) of a vector
+__device__ __forceinline__ size_t eng_pub(int b, int u_lo) { return ENG_PAD ? (size_t)b * ENG_LINE : (size_t)u_lo; }
 struct EngLayout {
     int per;        // units per producing workgroup (0: the vector is stored linearly)
-    __device__ __forceinline__ int off(int u) const { return per ? (u / per) * ENG_LINE + (u % per) : u; }
+    __device__ __forceinline__ int off(int u) const { return (ENG_PAD && per) ? (u / per) * ENG_LINE + (u % per) : u; }
 };
 struct EngIdent { __device__ __forceinline__ int operator()(int i) const { return i; } };
 
@@ -335,6 +346,9 @@ __device__ __forceinline__ void eng_gemv(const EngW<NT, RPU, MAXS>& r, const flo
             eng_put(gout, lane, o, tag);
             if (plain) plain[u_lo + lane] = o;
         }
+#if ENG_DRAIN
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     }
 }
 
@@ -489,7 +503,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             if (li > 0) { eng_issue(wd, l.w2, (const bf16_t*)nullptr, F, d_lo, d_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
 #endif
             ENG_STAMP(0);
-            eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, p.gqkv + (size_t)li * VSTR + (size_t)b * ENG_LINE, tag, nullptr,
+            eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, p.gqkv + (size_t)li * VSTR + eng_pub(b, q_lo), tag, nullptr,
                                                          q_lo, q_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(1);
@@ -508,7 +522,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             if (more) { eng_issue(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
 #endif
             ENG_STAMP(3);
-            eng_gemv<NTA, 1, SO, PRO_NONE, EPI_RESID>(wo, yS, HD, p.eps, l.bo, xA, p.gxb + (size_t)li * VSTR + (size_t)b * ENG_LINE, tag, nullptr, o_lo, o_hi, cw, lane, eo);
+            eng_gemv<NTA, 1, SO, PRO_NONE, EPI_RESID>(wo, yS, HD, p.eps, l.bo, xA, p.gxb + (size_t)li * VSTR + eng_pub(b, o_lo), tag, nullptr, o_lo, o_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(4);
             if (p.stamps && (p.nt & 2)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ENG_STAMP(9); }   // write-through acknowledged
@@ -521,7 +535,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             if (more) { eng_issue(wo, ln.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
 #endif
             ENG_STAMP(5);
-            eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, D, p.eps, nullptr, nullptr, p.gg + (size_t)li * VSTR + (size_t)b * ENG_LINE, tag, nullptr, f_lo, f_hi, cw, lane, eo);
+            eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, D, p.eps, nullptr, nullptr, p.gg + (size_t)li * VSTR + eng_pub(b, f_lo), tag, nullptr, f_lo, f_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(6);
 #if !ENG_ISSUE_LATE
@@ -533,7 +547,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             if (more) { eng_issue(wf, ln.w13, ln.ffn_norm, D, f_lo, f_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
 #endif
             ENG_STAMP(7);
-            eng_gemv<NTF, 1, SO, PRO_NONE, EPI_RESID>(wd, gS, F, p.eps, nullptr, xB, p.gx + (size_t)(li + 1) * VSTR + (size_t)b * ENG_LINE, tag,
+            eng_gemv<NTF, 1, SO, PRO_NONE, EPI_RESID>(wd, gS, F, p.eps, nullptr, xB, p.gx + (size_t)(li + 1) * VSTR + eng_pub(b, d_lo), tag,
                                                       li == p.n_layer - 1 ? p.x_out : nullptr, d_lo, d_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(8);
@@ -877,7 +891,9 @@ struct FastEngP {
     SampP samp;                   // sampling state (cb, noise_off, last are set per step in the kernel)
     long noise_cb_stride;         // fastV
     long noise_off1;              // offset of codebook 1's noise in a row (vocab_size)
+    unsigned long long* stamps;   // diagnostic builds only (tools/mb_engine.hip): [workgroup][step][layer][16] ticks, or nullptr
 };
+#define ENG_FSTAMP(k) do { if (p.stamps && tid == 0) p.stamps[(((size_t)b * p.ncb + cb) * nL + li) * 16 + (k)] = eng_rt(); } while (0)
 
 constexpr int ENG_FQ = 2, ENG_FF = 3, ENG_FO = 1;   // units per compute wave: QKV 8 rows -> 2, W13 12 pairs -> 3, Wo / W2 / head 4 rows -> 1
 
@@ -897,42 +913,39 @@ struct EngSub {
 // The attention of one fast layer at codebook position c for the heads h = w, w + nw, .. (fast_attn_kernel's arithmetic:
 // one wave per head, lane d owns dimension d (and d + 64)); q/k/v of this position come from qkvS (LDS, f32), the
 // earlier positions' K/V from kvS (LDS, bf16 bits; row j of layer-local cache: [j][Hkv * hd] K then V).
-template <int MAXCB>
+template <int MAXCB, int HD>
 __device__ __forceinline__ void eng_fast_attn(const float* qkvS, bf16_t* kS, bf16_t* vS, float* yS, const bf16_t* qn, const bf16_t* kn,
-                                              const float* rope, int c, int H, int Hkv, int hd, float eps, float scale, int w, int nw,
-                                              int lane) {
-    const int hp = hd >> 1, G = H / Hkv, KVW = Hkv * hd;
-    constexpr int EPL = 2;
+                                              const float (&cs)[2], const float (&sn)[2], int c, int ncb, int H, int Hkv, float eps, float scale,
+                                              int w, int nw, int lane) {
+    // head_dim is a compile-time constant here (64 or 128): lane d owns dimension d (and d + 64 when HD = 128); the K/V
+    // history of a layer is laid out [kv head][position][HD] so a position is an immediate offset from the head's base
+    constexpr int EPL = HD > 64 ? 2 : 1;
+    const int G = H / Hkv;
     for (int h = w; h < H; h += nw) {
         const int kvh = h / G;
-        // (earlier positions' K/V rows are read from LDS where they are used: keeping all of them in registers beside the
-        // compute waves' weight rows does not fit)
-        auto ldk = [&](int j, int e) { const int d = lane + 64 * e; return d < hd ? bf16_bits_to_f32(kS[(size_t)j * KVW + kvh * hd + d]) : 0.f; };
-        auto ldv = [&](int j, int e) { const int d = lane + 64 * e; return d < hd ? bf16_bits_to_f32(vS[(size_t)j * KVW + kvh * hd + d]) : 0.f; };
-        float q[EPL], kx[EPL], vx[EPL], cs[EPL], sn[EPL], gq[EPL], gk[EPL];
+        bf16_t* kh = kS + (size_t)kvh * ncb * HD + lane;
+        bf16_t* vh = vS + (size_t)kvh * ncb * HD + lane;
+        const float* qp = qkvS + h * HD + lane;
+        const float* kp = qkvS + (H + kvh) * HD + lane;
+        const float* vp = qkvS + (H + Hkv + kvh) * HD + lane;
+        float q[EPL], kx[EPL], vx[EPL];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int d = lane + 64 * e;
-            const bool on = d < hd;
-            q[e] = on ? qkvS[(size_t)h * hd + d] : 0.f;
-            kx[e] = on ? qkvS[(size_t)(H + kvh) * hd + d] : 0.f;
-            vx[e] = on ? qkvS[(size_t)(H + Hkv + kvh) * hd + d] : 0.f;
-            cs[e] = on ? rope[((size_t)c * hp + (d >> 1)) * 2] : 1.f;
-            sn[e] = on ? rope[((size_t)c * hp + (d >> 1)) * 2 + 1] : 0.f;
-            gq[e] = (on && qn) ? eng_ldg_bf16(qn, d) : 1.f;
-            gk[e] = (on && kn) ? eng_ldg_bf16(kn, d) : 1.f;
-        }
+        for (int e = 0; e < EPL; ++e) { q[e] = qp[64 * e]; kx[e] = kp[64 * e]; vx[e] = vp[64 * e]; }
         if (qn) {
-            const float ss = wave_sum(q[0] * q[0] + q[1] * q[1]);
-            const float inv = rsqrt_exact(ss / (float)hd + eps);
+            float ss = q[0] * q[0];
+            if (EPL > 1) ss = q[0] * q[0] + q[EPL - 1] * q[EPL - 1];
+            ss = wave_sum(HD < 64 ? (lane < HD ? ss : 0.f) : ss);
+            const float inv = rsqrt_exact(ss / (float)HD + eps);
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) q[e] = round_bf16((q[e] * inv) * gq[e]);
+            for (int e = 0; e < EPL; ++e) q[e] = round_bf16((q[e] * inv) * eng_ldg_bf16(qn, lane + 64 * e));
         }
         if (kn) {
-            const float ss = wave_sum(kx[0] * kx[0] + kx[1] * kx[1]);
-            const float inv = rsqrt_exact(ss / (float)hd + eps);
+            float ss = kx[0] * kx[0];
+            if (EPL > 1) ss = kx[0] * kx[0] + kx[EPL - 1] * kx[EPL - 1];
+            ss = wave_sum(ss);
+            const float inv = rsqrt_exact(ss / (float)HD + eps);
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) kx[e] = round_bf16((kx[e] * inv) * gk[e]);
+            for (int e = 0; e < EPL; ++e) kx[e] = round_bf16((kx[e] * inv) * eng_ldg_bf16(kn, lane + 64 * e));
         }
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
@@ -943,44 +956,49 @@ __device__ __forceinline__ void eng_fast_attn(const float* qkvS, bf16_t* kS, bf1
         }
         if (h % G == 0) {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                const int d = lane + 64 * e;
-                if (d < hd) { kS[(size_t)c * KVW + kvh * hd + d] = f32_to_bf16_bits(kx[e]); vS[(size_t)c * KVW + kvh * hd + d] = f32_to_bf16_bits(vx[e]); }
-            }
+            for (int e = 0; e < EPL; ++e) { kh[c * HD + 64 * e] = f32_to_bf16_bits(kx[e]); vh[c * HD + 64 * e] = f32_to_bf16_bits(vx[e]); }
         }
-        float sc[MAXCB];
-#pragma unroll
-        for (int j = 0; j < MAXCB; ++j) {
-            if (j <= c) {
-                const float k0 = j == c ? kx[0] : ldk(j, 0), k1 = j == c ? kx[1] : ldk(j, 1);
-                const float d = wave_sum(fmaf(q[1], k1, q[0] * k0));
-                sc[j] = round_bf16(round_bf16(d) * scale);
-            } else {
-                sc[j] = -INFINITY;
-            }
-        }
+        // scores (every lane gets every score: the wave reductions are fast_attn_kernel's); the score of position j is
+        // then kept by lane j alone, so the exponentials and the divisions of the softmax run ONCE per head instead of
+        // once per position: same operations on the same values, the sum is taken in position order as there
+        float sl = -INFINITY;      // lane j: score j
         float mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < MAXCB; ++j) mx = fmaxf(mx, sc[j]);
+        for (int j = 0; j < MAXCB; ++j) {
+            if (j <= c) {
+                float pr;
+                if (EPL > 1) {
+                    const float k0 = j == c ? kx[0] : bf16_bits_to_f32(kh[j * HD]), k1 = j == c ? kx[EPL - 1] : bf16_bits_to_f32(kh[j * HD + 64 * (EPL - 1)]);
+                    pr = fmaf(q[EPL - 1], k1, q[0] * k0);
+                } else {
+                    const float k0 = j == c ? kx[0] : bf16_bits_to_f32(kh[j * HD]);
+                    pr = fmaf(0.f, 0.f, q[0] * k0);       // fast_attn_kernel's second element is an exact zero term at HD <= 64
+                }
+                const float d = wave_sum(pr);
+                const float sj = round_bf16(round_bf16(d) * scale);
+                mx = fmaxf(mx, sj);
+                if (lane == j) sl = sj;
+            }
+        }
+        const float el = lane <= c ? expf(sl - mx) : 0.f;      // lane j: exp(score j - max)
         float sum = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXCB; ++j) {
-            if (j <= c) { sc[j] = expf(sc[j] - mx); sum += sc[j]; } else sc[j] = 0.f;
-        }
-        float o[EPL] = {0.f, 0.f};
+        for (int j = 0; j < MAXCB; ++j)
+            if (j <= c) sum += lane_f(el, j);
+        const float pl = lane <= c ? round_bf16(el / sum) : 0.f;   // lane j: probability j
+        float o[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = 0.f;
 #pragma unroll
         for (int j = 0; j < MAXCB; ++j) {
             if (j <= c) {
-                const float pj = round_bf16(sc[j] / sum);
-                o[0] = fmaf(pj, j == c ? vx[0] : ldv(j, 0), o[0]);
-                o[1] = fmaf(pj, j == c ? vx[1] : ldv(j, 1), o[1]);
+                const float pj = lane_f(pl, j);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[e] = fmaf(pj, j == c ? vx[e] : bf16_bits_to_f32(vh[j * HD + 64 * e]), o[e]);
             }
         }
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int d = lane + 64 * e;
-            if (d < hd) yS[(size_t)h * hd + d] = round_bf16(o[e]);
-        }
+        for (int e = 0; e < EPL; ++e) yS[h * HD + lane + 64 * e] = round_bf16(o[e]);
     }
 }
 
@@ -1166,7 +1184,7 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const float* L, 
     return winner;
 }
 
-template <int NTD, int NTA, int NTF, int MAXCB>
+template <int NTD, int NTA, int NTF, int MAXCB, int HDIM>
 __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     constexpr int SQ = ENG_FQ, SF = ENG_FF, SO = ENG_FO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1234,35 +1252,52 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
         for (int cb = 0; cb < p.ncb && alive; ++cb) {
             const int par = cb & 1;
             const unsigned tag = eng_tag16(epoch + (unsigned)cb);
+            float rcs[2], rsn[2];      // rotation entries of this codebook position (dimensions lane, lane + 64)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int d = lane + 64 * e;
+                rcs[e] = d < hd ? p.rope[((size_t)cb * (hd >> 1) + (d >> 1)) * 2] : 1.f;
+                rsn[e] = d < hd ? p.rope[((size_t)cb * (hd >> 1) + (d >> 1)) * 2 + 1] : 0.f;
+            }
             for (int li = 0; li < nL; ++li) {
                 const EngLayer l = eng_layer(p.layers, li);
                 const bool more = !(cb == p.ncb - 1 && li == nL - 1);
                 const EngLayer ln = eng_layer(p.layers, li + 1 < nL ? li + 1 : 0);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1: xA
-                eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, bq(par, li) + (size_t)b * ENG_LINE, tag,
+                ENG_FSTAMP(0);
+                eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, bq(par, li) + eng_pub(b, q_lo), tag,
                                                              nullptr, q_lo, q_hi, cw, lane, eo);
                 __builtin_amdgcn_sched_barrier(0);
+                ENG_FSTAMP(1);
                 if (more) eng_issue<false>(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b: qkvS
-                eng_fast_attn<MAXCB>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
-                                     p.rope, cb, p.H, p.Hkv, hd, p.eps, p.scale, wave, ENG_WAVES, lane);
+                ENG_FSTAMP(2);
+                eng_fast_attn<MAXCB, HDIM>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
+                                         rcs, rsn, cb, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                ENG_FSTAMP(9);
                 eng_barrier();                                          // B2: yS
-                eng_gemv<NTA, 1, SO, PRO_NONE, EPI_RESID>(wo, yS, HD, p.eps, l.bo, xA, bxb(par, li) + (size_t)b * ENG_LINE, tag, nullptr,
+                ENG_FSTAMP(3);
+                eng_gemv<NTA, 1, SO, PRO_NONE, EPI_RESID>(wo, yS, HD, p.eps, l.bo, xA, bxb(par, li) + eng_pub(b, o_lo), tag, nullptr,
                                                           o_lo, o_hi, cw, lane, eo);
                 __builtin_amdgcn_sched_barrier(0);
+                ENG_FSTAMP(4);
                 if (more) eng_issue<false>(wo, ln.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B3: xB
-                eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, D, p.eps, nullptr, nullptr, bg(par, li) + (size_t)b * ENG_LINE, tag, nullptr,
+                ENG_FSTAMP(5);
+                eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, D, p.eps, nullptr, nullptr, bg(par, li) + eng_pub(b, f_lo), tag, nullptr,
                                                               f_lo, f_hi, cw, lane, eo);
                 __builtin_amdgcn_sched_barrier(0);
+                ENG_FSTAMP(6);
                 if (more) eng_issue<false>(wf, ln.w13, ln.ffn_norm, D, f_lo, f_hi, cw, lane, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B4: gS
-                eng_gemv<NTF, 1, SO, PRO_NONE, EPI_RESID>(wd, gS, F, p.eps, nullptr, xB, bx(par, li + 1) + (size_t)b * ENG_LINE, tag, nullptr,
+                ENG_FSTAMP(7);
+                eng_gemv<NTF, 1, SO, PRO_NONE, EPI_RESID>(wd, gS, F, p.eps, nullptr, xB, bx(par, li + 1) + eng_pub(b, o_lo), tag, nullptr,
                                                           o_lo, o_hi, cw, lane, eo);
                 __builtin_amdgcn_sched_barrier(0);
+                ENG_FSTAMP(8);
                 if (more) eng_issue<false>(wd, ln.w2, (const bf16_t*)nullptr, F, o_lo, o_hi, cw, lane, 0);
                 // the head's rows are requested one hand-off before their use (held only across it)
                 if (li == nL - 1 && cb >= 1) eng_issue<false>(wh, p.fast_out, p.fast_norm, D, h_lo, h_hi, cw, lane, 0);
@@ -1271,7 +1306,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
             if (!alive) break;
             if (cb >= 1) {      // logits of position 0 are discarded (inference.py:122)
                 eng_barrier(); if (*dead) { alive = false; break; }     // B5: xA = stack output
-                eng_gemv<NTD, 1, SO, PRO_RMSNORM, EPI_STORE>(wh, xA, D, p.eps, nullptr, nullptr, blog(par) + (size_t)b * ENG_LINE, tag, nullptr,
+                eng_gemv<NTD, 1, SO, PRO_RMSNORM, EPI_STORE>(wh, xA, D, p.eps, nullptr, nullptr, blog(par) + eng_pub(b, h_lo), tag, nullptr,
                                                              h_lo, h_hi, cw, lane, eo);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1284,6 +1319,13 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
         for (int cb = 0; cb < p.ncb && alive; ++cb) {
             const int par = cb & 1;
             const unsigned tag = eng_tag16(epoch + (unsigned)cb);
+            float rcs[2], rsn[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int d = lane + 64 * e;
+                rcs[e] = d < hd ? p.rope[((size_t)cb * (hd >> 1) + (d >> 1)) * 2] : 1.f;
+                rsn[e] = d < hd ? p.rope[((size_t)cb * (hd >> 1) + (d >> 1)) * 2 + 1] : 0.f;
+            }
             for (int li = 0; li < nL; ++li) {
                 const EngLayer l = eng_layer(p.layers, li);
                 if (li > 0) {
@@ -1292,33 +1334,20 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                     const float* src = cb == 0 ? p.hid : p.femb;        // plain f32 left by the launches before this one
                     for (int d = atid * 4; d < D; d += ENG_GW * 64 * 4) *reinterpret_cast<float4*>(xA + d) = *reinterpret_cast<const float4*>(src + d);
                 } else {
-                    // the code the previous step drew: one granule, then that row of the codebook-embedding table
-                    const unsigned ptag = eng_tag16(epoch + (unsigned)(cb - 1));
-                    const unsigned* gc = p.gcode + (size_t)(cb - 1) * ENG_LINE;
-                    EngSpin spn{p.ctl, dead, 0, 0, 1000 + cb * 64 + 60};
-                    unsigned v = 0;
-                    bool got = true;
-                    for (;;) {
-                        v = __hip_atomic_load((eng_gu32*)gc, ENG_RLX);
-                        if ((v >> 16) == ptag) break;
-                        if (spn.give_up(lane)) { got = false; break; }
-                    }
-                    if (got) {
-                        const int code = (int)(v & 0xffffu);
-                        if (atid == 0) codes_s[cb - 1] = code;
-                        for (int d = atid * 8; d < D; d += ENG_GW * 64 * 8) {
-                            float e8[8];
-                            Vec<bf16_t>::unpack(eng_ldg16<false>(p.fast_emb + (size_t)code * D + d), e8);
+                    // the code this workgroup drew in the previous step: that row of the codebook-embedding table
+                    const int code = codes_s[cb - 1];
+                    for (int d = atid * 8; d < D; d += ENG_GW * 64 * 8) {
+                        float e8[8];
+                        Vec<bf16_t>::unpack(eng_ldg16<false>(p.fast_emb + (size_t)code * D + d), e8);
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) xA[d + j] = e8[j];
-                        }
+                        for (int j = 0; j < 8; ++j) xA[d + j] = e8[j];
                     }
                 }
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1
                 eng_gather(bq(par, li), layQ, 0, p.qkvN, tag, qkvS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 1);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b
-                eng_fast_attn<MAXCB>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
-                                     p.rope, cb, p.H, p.Hkv, hd, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_fast_attn<MAXCB, HDIM>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
+                                         rcs, rsn, cb, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 eng_barrier();                                          // B2
                 eng_gather(bxb(par, li), layD, 0, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 2);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B3
@@ -1329,8 +1358,10 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
             if (cb >= 1) {
                 eng_gather(bx(par, nL), layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 56);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B5
-                if (b == drawer(cb)) {
-                    // ---- the draw of codebook cb (inference.py:134-149) and the frame bookkeeping (finish_draw)
+                {
+                    // ---- the draw of codebook cb (inference.py:134-149).  EVERY workgroup gathers the logits and draws (the
+                    // draw is a deterministic function of logits, frame and seed): no hand-off of the code, the next step's
+                    // embedding row can be fetched at once.  Workgroup drawer(cb) alone does the frame bookkeeping (finish_draw).
                     eng_gather(blog(par), layV, 0, p.V, tag, logS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 57);
                     sub.sync(lane);
                     if (!*dead) {
@@ -1341,22 +1372,23 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                         EngSampLds S{redbuf, pen_id, pen_val, amv, ami, wcnt, prL, keyL, cut};
                         const int code = eng_sample_small(sp, logS, S, sub, atid, lane, gw);
                         const int R = p.ncb + 1;
-                        if (atid == 0) { sp.tokn[cb + 1] = code; codes_s[cb] = code; }
-                        if (last) {
-                            const int frozen = sp.done[0];
-                            sub.sync(lane);
-                            if (atid < R) {
-                                const int v = atid < 2 ? sp.tokn[atid] : codes_s[atid - 1];   // rows 0, 1: the slow draw's launch
-                                sp.tok[atid] = v;
-                                if (nfv < sp.cap && !frozen) sp.seq[(size_t)atid * sp.cap + nfv] = v;
+                        if (atid == 0) codes_s[cb] = code;
+                        sub.sync(lane);      // the next step's first read of codes_s comes from all four waves
+                        if (b == drawer(cb)) {
+                            if (atid == 0) sp.tokn[cb + 1] = code;
+                            if (last) {
+                                const int frozen = sp.done[0];
+                                if (atid < R) {
+                                    const int v = atid < 2 ? sp.tokn[atid] : (atid - 1 == cb ? code : codes_s[atid - 1]);   // rows 0, 1: the slow draw's launch
+                                    sp.tok[atid] = v;
+                                    if (nfv < sp.cap && !frozen) sp.seq[(size_t)atid * sp.cap + nfv] = v;
+                                }
+                                if (atid == 0 && !frozen) {
+                                    sp.pos[0] += 1;
+                                    sp.nf[0] = nfv + 1;
+                                    if (sp.tokn[0] == sp.im_end) sp.done[0] = 1;
+                                }
                             }
-                            if (atid == 0 && !frozen) {
-                                sp.pos[0] += 1;
-                                sp.nf[0] = nfv + 1;
-                                if (sp.tokn[0] == sp.im_end) sp.done[0] = 1;
-                            }
-                        } else if (atid == 0) {
-                            eng_put_raw(p.gcode + (size_t)cb * ENG_LINE, 0, (unsigned)code, tag);
                         }
                     }
                 }

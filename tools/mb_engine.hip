@@ -22,7 +22,14 @@ __global__ void fill_rope(float* r, int n_pos, int hp) {
     if (i < n_pos * hp) { const int pos = i / hp, k = i % hp; const float a = pos * powf(1e6f, -(float)k / hp); r[2 * i] = round_bf16(cosf(a)); r[2 * i + 1] = round_bf16(sinf(a)); }
 }
 
+static int run_fast(int nb, hipStream_t s);
+
 int main(int argc, char** argv) {
+    if (argc > 1 && atoi(argv[1]) == 0) {     // mb_engine 0  -> the fast codebook loop
+        hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+        hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        return run_fast(prop.multiProcessorCount, s);
+    }
     const int n_layer = argc > 1 ? atoi(argv[1]) : 28;
     const int pos0 = argc > 2 ? atoi(argv[2]) : 150;
     const int nsplit = argc > 3 ? atoi(argv[3]) : 8;
@@ -132,5 +139,94 @@ int main(int argc, char** argv) {
         printf("x' gather by gw0: first full pass returned %.2f us after polling began; %.2f full passes, %.2f single-piece polls per gather\n",
                rtt / cnt / 100.0, nf / cnt, nl / cnt);
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ the fast codebook loop
+static int run_fast(int nb, hipStream_t s) {
+    const int nL = 4, ncb = 10, D = 1024, H = 16, Hkv = 8, hd = 64, F = 3072, HD = H * hd, qkvN = (H + 2 * Hkv) * hd, V = 1024, cbs = 4096;
+    auto balloc = [&](size_t n, unsigned seed, float scale) { bf16_t* p; CK(hipMalloc(&p, n * 2 + 64)); fill_bf16<<<1024, 256, 0, s>>>(p, n, seed, scale); return p; };
+    auto zalloc = [&](size_t bytes) { void* q; CK(hipMalloc(&q, bytes)); CK(hipMemset(q, 0, bytes)); return q; };
+    std::vector<EngLayer> hl(nL);
+    for (int i = 0; i < nL; ++i) {
+        EngLayer& l = hl[i];
+        l.wqkv = balloc((size_t)qkvN * D, 11 * i + 1, 0.06f); l.bqkv = nullptr; l.attn_norm = balloc(D, 11 * i + 2, 2.0f);
+        l.qn = nullptr; l.kn = nullptr; l.wo = balloc((size_t)D * HD, 11 * i + 5, 0.04f); l.bo = nullptr;
+        l.ffn_norm = balloc(D, 11 * i + 6, 2.0f); l.w13 = balloc((size_t)2 * F * D, 11 * i + 7, 0.06f); l.w2 = balloc((size_t)D * F, 11 * i + 8, 0.04f);
+        l.kc = nullptr; l.vc = nullptr;
+    }
+    EngLayer* dl; CK(hipMalloc(&dl, hl.size() * sizeof(EngLayer))); CK(hipMemcpy(dl, hl.data(), hl.size() * sizeof(EngLayer), hipMemcpyHostToDevice));
+    FastEngP p{};
+    p.layers = dl; p.n_layer = nL; p.ncb = ncb; p.D = D; p.H = H; p.Hkv = Hkv; p.hd = hd; p.F = F; p.qkvN = qkvN; p.V = V;
+    p.eps = 1e-6f; p.scale = 1.0f / sqrtf((float)hd);
+    float* rope; CK(hipMalloc(&rope, (size_t)ncb * hd * 4)); fill_rope<<<(ncb * hd / 2 + 255) / 256, 256, 0, s>>>(rope, ncb, hd / 2);
+    p.rope = rope; p.fast_norm = balloc(D, 801, 2.0f); p.fast_out = balloc((size_t)V * D, 802, 0.06f); p.fast_emb = balloc((size_t)cbs * D, 803, 1.0f);
+    float* hid = (float*)zalloc(D * 4); float* femb = (float*)zalloc(D * 4);
+    { std::vector<float> h(D); for (int i = 0; i < D; ++i) h[i] = (float)((i * 37) % 17 - 8) * 0.0625f; CK(hipMemcpy(hid, h.data(), D * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(femb, h.data(), D * 4, hipMemcpyHostToDevice)); }
+    p.hid = hid; p.femb = femb;
+    const size_t VW = (size_t)nb * ENG_LINE;
+    const size_t words = (2 * ((size_t)(nL + 1) + 3 * nL + 1)) * VW + (size_t)ncb * ENG_LINE;
+    unsigned* g = (unsigned*)zalloc(words * 4);
+    p.gx = g; g += 2 * (size_t)(nL + 1) * VW; p.gqkv = g; g += 2 * (size_t)nL * VW; p.gxb = g; g += 2 * (size_t)nL * VW; p.gg = g; g += 2 * (size_t)nL * VW;
+    p.glog = g; g += 2 * VW; p.gcode = g;
+    p.ctl = (unsigned*)zalloc(ENG_CTL_WORDS * 4);
+    const int R = ncb + 1, cap = 256;
+    RowCtl hc{0.7f, 0.8f, 1.1f, 0, 1234ull};
+    RowCtl* dctl; CK(hipMalloc(&dctl, sizeof hc)); CK(hipMemcpy(dctl, &hc, sizeof hc, hipMemcpyHostToDevice));
+    SampP sp{};
+    sp.V = V; sp.ldl = V; sp.ctl = dctl; sp.tokn = (int*)zalloc(R * 4); sp.seq = (int*)zalloc((size_t)R * cap * 4); sp.cap = cap;
+    int one = 1; sp.nf = (int*)zalloc(4); CK(hipMemcpy(sp.nf, &one, 4, hipMemcpyHostToDevice));
+    sp.ncb = ncb; sp.sem_begin = 4000; sp.im_end = 100; sp.cbsize = cbs; sp.noise = nullptr; sp.tok = (int*)zalloc(R * 4);
+    sp.pos = (int*)zalloc(4); sp.done = (int*)zalloc(4);
+    p.samp = sp; p.noise_cb_stride = V; p.noise_off1 = 8192;
+    unsigned long long* stamps = (unsigned long long*)zalloc((size_t)nb * ncb * nL * 16 * 8);
+    size_t ldsb = ((size_t)D * 2 + qkvN + HD + F + V + ENG_MAX_OUT + 8 + 32 + 32 + 12 + 2048 + 4 + 4 + 16) * 4 + (size_t)nL * 2 * ncb * Hkv * hd * 2 + 64;
+    CK(hipFuncSetAttribute((const void*)fast_engine_kernel<2, 2, 6, 10, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    CK(hipStreamSynchronize(s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int mode = 0; mode < 2; ++mode) {
+        p.stamps = mode ? stamps : nullptr;
+        float sum = 0.f; const int reps = 10;
+        for (int r = 0; r < reps + 3; ++r) {
+            CK(hipMemcpyAsync(sp.nf, &one, 4, hipMemcpyHostToDevice, s));
+            CK(hipEventRecord(e0, s));
+            fast_engine_kernel<2, 2, 6, 10, 64><<<nb, ENG_THREADS, ldsb, s>>>(p);
+            CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 3) sum += ms;
+        }
+        unsigned h[4]; CK(hipMemcpy(h, p.ctl, 16, hipMemcpyDeviceToHost));
+        printf("fast loop %-12s: %.1f us per launch = %.2f us per layer-step%s\n", mode ? "with stamps" : "plain", sum / reps * 1e3, sum / reps * 1e3 / (nL * ncb),
+               h[ENG_CTL_ABORT] ? "  ABORTED" : "");
+        if (h[ENG_CTL_ABORT]) { printf("abort at phase %u\n", h[ENG_CTL_WHERE]); return 1; }
+    }
+    std::vector<unsigned long long> st((size_t)nb * ncb * nL * 16);
+    CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
+    const char* names[10] = {"x ready (B1)", "QKV rows done", "qkv gathered (B1b)", "y ready (B2)", "Wo rows done", "x' gathered (B3)", "W13 rows done", "g gathered (B4)",
+                             "W2 rows done", "own attention done"};
+    const int order[10] = {0, 1, 2, 9, 3, 4, 5, 6, 7, 8};
+    double lo[10] = {0}, md[10] = {0}, hi[10] = {0};
+    int cnt = 0;
+    std::vector<unsigned long long> v(nb);
+    for (int cb = 2; cb < ncb; ++cb) for (int li = 1; li < nL; ++li) {
+        unsigned long long t0 = 0;
+        for (int b = 0; b < nb; ++b) t0 = std::max(t0, st[(((size_t)b * ncb + cb) * nL + li - 1) * 16 + 8]);
+        for (int k = 0; k < 10; ++k) {
+            for (int b = 0; b < nb; ++b) v[b] = st[(((size_t)b * ncb + cb) * nL + li) * 16 + k];
+            std::sort(v.begin(), v.end());
+            lo[k] += (double)v[0] - (double)t0; md[k] += (double)v[nb / 2] - (double)t0; hi[k] += (double)v[nb - 1] - (double)t0;
+        }
+        ++cnt;
+    }
+    printf("chip-wide (steps 2.., layers 1..), us after the last workgroup finished the previous layer's W2 rows (earliest / median / latest):\n");
+    for (int kk = 0; kk < 10; ++kk) { const int k = order[kk]; printf("   %-22s %7.2f %7.2f %7.2f\n", names[k], lo[k] / cnt / 100.0, md[k] / cnt / 100.0, hi[k] / cnt / 100.0); }
+    // per step: time from the last layer's W2 to the next step's first B1 (head + draw + code hand-off)
+    double gap = 0; int gc = 0;
+    for (int cb = 2; cb < ncb; ++cb) {
+        unsigned long long t0 = 0, t1 = ~0ull;
+        for (int b = 0; b < nb; ++b) { t0 = std::max(t0, st[(((size_t)b * ncb + cb - 1) * nL + nL - 1) * 16 + 8]); t1 = std::min(t1, st[(((size_t)b * ncb + cb) * nL + 0) * 16 + 0]); }
+        gap += (double)t1 - (double)t0; ++gc;
+    }
+    printf("head + draw + code hand-off between two steps: %.2f us\n", gap / gc / 100.0);
     return 0;
 }
