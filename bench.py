@@ -1,7 +1,7 @@
 """Headline benchmark: semantic tokens/sec (+ RTF) of the dual-AR decode + codec decode hot path on
 synthetic 10 s utterances at the openaudio-s1-mini shapes (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: this process only launches N ranks, see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,15 +10,21 @@ A "step" = one utterance through the hot path: prefill of a 48-token prompt, 215
 decode of the (10, 215) codes.  Weights and prompts are resident in HBM before the timed region.
 With N > 1 every rank runs its own utterances (the path shards by utterance, no data-path
 collective); weights are broadcast once from rank 0 over RCCL.  Rank 0 prints one JSON line.
+
+`--gpus N` without a torch.distributed environment: this process starts N fresh ranks through
+`python -m torch.distributed.run` BEFORE anything here touches the GPU (a process that has initialised
+the GPU is never re-executed), relays rank 0's JSON line and exits with the launcher's code.
+
+`--config cfg4`: BASELINE configs[3] - every rank decodes 32 mixed-length utterances (prompts U[16,96], frame budgets
+U[108,430], SURVEY §8-d seed 3 + rank) with continuous batching on its 32 slots; value = all ranks' frames / wall.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -26,38 +32,135 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 N_FRAMES = 215         # 10 s at 21.53 frames/s
 PROMPT_LEN = 48
+# algorithmic bytes of one decode frame at the s1-mini shapes: slow layers 880.8 MB + vocabulary head
+# 319.0 MB + fast layers 100.7 MB (once per frame) + fast head 2.1 MB, plus 114 688 bytes of K/V per cached position
+KV_BYTES_PER_POS = 114688
+
+
+def frame_bytes(args):
+    slow = args.n_layer * (args.dim * (args.n_head + 2 * args.n_local_heads) * args.head_dim + args.n_head * args.head_dim * args.dim
+                           + 3 * args.dim * args.intermediate_size) * 2
+    head = args.vocab_size * args.dim * 2
+    fast = args.n_fast_layer * (args.fast_dim * (args.fast_n_head + 2 * args.fast_n_local_heads) * args.fast_head_dim
+                                + args.fast_n_head * args.fast_head_dim * args.fast_dim
+                                + 3 * args.fast_dim * args.fast_intermediate_size) * 2
+    fhead = min(1024, args.codebook_size) * args.fast_dim * 2
+    return {"slow": slow, "head": head, "fast": fast + fhead, "total": slow + head + fast + fhead}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a, argv):
+    """Parent of a multi-GPU run: never touches the GPU.  One child per GPU via torch.distributed.run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    elif r.returncode == 0:
+        print("[bench] the ranks printed no result line", file=sys.stderr)
+        return 1
+    return r.returncode
 
 
 def synth_weights(args, seed=0):
     """Random-init weights by the reference's rule (llama.py:455-464: normal(0, initializer_range) for
     Linear/Embedding, ones for norm gains), bf16."""
+    import torch
     from fish_tts_amd.weights import random_state_dict
     return random_state_dict(args, seed=seed, dtype=torch.bfloat16)
 
 
-def synth_prompt(tok, seed=1):
+def synth_prompt(tok, seed=1, length=PROMPT_LEN):
+    import torch
     g = torch.Generator().manual_seed(seed)
-    p = torch.zeros(11, PROMPT_LEN, dtype=torch.int32)
-    p[0] = torch.randint(0, tok.n_ranks, (PROMPT_LEN,), generator=g)
+    p = torch.zeros(11, length, dtype=torch.int32)
+    p[0] = torch.randint(0, tok.n_ranks, (length,), generator=g)
     p[0, 0] = tok.get_token_id("<|interleave|>")
     return p.numpy()
 
 
-def cpu_baseline(args_dict, sd, prompt, tok, frames=8):
-    """The oracle (CPU restatement of the reference eager path, bf16) timed on the host cores on a
-    bounded sample: prefill of the same prompt + `frames` decode frames."""
+def cpu_baseline(args_dict, sd, prompt, tok, frames=32, codec_frames=N_FRAMES, threads=None):
+    """the oracle (CPU restatement of the reference eager path, bf16 AR / f32 codec) timed on the host
+    cores on a bounded sample of the same workload: prefill of the same prompt (timed apart), `frames` decode frames,
+    one codec decode of `codec_frames` frames; RTF from those rates."""
+    import torch
     from oracle import ar as O
+    ncpu = os.cpu_count() or 1
+    threads = threads or max(1, min(ncpu, 16))   # torch CPU eager does not scale past a socket's worth of cores here
+    torch.set_num_threads(threads)
     shape = O.ARShape(**{k: v for k, v in args_dict.items() if k in O.ARShape.__dataclass_fields__},
                       semantic_begin_id=tok.semantic_begin_id, semantic_end_id=tok.semantic_end_id,
                       im_end_id=tok.get_token_id("<|im_end|>"))
     orc = O.AROracle(shape, sd, torch.bfloat16)
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    p = torch.from_numpy(prompt)
     t0 = time.perf_counter()
-    seq = orc.generate(torch.from_numpy(prompt), frames, temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
-    dt = time.perf_counter() - t0
-    n = seq.shape[1] - prompt.shape[1]
-    return {"value": round(n / dt, 3), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"prefill of the same {PROMPT_LEN}-token prompt + {n} greedy frames, bf16, torch CPU eager "
-                      f"({dt:.1f} s)"}
+    orc.generate(p, 1, **kw)                       # prefill + the frame it yields
+    t_pf = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    seq = orc.generate(p, 1 + frames, **kw)
+    t_all = time.perf_counter() - t0
+    n = seq.shape[1] - prompt.shape[1] - 1
+    dec_s = max(t_all - t_pf, 1e-9)
+    out = {"value": round(n / dec_s, 3), "unit": "tokens/s", "cores": threads, "kind": "port",
+           "sample": f"{n} greedy decode frames after a {prompt.shape[1]}-token prefill (prefill {t_pf:.1f} s timed apart, "
+                     f"decode {dec_s:.1f} s), bf16, torch CPU eager, {threads} of {ncpu} host threads",
+           "prefill_s": round(t_pf, 2)}
+    try:
+        from oracle import codec as OC
+        cs = OC.CodecShape()
+        orc_c = OC.CodecOracle(cs, OC.random_weights(cs, seed=0))
+        codes = torch.randint(0, 1024, (1, cs.n_codebooks + 1, codec_frames))
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            orc_c.decode(codes, torch.tensor([codec_frames]))
+        t_c = time.perf_counter() - t0
+        audio_s = codec_frames * 2048 / 44100.0
+        out["codec_s"] = round(t_c, 2)
+        out["rtf"] = round((audio_s * 21.533 / max(n / dec_s, 1e-9) + t_c + t_pf) / audio_s, 3)
+        out["sample"] += f"; one {codec_frames}-frame codec decode in f32 ({t_c:.1f} s)"
+    except Exception as e:  # noqa: BLE001
+        out["sample"] += f"; codec leg skipped ({type(e).__name__}: {e})"
+    return out
+
+
+def mixed_batch(eng, tok, n_utt, seed, burst=8, reps=2):
+    """BASELINE configs[2]: n_utt utterances (prompts U[16,96], frame budgets U[108,430]) with continuous batching;
+    returns (frames, seconds) of the last of `reps` passes (the first pass warms the graphs of every batch width)."""
+    import numpy as np
+    from fish_tts_amd.batch import Utterance, run_batch
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(16, 97, n_utt)
+    targets = rng.integers(108, 431, n_utt)
+
+    def prompt(L):
+        p = np.zeros((11, L), dtype=np.int32)
+        p[0] = rng.integers(0, tok.n_ranks, L)
+        return p
+    dt = 0.0
+    for rep in range(reps):
+        utts = [Utterance(prompt(int(l)), int(t), 0.7, 0.8, 1.1, seed=i, ban_eos=True) for i, (l, t) in enumerate(zip(lens, targets))]
+        eng.sync()
+        t0 = time.perf_counter()
+        run_batch(eng, utts, burst=burst)
+        dt = time.perf_counter() - t0
+    made = sum(u.columns().shape[1] for u in utts)
+    return made, dt
 
 
 def main():
@@ -65,14 +168,37 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg4"],
+                    help="cfg2 = BASELINE configs[1] (the headline: batch 1, 10 s); cfg4 = configs[3] (32 mixed-length slots per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch-probe", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=32)
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU only: the ranks form a gloo group and rank 0 prints how many it saw (tests/test_bench_launcher.py)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    if a.launcher_selftest:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"metric": "launcher selftest", "n_gpus": int(t.item()), "requested": a.gpus}))
+        dist.destroy_process_group()
+        return
+
+    import numpy as np  # noqa: F401
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -92,9 +218,53 @@ def main():
 
     # weights: generated on rank 0, broadcast once over RCCL, then copied into the engine's own HBM
     sd = synth_weights(args) if rank == 0 else None
+    ranks_seen = 1
     if world > 1:
         from fish_tts_amd.parallel import broadcast_state_dict
         sd = broadcast_state_dict(sd, args, src=0, device=torch.device("cuda", local_rank))
+        seen = torch.ones(1, device="cuda")
+        dist.all_reduce(seen)            # n_gpus in the result line = ranks the RCCL group really has
+        ranks_seen = int(seen.item())
+
+    if a.config == "cfg4":
+        margs = s1_mini_args(max_seq_len=4096)
+        eng = ARHipEngine(margs, tok.semantic_begin_id, tok.semantic_end_id, im_end, precision="bf16", device=local_rank,
+                          max_batch=32, max_new_tokens=512)
+        eng.load_state_dict(sd)
+        made, dtm = 0, 0.0
+        for i in range(max(a.warmup, 1)):     # at least one pass: it captures the graphs of every batch width
+            mixed_batch(eng, tok, 32, seed=1000 + rank, reps=1)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_begin = time.perf_counter()
+        for i in range(a.steps):
+            m, _ = mixed_batch(eng, tok, 32, seed=3 + rank + 100 * i, reps=1)
+            made += m
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t_begin
+        if dist is not None:
+            t = torch.tensor([elapsed, float(made)], device="cuda", dtype=torch.float64)
+            mx, sm = t.clone(), t.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+            elapsed, made = float(mx[0]), float(sm[1])
+        if rank == 0:
+            print(json.dumps({
+                "metric": "semantic tokens/sec", "value": round(made / elapsed, 2), "unit": "tokens/s", "n_gpus": ranks_seen,
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "openaudio-s1-mini shapes (BASELINE configs[3]): 32 mixed-length utterances per GPU "
+                                       "(prompts U[16,96], 108-430 frames), continuous batching on 32 lock-step slots, AR only",
+                           "parallelism": f"replica x{world}", "frames_total": int(made)},
+                "roofline": None, "cpu_baseline": None}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     eng = ARHipEngine(args, tok.semantic_begin_id, tok.semantic_end_id, im_end, precision="bf16",
                       device=local_rank, max_batch=1, max_new_tokens=N_FRAMES + 8)
     eng.load_state_dict(sd)
@@ -153,59 +323,77 @@ def main():
             dist.destroy_process_group()
         return
 
-    # roofline of the dominant kernel family: the weight-streaming GEMV launches whose weights come from HBM
-    # (4 per slow layer + the vocabulary head = 1.2 GB of the 1.303 GB algorithmic bytes of a frame-step),
-    # timed live: a hipGraph of exactly those launches replayed between two HIP events on the engine's stream
+    # ---- roofline of the step's dominant kernel chain: ONE decode frame (slow stack, vocabulary head, semantic draw, fast
+    # codebook loop), timed live with HIP events on the engine's stream.  achieved = algorithmic bytes of a frame
+    # (1.303 GB of weights + 114 688 B of K/V per cached position) / measured frame time.
     sp = eng._sampling(0.7, 0.8, 1.1, seed=7, ban_eos=True)
-    ms, launches, nbytes = eng.profile_gemv(20, sp)
-    achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    fb = frame_bytes(args)
+    eng.prefill(prompt, sp)
+    NPF = 48
+    ms_graph, seg, nodes = eng.profile_frame(NPF, sp)
+    flags = eng.engine_state()[0]
+    pos_mid = PROMPT_LEN + NPF            # mean cached positions over the profiled frames (about)
+    per_frame_bytes = fb["total"] + KV_BYTES_PER_POS * pos_mid
+    frame_ms = ms_graph / NPF
+    achieved = per_frame_bytes / (frame_ms * 1e-3) / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):  # HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes
-        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if os.path.exists(tpath):  # HBM bytes per frame from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this bench (eager frames)
+        traffic = json.load(open(tpath)).get("hbm_bytes_per_frame")
+    parts = {}
+    for name, ms_k, nbytes in (("slow_stack", seg[0], fb["slow"] + KV_BYTES_PER_POS * pos_mid), ("head_and_draw", seg[1], fb["head"]),
+                               ("fast_loop", seg[2], fb["fast"])):
+        per = ms_k / max(NPF - 1, 1)
+        parts[name] = {"ms": round(per, 4), "algorithmic_GB": round(nbytes / 1e9, 4),
+                       "GBps": round(nbytes / (per * 1e-3) / 1e9, 1) if per > 0 else None}
     roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "ft::gemv_kernel / ft::gemv_attn_combine_kernel (slow layers + vocabulary head)",
-            "launches": launches, "bytes_per_launch": round(nbytes / max(launches, 1)),
-            "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 3)}
+            "kernel": ("one decode frame = ft::slow_engine_kernel + vocabulary head gemv + semantic draw + ft::fast_engine_kernel"
+                       if flags == 3 else "one decode frame (launch path: gemv / attention / sampler kernels)"),
+            "launches_per_frame": nodes, "bytes_per_launch": int(per_frame_bytes), "avg_us_per_launch": round(frame_ms * 1e3, 2),
+            "frame_ms": round(frame_ms, 4), "parts": parts}
+    try:   # sub-field kept from round 1: the HBM-streamed GEMV launches of the launch path alone
+        ms, launches, nbytes = eng.profile_gemv(20, sp)
+        roof["gemv_launch_path"] = {"GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "launches": launches,
+                                    "avg_us_per_launch": round(ms * 1e3 / max(launches, 1), 3)}
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] gemv sub-profile skipped: {e}", file=sys.stderr)
 
     audio_s = frames_total * 2048 / 44100.0
     tok_s = frames_total / elapsed  # whole step (prefill + decode + codec) over all ranks
     out = {
         "metric": "semantic tokens/sec", "value": round(tok_s, 2),
-        "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "unit": "tokens/s", "n_gpus": ranks_seen, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "openaudio-s1-mini shapes (BASELINE configs[1]): batch=1 per GPU, 48-token prompt, "
                                "215 frames (10 s), top-p sampling, hipGraph-captured frame step"
                                + (", + DAC codec decode" if codec is not None else ", codec decode NOT included"),
-                   "frames_per_step": N_FRAMES, "prompt_len": PROMPT_LEN, "parallelism": f"replica x{world}"},
+                   "frames_per_step": N_FRAMES, "prompt_len": PROMPT_LEN, "parallelism": f"replica x{world}",
+                   "frame_engine": flags},
         "ar_tokens_per_s": round(frames_total / (ar_max if world > 1 else ar_s), 2),
         "rtf": round(elapsed / audio_s * world, 5) if codec is not None else None,
         "codec_ms_per_step": round(cod_s / a.steps * 1e3, 3) if codec is not None else None,
         "roofline": roof,
     }
-    # extra, outside the timed region and never part of `value`: BASELINE configs[2]'s lock-step batch on this GPU
-    out["lockstep_batch32_tokens_per_s"] = None
+    # ---- extras, outside the timed region and never part of `value`, each with its own wall clock and frame count:
+    # BASELINE configs[2] (32 slots, mixed lengths, continuous batching) and configs[4] (voice cloning, B = 8, streamed)
+    out["configs"] = {}
     if world == 1 and not a.no_batch_probe:
         try:
-            from fish_tts_amd.config import s1_mini_args as _s1
             eng.close()
-            beng = ARHipEngine(_s1(max_seq_len=1024), tok.semantic_begin_id, tok.semantic_end_id, im_end, precision="bf16",
-                               device=local_rank, max_batch=32, max_new_tokens=160)
+            margs = s1_mini_args(max_seq_len=4096)
+            beng = ARHipEngine(margs, tok.semantic_begin_id, tok.semantic_end_id, im_end, precision="bf16",
+                               device=local_rank, max_batch=32, max_new_tokens=512)
             beng.load_state_dict(sd)
-            sps = [beng._sampling(0.7, 0.8, 1.1, seed=i, ban_eos=True) for i in range(32)]
-            for rep in range(2):
-                for b in range(32):
-                    beng.prefill(prompt, sps[b], slot=b)
-                beng.sync()
-                t0 = time.perf_counter()
-                _, nb = beng.decode(128, sps, poll=128)
-                dtb = time.perf_counter() - t0
-            out["lockstep_batch32_tokens_per_s"] = round(float(nb.sum()) / dtb, 1)
+            made, dtm = mixed_batch(beng, tok, 32, seed=2)
+            out["configs"]["configs[2] batch=32 mixed lengths, continuous batching"] = {
+                "frames": int(made), "wall_s": round(dtm, 4), "tokens_per_s": round(made / dtm, 1),
+                "ar_rtf": round(dtm / (made * 2048 / 44100.0), 5)}
             beng.close()
+            out["configs"]["configs[4] voice cloning B=8 streamed"] = voice_cloning_probe(sd, tok, im_end, local_rank)
         except Exception as e:  # noqa: BLE001
-            print(f"[bench] batch probe skipped: {e}", file=sys.stderr)
+            print(f"[bench] batch probes skipped: {type(e).__name__}: {e}", file=sys.stderr)
     if not a.no_cpu_baseline and world == 1:
         cpu_sd = {k: v.cpu() for k, v in sd.items()}
         out["cpu_baseline"] = cpu_baseline(args.__dict__, cpu_sd, prompt, tok, frames=a.cpu_frames)
@@ -214,6 +402,54 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def voice_cloning_probe(sd, tok, im_end, device):
+    """BASELINE configs[4]: 8 utterances that share a 30 s reference (661 frames) + 49 text tokens each, reference K/V
+    built once and restored per slot, frames streamed in bursts of 5; time to the 10th frame of every slot + tok/s."""
+    import numpy as np
+    from fish_tts_amd.ar_engine import ARHipEngine
+    from fish_tts_amd.batch import Utterance, run_batch
+    from fish_tts_amd.config import s1_mini_args
+    rng = np.random.default_rng(3)
+    B = 8
+    eng = ARHipEngine(s1_mini_args(max_seq_len=4096), tok.semantic_begin_id, tok.semantic_end_id, im_end, precision="bf16",
+                      device=device, max_batch=B, max_new_tokens=512)
+    eng.load_state_dict(sd)
+    ref = np.concatenate([rng.integers(0, 4096, (1, 661)), rng.integers(0, 1024, (9, 661))]).astype(np.int32)
+    head = np.zeros((11, 2 + 64 + 661 + 1), dtype=np.int32)
+    head[0, : 2 + 64] = rng.integers(0, tok.n_ranks, 66)
+    head[0, 66: 66 + 661] = ref[0] + tok.semantic_begin_id
+    head[1:, 66: 66 + 661] = ref
+    head[0, -1] = im_end
+    res = {}
+    for rep in range(2):
+        t0 = time.perf_counter()
+        pf = eng.build_prefix(head)
+        eng.sync()
+        t_build = time.perf_counter() - t0
+        utts = []
+        for i in range(B):
+            text = np.zeros((11, 49), dtype=np.int32)
+            text[0] = rng.integers(0, tok.n_ranks, 49)
+            utts.append(Utterance(np.concatenate([head, text], axis=1), 215, 0.7, 0.8, 1.1, seed=i, ban_eos=True, prefix=pf))
+        first10, count = {}, [0] * B
+        eng.sync()
+        t0 = time.perf_counter()
+
+        def on_frames(i, blk):
+            count[i] += blk.shape[1]
+            if count[i] >= 10 and i not in first10:
+                first10[i] = time.perf_counter() - t0
+        run_batch(eng, utts, burst=5, on_frames=on_frames)
+        dt = time.perf_counter() - t0
+        pf.free()
+        made = sum(u.columns().shape[1] for u in utts)
+        res = {"frames": int(made), "wall_s": round(dt, 4), "tokens_per_s": round(made / dt, 1),
+               "first_10_frames_all_slots_ms": round(max(first10.values()) * 1e3, 1), "reference_kv_build_ms": round(t_build * 1e3, 1),
+               "prompt_len": int(utts[0].prompt.shape[1])}
+    eng.close()
+    return res
 
 
 if __name__ == "__main__":

@@ -73,6 +73,8 @@ SYMBOLS = {
     "ft_codec_rvq_encode": (C.c_int32, [_P, _P, C.c_int32, _P]),
     "ft_ar_profile_gemv": (C.c_int32, [_P, C.c_int32, C.POINTER(ft_sampling), C.POINTER(C.c_double),
                                        C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "ft_ar_profile_frame": (C.c_int32, [_P, C.c_int32, C.POINTER(ft_sampling), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_int32)]),
     "ft_sync": (C.c_int32, [_P]),
     "ft_ar_engine_state": (C.c_int32, [_P, _P, _P, _P]),
     "ft_test_sample": (C.c_int32, [_P, _P, C.c_int32, C.POINTER(ft_sampling), _P, _P, _P]),

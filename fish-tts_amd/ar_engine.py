@@ -262,6 +262,15 @@ class ARHipEngine:
         return ms.value, n.value, b.value
 
     # ------------------------------------------------------------------ generate (inference.py:281-384)
+    def profile_frame(self, frames: int, sampling: L.ft_sampling):
+        """(ms of `frames` graph replays, [ms slow stack, ms head + draw, ms fast loop] over frames-1 eager frames,
+        launches per captured frame) - slot 0 must be prefilled."""
+        ms, n = C.c_double(0), C.c_int32(0)
+        seg = (C.c_double * 3)()
+        self._check(self.lib.ft_ar_profile_frame(self._h, frames, C.byref(sampling), C.byref(ms), seg, C.byref(n)),
+                    "ft_ar_profile_frame")
+        return ms.value, [seg[0], seg[1], seg[2]], n.value
+
     def _clamp_new(self, T: int, max_new_tokens: int) -> int:
         m = self.args.max_seq_len
         if T >= m:

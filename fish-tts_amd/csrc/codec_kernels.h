@@ -742,12 +742,10 @@ static inline void skinny_gemm_launch(const TapGemmP& p, int gy, hipStream_t st)
 #define FT_SK(NWV, NORMV, XV)                                                                                       \
     do {                                                                                                              \
         constexpr size_t lds_ = skinny_lds_bytes<TS, NWV>(XV);                                                        \
-        static bool attr_ = false;                                                                                    \
-        if (!attr_ && lds_ > 48 * 1024) {                                                                             \
-            hipFuncSetAttribute((const void*)skinny_gemm_kernel<TS, NWV, NORMV, XV>,                                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                               \
-            attr_ = true;                                                                                             \
-        }                                                                                                             \
+        static DevOnce once_;                                                                                         \
+        if (lds_ > 48 * 1024)                                                                                         \
+            once_.run([] { hipFuncSetAttribute((const void*)skinny_gemm_kernel<TS, NWV, NORMV, XV>,                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); });            \
         skinny_gemm_kernel<TS, NWV, NORMV, XV><<<grid, NWV * 64, lds_, st>>>(p);                                      \
     } while (0)
 #define FT_SK_X(NWV, NORMV) do { if (xlds) FT_SK(NWV, NORMV, true); else FT_SK(NWV, NORMV, false); } while (0)

@@ -3,7 +3,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace ft {
+
+// hipFuncSetAttribute applies to the CURRENT device's function object, and a process may hold contexts on several
+// GPUs (FishTTS(gpu_index=...)) driven from several threads: remember per device which opt-ins were made.  A thread
+// publishes its device's bit only after it has set the attribute itself (two threads may both set it: harmless).
+struct DevOnce {
+    std::atomic<unsigned long long> mask{0};
+    template <typename F> void run(F&& set) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const unsigned long long bit = 1ull << (d & 63);
+        if (mask.load(std::memory_order_acquire) & bit) return;
+        set();
+        mask.fetch_or(bit, std::memory_order_release);
+    }
+};
 
 typedef uint16_t bf16_t;  // raw bf16 bits
 

@@ -111,6 +111,7 @@ struct ft_ctx {
     size_t eng_lds_slow = 0, eng_lds_fast = 0, eng_fast_words = 0;
 
     std::map<int, hipGraphExec_t> graphs;
+    std::map<int, int> graph_nodes;   // nodes of each captured frame graph (launches per frame)
 
     // measurement hook
     bool prof = false, prof_count_only = false;

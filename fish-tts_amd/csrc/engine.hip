@@ -685,12 +685,9 @@ static void attn_decode(Launch& L, const AttnP& p) {
         case 2: attn_decode_kernel<WT, 2, ROUND><<<grid, block, lds, L.s>>>(p); break;
         case 4: attn_decode_kernel<WT, 4, ROUND><<<grid, block, lds, L.s>>>(p); break;
         case 8: {
-            static bool attr_done = false;
-            if (!attr_done) {
-                hipFuncSetAttribute((const void*)attn_decode_kernel<WT, 8, ROUND>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr_done = true;
-            }
+            static DevOnce once;     // per device (the opt-in belongs to the current device's function object)
+            once.run([&] { hipFuncSetAttribute((const void*)attn_decode_kernel<WT, 8, ROUND>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
             attn_decode_kernel<WT, 8, ROUND><<<grid, block, lds, L.s>>>(p);
             break;
         }
@@ -900,14 +897,13 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
         b.part_idx = ctx->samp_part_idx + (size_t)m0 * b.nchunk;
         const dim3 gridc(b.nchunk, L.M);
         {
-            static bool attr_done = false;
-            if (!attr_done) {
+            static DevOnce once;     // per device
+            once.run([] {
                 hipFuncSetAttribute((const void*)samp_threshold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)SAMP_TH_LDS);
                 hipFuncSetAttribute((const void*)samp_cut_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)SAMP_TH_LDS);
-                attr_done = true;
-            }
+            });
         }
         // histogram + cut search of a row in one block (LDS counters); FT_SAMPLER_GLOBAL_HIST selects the first
         // implementation (global-atomic histogram, then the cut search on its read-back)
@@ -1402,6 +1398,7 @@ static ft_status get_graph(ft_ctx* ctx, int M, hipGraphExec_t* out) {
         return ft_fail(ctx, FT_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(e));
     }
     hipGraphExec_t exec = nullptr;
+    { size_t nn = 0; if (hipGraphGetNodes(graph, nullptr, &nn) == hipSuccess) ctx->graph_nodes[key] = (int)nn; }
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     hipGraphDestroy(graph);
     if (e != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("graph instantiate: ") + hipGetErrorString(e));
@@ -1649,6 +1646,60 @@ extern "C" ft_status ft_ar_profile_gemv(ft_ctx* ctx, int32_t frames, const ft_sa
     for (auto e : ctx->prof_ev) hipEventDestroy(e);
     ctx->prof_ev.clear();
     return FT_OK;
+}
+
+extern "C" ft_status ft_ar_profile_frame(ft_ctx* ctx, int32_t frames, const ft_sampling* sp, double* ms_graph,
+                                         double* seg_ms, int32_t* nodes_per_frame) {
+    FT_TRY(ar_ready(ctx));
+    if (!sp || frames < 1) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_profile_frame: bad argument");
+    const ft_ar_config& c = ctx->c;
+    const int R = c.num_codebooks + 1;
+    FT_TRY(upload_ctl(ctx, 0, 1, sp));
+    int h[2] = {0, 0};
+    FT_HIP(ctx, hipMemcpy(h, ctx->d_nf, sizeof(int), hipMemcpyDeviceToHost));
+    FT_HIP(ctx, hipMemcpy(h + 1, ctx->d_pos, sizeof(int), hipMemcpyDeviceToHost));
+    if (h[0] < 1) return ft_fail(ctx, FT_ERR_STATE, "ft_ar_profile_frame: slot 0 has not been prefilled");
+    if (h[0] + 2 * frames + 2 > ctx->cap || h[1] + 2 * frames + 2 > ctx->n_slots)
+        return ft_fail(ctx, FT_ERR_ARG, "ft_ar_profile_frame: not enough frame / cache capacity left in slot 0");
+    hipEvent_t ev[4];
+    for (auto& e : ev) FT_HIP(ctx, hipEventCreate(&e));
+    // (1) the captured frame graph, replayed back to back
+    hipGraphExec_t exec = nullptr;
+    FT_TRY(get_graph(ctx, 1, &exec));
+    FT_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+    FT_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
+    for (int f = 0; f < frames; ++f) FT_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+    FT_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float t = 0.f;
+    FT_HIP(ctx, hipEventElapsedTime(&t, ev[0], ev[1]));
+    if (ms_graph) *ms_graph = t;
+    if (nodes_per_frame) { auto it = ctx->graph_nodes.find(1 * 64 + ctx->nsplit); *nodes_per_frame = it == ctx->graph_nodes.end() ? 0 : it->second; }
+    // (2) the same frame launched eagerly, events between its three parts (bf16 only)
+    double seg[3] = {0, 0, 0};
+    if (seg_ms && c.dtype == FT_BF16) {
+        for (int f = 0; f < frames - 1; ++f) {
+            Launch L{ctx, ctx->stream, 0, 1, 0};
+            FT_HIP(ctx, hipEventRecord(ev[0], ctx->stream));
+            if (eng_slow_ok(L)) enqueue_slow_engine(L, ctx->d_tok, 1, R, 0);
+            else enqueue_slow<bf16_t, true>(L, ctx->d_tok, 1, R, 0, true);
+            FT_HIP(ctx, hipEventRecord(ev[1], ctx->stream));
+            enqueue_head<bf16_t, true>(L);
+            enqueue_sample<bf16_t, true>(L, 0, c.num_codebooks == 1);
+            FT_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+            if (eng_fast_ok(L)) enqueue_fast_engine(L);
+            else for (int cb = 0; cb < c.num_codebooks; ++cb) enqueue_fast_step<bf16_t, true>(L, cb);
+            FT_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
+            FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, "ft_ar_profile_frame: launch failed");
+            for (int k = 0; k < 3; ++k) { float d = 0.f; hipEventElapsedTime(&d, ev[k], ev[k + 1]); seg[k] += d; }
+        }
+        for (int k = 0; k < 3; ++k) seg_ms[k] = seg[k];
+    } else if (seg_ms) {
+        seg_ms[0] = seg_ms[1] = seg_ms[2] = 0.0;
+    }
+    for (auto& e : ev) hipEventDestroy(e);
+    return eng_check(ctx);
 }
 
 extern "C" ft_status ft_test_sample(ft_ctx* ctx, const float* logits, int32_t cb, const ft_sampling* sp,

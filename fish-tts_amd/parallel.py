@@ -62,7 +62,9 @@ def synthesize_sharded(tts, texts: Sequence[str], dst: int = 0, **kw):
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     share = deal_utterances([len(t) for t in texts], world)[rank]
-    wavs = tts.synthesize_batch([texts[i] for i in share], seed=kw.pop("seed", 0) + (share[0] if share else 0), **kw) if share else []
+    seed = kw.pop("seed", 0)
+    # utterance i draws with seed + i whatever the world size and whatever else its rank was dealt
+    wavs = tts.synthesize_batch([texts[i] for i in share], seeds=[seed + i for i in share], **kw) if share else []
     gathered = [None] * world if rank == dst else None
     dist.gather_object(list(zip(share, wavs)), gathered, dst=dst)
     if rank != dst:

@@ -237,14 +237,18 @@ class FishTTS:
 
     def synthesize_batch(self, texts: List[str], references: Optional[List[VoiceProfile]] = None,
                          temperature: float = 0.7, top_p: float = 0.8, repetition_penalty: float = 1.1,
-                         max_tokens: int = 2048, seed: int = 0) -> List[bytes]:
+                         max_tokens: int = 2048, seed: int = 0, seeds: Optional[List[int]] = None) -> List[bytes]:
         """Extension (BASELINE configs[2]): many texts -> WAV bytes each, decoded `max_batch` at a time in lock step
-        with refill (fish_tts_amd.batch); utterance i uses seed + i.  Same per-utterance semantics as synthesize()."""
+        with refill (fish_tts_amd.batch); utterance i uses seed + i, or seeds[i] when `seeds` is given (a sharded run
+        passes the GLOBAL indices so an utterance draws the same noise on any number of GPUs).  Same per-utterance
+        semantics as synthesize()."""
         from .batch import Utterance, run_batch
         from .prompt import build_prompt_split
         assert 0 < top_p <= 1, "top_p must be in (0, 1]"
         assert 0 < repetition_penalty < 2, "repetition_penalty must be in (0, 2)"
         assert 0 < temperature < 2, "temperature must be in (0, 2)"
+        if seeds is not None and len(seeds) != len(texts):
+            raise ValueError("seeds must have one entry per text")
         prompt_text, prompt_tokens = self._get_prompt_data(references)
         ncb = self._engine.args.num_codebooks
         with self._gen_lock:
@@ -256,7 +260,8 @@ class FishTTS:
                 prefix = None
                 if self._prefix_cache is not None and n_prefix >= self._prefix_cache.min_positions:
                     prefix = self._prefix_cache.get(self._engine, enc[:, :n_prefix])
-                utts.append(Utterance(enc, max_tokens, temperature, top_p, repetition_penalty, seed + i, prefix=prefix))
+                utts.append(Utterance(enc, max_tokens, temperature, top_p, repetition_penalty, seeds[i] if seeds is not None else seed + i,
+                                      prefix=prefix))
             run_batch(self._engine, utts)
         out = []
         for u in utts:

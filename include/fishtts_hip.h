@@ -157,6 +157,14 @@ ft_status ft_codec_rvq_encode(ft_ctx* ctx, const float* z, int32_t T, int32_t* c
  * launches timed and the algorithmic bytes those launches stream. */
 ft_status ft_ar_profile_gemv(ft_ctx* ctx, int32_t frames, const ft_sampling* sp, double* ms,
                              int64_t* launches, int64_t* bytes);
+/* Measurement hook used by bench.py (never by the product path): `frames` real decode frames of slot 0 (prefilled by
+ * the caller, enough frame / cache capacity left) timed with HIP events on the engine's own stream.
+ * ms_graph: elapsed ms of `frames` back-to-back replays of the captured frame graph (what ft_ar_decode runs);
+ * seg_ms[3]: ms summed over frames-1 further frames launched eagerly with events between the three parts of a frame:
+ * the slow stack, the vocabulary head + semantic draw, the fast codebook loop (bf16 only, else zeros);
+ * nodes_per_frame: launches in the captured frame.  Reference: one decode_one_token_ar call, inference.py:83-155. */
+ft_status ft_ar_profile_frame(ft_ctx* ctx, int32_t frames, const ft_sampling* sp, double* ms_graph,
+                              double* seg_ms, int32_t* nodes_per_frame);
 ft_status ft_sync(ft_ctx* ctx);
 /* State of the persistent frame engine (csrc/frame_engine.h), the batch-1 form of the decode step
  * (fish_tts/models/inference.py:83-155 as two launches of one workgroup per CU instead of ~325 launches).

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import ar as O
-from tests.hip_util import NoiseTape, first_divergence, make_pair
+from tests.hip_util import NoiseTape, args_from_shape, first_divergence, make_pair
 from tests.shapes import make_prompt, tiny_shape, tiny_shape_b
 
 pytestmark = pytest.mark.gpu
@@ -536,3 +536,38 @@ def test_large_vocabulary_sampler_vs_oracle(monkeypatch):
                 bad.append((mode, ci, tp, temp, rep, got, want))
         eng.close()
         assert not bad, bad[:6]
+
+
+def test_state_dict_with_extra_keys_loads_like_strict_false():
+    """The reference loads with load_state_dict(strict=False, assign=True) (llama.py:498): keys the model does not have -
+    an `output.weight` saved beside tied embeddings, training-only tensors - are ignored; a missing weight still fails."""
+    from fish_tts_amd.ar_engine import ARHipEngine, HipError
+    shape = tiny_shape()
+    prompt = make_prompt(shape, 9, seed=3, n_vq=2).numpy()
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    eng, _ = make_pair(shape, "fp32")
+    want = eng.generate(prompt, 6, **kw)
+    eng.close()
+    w = O.random_weights(shape, seed=0)
+    extra = dict(w)
+    extra["output.weight"] = w["embeddings.weight"].clone()          # tied model: the head is the embedding table
+    extra["some_training_only.ema_decay"] = torch.zeros(3)
+    eng = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,
+                      precision="fp32", device=0, max_batch=1, max_new_tokens=64)
+    eng.load_state_dict({k: v.float() for k, v in extra.items()})
+    assert np.array_equal(eng.generate(prompt, 6, **kw), want)
+    eng.close()
+    # a mis-shaped tensor is still an error, and so is a missing one
+    eng = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,
+                      precision="fp32", device=0, max_batch=1, max_new_tokens=64)
+    bad = dict(w)
+    bad["norm.weight"] = torch.ones(shape.dim + 1)
+    with pytest.raises(HipError):
+        eng.load_state_dict({k: v.float() for k, v in bad.items()})
+    eng.close()
+    eng = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,
+                      precision="fp32", device=0, max_batch=1, max_new_tokens=64)
+    missing = {k: v.float() for k, v in w.items() if k != "norm.weight"}
+    with pytest.raises(HipError):
+        eng.load_state_dict(missing)
+    eng.close()

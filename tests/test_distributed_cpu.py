@@ -37,14 +37,16 @@ def _worker(rank, world, port, q):
     mine = deal_utterances([5, 9, 3, 7], world)[rank]
 
     class FakeTTS:   # stands in for FishTTS(max_batch=...) on a GPU: records what this rank was asked to speak
-        def synthesize_batch(self, texts, seed=0, **kw):
-            return [f"rank{rank}:{t}".encode() for t in texts]
+        def synthesize_batch(self, texts, seed=0, seeds=None, **kw):
+            return [f"rank{rank}:{t}:{s}".encode() for t, s in zip(texts, seeds)]
     from fish_tts_amd.parallel import synthesize_sharded
     texts = ["bb", "a", "dddd", "ccc", "eeeee"]
-    wavs = synthesize_sharded(FakeTTS(), texts, dst=0)
+    wavs = synthesize_sharded(FakeTTS(), texts, dst=0, seed=100)
     sharded_ok = True
     if rank == 0:
         sharded_ok = [w.split(b":")[1].decode() for w in wavs] == texts and len({w.split(b":")[0] for w in wavs}) == world
+        # utterance i was drawn with seed + i on whichever rank spoke it
+        sharded_ok = sharded_ok and [int(w.split(b":")[2]) for w in wavs] == [100 + i for i in range(len(texts))]
     else:
         sharded_ok = wavs is None
     q.put((rank, ok and sharded_ok, mine))
