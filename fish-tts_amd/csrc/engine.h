@@ -108,7 +108,8 @@ struct ft_ctx {
     unsigned long long* eng_gpart = nullptr;
     unsigned* eng_fast_g = nullptr;   // granule buffers of the fast stack (one allocation)
     unsigned* eng_ctl = nullptr;
-    size_t eng_lds_slow = 0, eng_lds_fast = 0, eng_fast_words = 0;
+    size_t eng_lds_slow = 0, eng_lds_fast = 0, eng_fast_words = 0, eng_pool_words = 0;
+    bool eng_relay = true;        // per-XCD replicas of the hand-off buffers (FT_NO_RELAY: every workgroup polls the source)
 
     std::map<int, hipGraphExec_t> graphs;
     std::map<int, int> graph_nodes;   // nodes of each captured frame graph (launches per frame)

@@ -283,7 +283,7 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     if (ctx->samp_chunk_cnt) hipFree(ctx->samp_chunk_cnt);
     if (ctx->samp_part_score) hipFree(ctx->samp_part_score);
     if (ctx->samp_part_idx) hipFree(ctx->samp_part_idx);
-    { void* eb[] = {ctx->eng_layers, ctx->eng_flayers, ctx->eng_gx, ctx->eng_gqkv, ctx->eng_gy, ctx->eng_gxb, ctx->eng_gg,
+    { void* eb[] = {ctx->eng_layers, ctx->eng_flayers, ctx->eng_gx /* pool: gxb, gg, gy, gqkv live in it */,
                     ctx->eng_gpart, ctx->eng_fast_g, ctx->eng_ctl}; for (void* q : eb) if (q) hipFree(q); }
     if (ctx->h_pin) hipHostFree(ctx->h_pin);
     for (auto e : ctx->prof_ev) hipEventDestroy(e);
@@ -451,12 +451,16 @@ static ft_status eng_setup(ft_ctx* ctx) {
         return FT_OK;
     };
     const size_t L = c.n_layer;
-    const size_t VB = (size_t)nb * ENG_LINE * 4;   // a hand-off buffer holds one 128-byte line per producing workgroup
-    FT_TRY(zalloc((void**)&ctx->eng_gx, (L + 1) * VB));
-    FT_TRY(zalloc((void**)&ctx->eng_gqkv, L * VB));
-    FT_TRY(zalloc((void**)&ctx->eng_gy, L * HD * 4));
-    FT_TRY(zalloc((void**)&ctx->eng_gxb, L * VB));
-    FT_TRY(zalloc((void**)&ctx->eng_gg, L * VB));
+    const size_t VB = (size_t)nb * ENG_LINE * 4;   // bytes reserved per hand-off vector (one 128-byte line per workgroup)
+    // one pool [gx | gxb | gg | gy | gqkv], followed by the eight per-XCD replicas of it (XCD relay)
+    const size_t pool_words = ((L + 1) * VB + 3 * L * VB + L * HD * 4) / 4;
+    ctx->eng_relay = getenv("FT_NO_RELAY") == nullptr;
+    FT_TRY(zalloc((void**)&ctx->eng_gx, pool_words * 4 * (ctx->eng_relay ? 9 : 1)));
+    ctx->eng_pool_words = pool_words;
+    ctx->eng_gxb = ctx->eng_gx + (L + 1) * (VB / 4);
+    ctx->eng_gg = ctx->eng_gxb + L * (VB / 4);
+    ctx->eng_gy = ctx->eng_gg + L * (VB / 4);
+    ctx->eng_gqkv = ctx->eng_gy + L * HD;
     FT_TRY(zalloc((void**)&ctx->eng_gpart, L * c.n_head * ctx->nsplit_max * (size_t)(c.head_dim + 2) * 8));
     FT_TRY(zalloc((void**)&ctx->eng_ctl, ENG_CTL_WORDS * 4));
     const int G = c.n_head / c.n_local_heads, hd = c.head_dim, NSLOT = 4 * (64 / (hd >> 3));
@@ -489,7 +493,7 @@ static ft_status eng_setup(ft_ctx* ctx) {
     const size_t nLf = c.n_fast_layer;
     // [2 parities]: gx (nLf + 1), gqkv, gxb, gg (nLf each), glog (1); then one line per codebook for the drawn codes
     ctx->eng_fast_words = (2 * ((nLf + 1) + 3 * nLf + 1)) * (VB / 4) + (size_t)c.num_codebooks * ENG_LINE;
-    FT_TRY(zalloc((void**)&ctx->eng_fast_g, ctx->eng_fast_words * 4));
+    FT_TRY(zalloc((void**)&ctx->eng_fast_g, ctx->eng_fast_words * 4 * (ctx->eng_relay ? 9 : 1)));
     size_t ff = (size_t)c.fast_dim * 2 + fqkvN + HDf + c.fast_intermediate_size + ctx->fastV + ENG_MAX_OUT + 8 + 32 + 32 + 12 + 2048 + 4 + 4 + 16;
     ctx->eng_lds_fast = ff * sizeof(float) + (size_t)nLf * 2 * c.num_codebooks * c.fast_n_local_heads * c.fast_head_dim * 2 + 64;
     if (ctx->eng_lds_fast > 160 * 1024) return FT_OK;
@@ -572,6 +576,7 @@ static void enqueue_fast_engine(Launch& L) {
     p.glog = g; g += 2 * VW;
     p.gcode = g;
     p.ctl = ctx->eng_ctl;
+    p.rep_delta0 = ctx->eng_relay ? (long)ctx->eng_fast_words : 0; p.rep_stride = ctx->eng_relay ? (long)ctx->eng_fast_words : 0;
     SampP s{};
     s.logits = nullptr; s.ldl = ctx->fastV; s.V = ctx->fastV;
     s.ctl = ctx->d_ctl + m0; s.tokn = ctx->d_tokn + (size_t)m0 * R; s.seq = ctx->d_seq + (size_t)m0 * R * ctx->cap;
@@ -603,6 +608,7 @@ static void enqueue_slow_engine(Launch& L, const int* toks, long tok_row_stride,
     p.cache_off = (size_t)m0 * ctx->cache_m_stride;
     p.gx = ctx->eng_gx; p.gqkv = ctx->eng_gqkv; p.gpart = ctx->eng_gpart; p.gy = ctx->eng_gy; p.gxb = ctx->eng_gxb; p.gg = ctx->eng_gg;
     p.ctl = ctx->eng_ctl; p.x_out = ctx->x + (size_t)m0 * c.dim; p.nt = ctx->nt_weights;
+    p.rep_delta0 = ctx->eng_relay ? (long)ctx->eng_pool_words : 0; p.rep_stride = ctx->eng_relay ? (long)ctx->eng_pool_words : 0;
     slow_engine_kernel<2, 4, 6, 2><<<ctx->eng_nb, ENG_THREADS, ctx->eng_lds_slow, L.s>>>(p);
     L.chk();
 }

@@ -44,7 +44,7 @@ typedef __attribute__((address_space(1))) unsigned long long eng_gu64;
 #define ENG_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 // control words (device memory, zeroed at creation)
-enum { ENG_CTL_EPOCH = 0, ENG_CTL_ABORT = 1, ENG_CTL_EXIT = 2, ENG_CTL_WHERE = 3, ENG_CTL_WORDS = 16 };
+enum { ENG_CTL_EPOCH = 0, ENG_CTL_ABORT = 1, ENG_CTL_EXIT = 2, ENG_CTL_WHERE = 3, ENG_CTL_ARRIVED = 4, ENG_CTL_XCD = 16, ENG_CTL_WORDS = 32 };
 
 struct EngLayer {   // device-resident table, one entry per transformer block
     const bf16_t *wqkv, *bqkv, *attn_norm, *qn, *kn, *wo, *bo, *ffn_norm, *w13, *w2;
@@ -219,6 +219,63 @@ __device__ __forceinline__ void eng_gather(const unsigned* g, EngLayout lay, int
 }
 
 // ------------------------------------------------------------------------------------------
+// XCD relay.  Every CU needs every vector, but 256 CUs polling the same memory lines is what makes a hand-off cost
+// 2.4-3 us (each poll and each producer store queues behind ~1000 other requests for those lines).  So only ONE
+// workgroup per XCD and 1 KiB piece polls memory (8 pollers per line instead of 256); it copies the piece into its XCD's
+// replica of the buffer with PLAIN stores, which stay in that XCD's L2, and the 32 CUs of the XCD poll the replica
+// (sc1 loads: past their L1, served by the L2 they share with the importer).  The XCD of a workgroup is read from the
+// hardware (XCC_ID), never assumed from blockIdx; replicas carry the same self-validating {tag, value} granules.
+// ------------------------------------------------------------------------------------------
+#ifndef ENG_RELAY
+#define ENG_RELAY 1
+#endif
+struct EngRelay {
+    int on;          // 0: every workgroup polls the source buffer itself
+    int rank, nr;    // this workgroup's rank among the nr workgroups of its XCD
+    long delta;      // words from a source address to the same vector in this XCD's replica
+};
+
+// Called by thread 0 of every workgroup at kernel entry (results go to LDS r[0..2]); all workgroups of a launch are
+// co-resident, so waiting for all of them to have registered is safe (and bounded).
+__device__ __forceinline__ void eng_register(unsigned* ctl, int nb, int* r, int* dead) {
+    const int xcd = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u);    // HW_REG_XCC_ID[3:0]
+    const unsigned rank = atomicAdd(ctl + ENG_CTL_XCD + xcd, 1u);
+    atomicAdd(ctl + ENG_CTL_ARRIVED, 1u);
+    EngSpin sp{ctl, dead, 0, 0, 9999};
+    bool ok = true;
+    while (__hip_atomic_load((eng_gu32*)(ctl + ENG_CTL_ARRIVED), ENG_RLX) < (unsigned)nb) {
+        if (sp.give_up(0)) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    r[0] = xcd; r[1] = (int)rank;
+    r[2] = ok ? (int)__hip_atomic_load((eng_gu32*)(ctl + ENG_CTL_XCD + xcd), ENG_RLX) : 1;
+}
+
+template <typename DMap = EngIdent>
+__device__ __forceinline__ void eng_gather_x(const EngRelay& rl, const unsigned* g, EngLayout lay, int u0, int n, unsigned tag, float* dst,
+                                             int gw, int ngw, int lane, unsigned* ctl, int* dead, int where, DMap dmap = DMap(),
+                                             unsigned long long* dbg = nullptr) {
+    if (!rl.on) { eng_gather(g, lay, u0, n, tag, dst, gw, ngw, lane, ctl, dead, where, dmap, dbg); return; }
+    unsigned* rep = const_cast<unsigned*>(g) + rl.delta;
+    // import duty: piece p belongs to the workgroup of rank p % nr of every XCD, and there to wave p % ngw
+    const int npiece = (n + 255) >> 8;
+    for (int p = rl.rank; p < npiece; p += rl.nr) {
+        if (p % ngw != gw) continue;
+        const int i = p * 256 + lane * 4 < n ? p * 256 + lane * 4 : p * 256;
+        const int o = lay.off(u0 + i);
+        EngSpin sp{ctl, dead, 0, 0, where};
+        U4 a;
+        for (;;) {
+            eng_ld1_sc1(g + o, a);
+            if (__all(eng_tags_ok(a, tag))) break;
+            if (sp.give_up(lane)) return;
+        }
+        if (p * 256 + lane * 4 < n) *reinterpret_cast<U4*>(rep + o) = a;      // plain store: stays in this XCD's L2
+    }
+    eng_gather(rep, lay, u0, n, tag, dst, gw, ngw, lane, ctl, dead, where, dmap, dbg);
+}
+
+// ------------------------------------------------------------------------------------------
 // One matrix-vector phase on this workgroup's units [u_lo, u_hi) of a weight matrix [N][K] (a unit is RPU
 // consecutive rows: 1, or 2 for the interleaved (w1_i, w3_i) pairs).  Unit u_lo + cw + s * ENG_CW belongs to
 // compute wave cw (s < MAXS).  eng_issue requests the rows (and the norm gains) into registers, eng_gemv
@@ -381,6 +438,7 @@ struct SlowEngP {
     unsigned* gxb;                // [n_layer][D]
     unsigned* gg;                 // [n_layer][F]
     unsigned* ctl;
+    long rep_delta0, rep_stride;  // words from a source buffer to XCD 0's replica, and between replicas (0, 0: no relay)
     float* x_out;                 // plain f32 [D]: input of the vocabulary head launch and of the fast stack
     int nt;                       // bit 1 (timing experiments only): skip the weight loads
     unsigned long long* stamps;   // diagnostic builds only (tools/mb_engine.hip): [workgroup][layer][16] s_memrealtime ticks, or nullptr
@@ -428,7 +486,12 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     float* outS = mscr + 64 * 6;          // [ENG_MAX_OUT] this workgroup's outputs of the current phase
     int* dead = reinterpret_cast<int*>(outS + ENG_MAX_OUT);
     int* out_count = dead + 1;
+    int* reg_s = dead + 4;                // [3] XCD, rank in it, workgroups in it
     if (tid == 0) { *dead = 0; *out_count = 0; }
+    if (tid == ENG_CW * 64) {             // one thread owns the registration words
+        reg_s[0] = 0; reg_s[1] = 0; reg_s[2] = 1;
+        if (ENG_RELAY && p.rep_stride) eng_register(p.ctl, nb, reg_s, dead);
+    }
     const unsigned epoch = __hip_atomic_load((eng_gu32*)(p.ctl + ENG_CTL_EPOCH), ENG_RLX);
     const unsigned tag = eng_tag16(epoch), tag32 = eng_tag32(epoch);
     const int pos = p.pos[0] + p.pos_off;
@@ -493,6 +556,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             eng_issue(wd, l0.w2, (const bf16_t*)nullptr, F, d_lo, d_hi, cw, lane, p.nt);
             __builtin_amdgcn_sched_barrier(0);
         }
+        eng_barrier();                                              // (registration results in LDS)
         eng_barrier();                                              // B0
         for (int li = 0; li < p.n_layer; ++li) {
             const EngLayer l = eng_layer(p.layers, li);
@@ -590,6 +654,8 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             }
         };
         kv_prefetch(0);
+        eng_barrier();                                              // (registration results in LDS)
+        const EngRelay rl{ENG_RELAY && p.rep_stride != 0, reg_s[1], reg_s[2], p.rep_delta0 + (long)reg_s[0] * p.rep_stride};
         // rotation entries of this position (the same for every layer)
         float rope_c = 1.f, rope_s = 0.f;
         if (lane < hp) { rope_c = p.rope[((size_t)pos * hp + lane) * 2]; rope_s = p.rope[((size_t)pos * hp + lane) * 2 + 1]; }
@@ -597,7 +663,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
         for (int li = 0; li < p.n_layer; ++li) {
             const EngLayer l = eng_layer(p.layers, li);
             if (li > 0) {
-                eng_gather(p.gx + (size_t)li * VSTR, layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 0);
+                eng_gather_x(rl, p.gx + (size_t)li * VSTR, layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 0);
                 eng_barrier(); if (*dead) break;                    // B1
             }
             // ---- attention (attn_decode_kernel's arithmetic; these four waves stand in for its 256 threads)
@@ -825,7 +891,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 const int epb = hd / p.nsplit, ns = p.nsplit;
                 auto ymap = [=](int i) { const int a2 = i / (G * epb), r2 = i % (G * epb), g2 = r2 / epb, eo = r2 % epb;
                                          return ((a2 / ns) * G + g2) * hd + (a2 % ns) * epb + eo; };
-                eng_gather(p.gy + (size_t)li * HD, layLin, 0, HD, tag, yS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 3, ymap);
+                eng_gather_x(rl, p.gy + (size_t)li * HD, layLin, 0, HD, tag, yS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 3, ymap);
             }
             eng_barrier(); if (*dead) break;                        // B2
             // the K/V rows (and norm gains) of this workgroup's next attention turn start their trip now: the polls
@@ -833,7 +899,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             // sit in front of the merge polls and of the y polls)
             if (a >= 0) kv_prefetch(li + 1);
             const unsigned long long t_poll0 = p.stamps ? eng_rt() : 0ull;   // kept in a register: a store here would sit in front of the polls
-            eng_gather(p.gxb + (size_t)li * VSTR, layD, 0, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 4, EngIdent(),
+            eng_gather_x(rl, p.gxb + (size_t)li * VSTR, layD, 0, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 4, EngIdent(),
                        (p.stamps && gw == 0) ? p.stamps + ((size_t)b * p.n_layer + li) * 16 + 13 : nullptr);
             const unsigned long long t_poll1 = p.stamps ? eng_rt() : 0ull;
             eng_barrier(); if (*dead) break;                        // B3
@@ -841,7 +907,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 unsigned long long* q = p.stamps + ((size_t)b * p.n_layer + li) * 16;
                 q[10] = t_poll0; q[11] = t_poll1; q[12] = eng_rt();
             }
-            eng_gather(p.gg + (size_t)li * VSTR, layF, 0, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 5);
+            eng_gather_x(rl, p.gg + (size_t)li * VSTR, layF, 0, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 5);
             eng_barrier(); if (*dead) break;                        // B4
         }
     }
@@ -855,6 +921,8 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
         const unsigned old = atomicAdd(p.ctl + ENG_CTL_EXIT, 1u);
         if (old + 1 == (unsigned)nb) {
             __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_EXIT), 0u, ENG_RLX);
+            __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_ARRIVED), 0u, ENG_RLX);
+            for (int x = 0; x < 8; ++x) __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_XCD + x), 0u, ENG_RLX);
             __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_EPOCH), epoch + ENG_EPOCH_STEP, ENG_RLX);
         }
     }
@@ -888,6 +956,7 @@ struct FastEngP {
     unsigned* glog;               // [2][nb lines]
     unsigned* gcode;              // [ncb][ENG_LINE]
     unsigned* ctl;
+    long rep_delta0, rep_stride;  // as in SlowEngP
     SampP samp;                   // sampling state (cb, noise_off, last are set per step in the kernel)
     long noise_cb_stride;         // fastV
     long noise_off1;              // offset of codebook 1's noise in a row (vocab_size)
@@ -1212,8 +1281,13 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     int* out_count = dead + 1;
     int* sub_count = dead + 2;
     int* codes_s = dead + 4;                   // [MAXCB] codes of this frame as they become known
-    bf16_t* kvS = reinterpret_cast<bf16_t*>(codes_s + MAXCB);    // [n_layer][2][ncb][Hkv * hd] bf16 bits
+    int* reg_s = codes_s + MAXCB;              // [4] XCD, rank in it, workgroups in it
+    bf16_t* kvS = reinterpret_cast<bf16_t*>(reg_s + 4);    // [n_layer][2][ncb][Hkv * hd] bf16 bits
     if (tid == 0) { *dead = 0; *out_count = 0; *sub_count = 0; }
+    if (tid == ENG_CW * 64) {                  // one thread owns the registration words
+        reg_s[0] = 0; reg_s[1] = 0; reg_s[2] = 1;
+        if (ENG_RELAY && p.rep_stride) eng_register(p.ctl, nb, reg_s, dead);
+    }
     const unsigned epoch = __hip_atomic_load((eng_gu32*)(p.ctl + ENG_CTL_EPOCH), ENG_RLX);
     const size_t VSTR = (size_t)nb * ENG_LINE;
     const EngLayout layD{D / nb}, layF{F / nb}, layQ{p.qkvN / nb}, layV{p.V / nb};
@@ -1248,6 +1322,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
             eng_issue<false>(wd, l0.w2, (const bf16_t*)nullptr, F, o_lo, o_hi, cw, lane, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        eng_barrier();                                                  // (registration results in LDS)
         eng_barrier();                                                  // B0
         for (int cb = 0; cb < p.ncb && alive; ++cb) {
             const int par = cb & 1;
@@ -1315,6 +1390,8 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
         // ====================== gathering waves: inputs, attention share, the draws ======================
         EngSub sub{sub_count, 0};
         SampP sp = p.samp;
+        eng_barrier();                                                  // (registration results in LDS)
+        const EngRelay rl{ENG_RELAY && p.rep_stride != 0, reg_s[1], reg_s[2], p.rep_delta0 + (long)reg_s[0] * p.rep_stride};
         eng_barrier();                                                  // B0
         for (int cb = 0; cb < p.ncb && alive; ++cb) {
             const int par = cb & 1;
@@ -1329,7 +1406,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
             for (int li = 0; li < nL; ++li) {
                 const EngLayer l = eng_layer(p.layers, li);
                 if (li > 0) {
-                    eng_gather(bx(par, li), layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 0);
+                    eng_gather_x(rl, bx(par, li), layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 0);
                 } else if (cb <= 1) {
                     const float* src = cb == 0 ? p.hid : p.femb;        // plain f32 left by the launches before this one
                     for (int d = atid * 4; d < D; d += ENG_GW * 64 * 4) *reinterpret_cast<float4*>(xA + d) = *reinterpret_cast<const float4*>(src + d);
@@ -1344,25 +1421,25 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                     }
                 }
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1
-                eng_gather(bq(par, li), layQ, 0, p.qkvN, tag, qkvS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 1);
+                eng_gather_x(rl, bq(par, li), layQ, 0, p.qkvN, tag, qkvS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 1);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b
                 eng_fast_attn<MAXCB, HDIM>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
                                          rcs, rsn, cb, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 eng_barrier();                                          // B2
-                eng_gather(bxb(par, li), layD, 0, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 2);
+                eng_gather_x(rl, bxb(par, li), layD, 0, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 2);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B3
-                eng_gather(bg(par, li), layF, 0, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 3);
+                eng_gather_x(rl, bg(par, li), layF, 0, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 3);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B4
             }
             if (!alive) break;
             if (cb >= 1) {
-                eng_gather(bx(par, nL), layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 56);
+                eng_gather_x(rl, bx(par, nL), layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 56);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B5
                 {
                     // ---- the draw of codebook cb (inference.py:134-149).  EVERY workgroup gathers the logits and draws (the
                     // draw is a deterministic function of logits, frame and seed): no hand-off of the code, the next step's
                     // embedding row can be fetched at once.  Workgroup drawer(cb) alone does the frame bookkeeping (finish_draw).
-                    eng_gather(blog(par), layV, 0, p.V, tag, logS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 57);
+                    eng_gather_x(rl, blog(par), layV, 0, p.V, tag, logS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 57);
                     sub.sync(lane);
                     if (!*dead) {
                         sp.cb = cb;
@@ -1402,6 +1479,8 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
         const unsigned old = atomicAdd(p.ctl + ENG_CTL_EXIT, 1u);
         if (old + 1 == (unsigned)nb) {
             __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_EXIT), 0u, ENG_RLX);
+            __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_ARRIVED), 0u, ENG_RLX);
+            for (int x = 0; x < 8; ++x) __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_XCD + x), 0u, ENG_RLX);
             __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_EPOCH), epoch + ENG_EPOCH_STEP, ENG_RLX);
         }
     }

@@ -60,12 +60,16 @@ int main(int argc, char** argv) {
     p.pos = dpos; p.pos_off = 0; p.n_slots = n_slots; p.nsplit = nsplit; p.cache_off = 0;
     auto zalloc = [&](size_t bytes) { void* q; CK(hipMalloc(&q, bytes)); CK(hipMemset(q, 0, bytes)); return q; };
     // every hand-off buffer out of ONE large allocation (one TLB fragment instead of six small mappings)
-    char* pool = (char*)zalloc((size_t)64 << 20);
+    const int relay = getenv("NO_RELAY") ? 0 : 1;
+    char* pool = (char*)zalloc((size_t)128 << 20);
     size_t off = 0;
     auto carve = [&](size_t bytes) { char* q = pool + off; off += (bytes + 4095) & ~(size_t)4095; return q; };
     const size_t VB = (size_t)nb * ENG_LINE * 4;   // bytes per padded vector buffer
     p.gx = (unsigned*)carve((size_t)(n_layer + 1) * VB); p.gqkv = (unsigned*)carve((size_t)n_layer * VB);
     p.gy = (unsigned*)carve((size_t)n_layer * HD * 4); p.gxb = (unsigned*)carve((size_t)n_layer * VB); p.gg = (unsigned*)carve((size_t)n_layer * VB);
+    const size_t pool_words = off / 4;      // [gx | gqkv | gy | gxb | gg]: replicated per XCD
+    off = pool_words * 4 * 9;
+    p.rep_delta0 = relay ? (long)pool_words : 0; p.rep_stride = relay ? (long)pool_words : 0;
     p.gpart = (unsigned long long*)carve((size_t)n_layer * H * 32 * (hd + 2) * 8);
     p.ctl = (unsigned*)carve(ENG_CTL_WORDS * 4);
     float* xo; CK(hipMalloc(&xo, D * 4)); p.x_out = xo; p.nt = 1;
@@ -166,7 +170,9 @@ static int run_fast(int nb, hipStream_t s) {
     p.hid = hid; p.femb = femb;
     const size_t VW = (size_t)nb * ENG_LINE;
     const size_t words = (2 * ((size_t)(nL + 1) + 3 * nL + 1)) * VW + (size_t)ncb * ENG_LINE;
-    unsigned* g = (unsigned*)zalloc(words * 4);
+    const int relay = getenv("NO_RELAY") ? 0 : 1;
+    unsigned* g = (unsigned*)zalloc(words * 4 * 9);
+    p.rep_delta0 = relay ? (long)words : 0; p.rep_stride = relay ? (long)words : 0;
     p.gx = g; g += 2 * (size_t)(nL + 1) * VW; p.gqkv = g; g += 2 * (size_t)nL * VW; p.gxb = g; g += 2 * (size_t)nL * VW; p.gg = g; g += 2 * (size_t)nL * VW;
     p.glog = g; g += 2 * VW; p.gcode = g;
     p.ctl = (unsigned*)zalloc(ENG_CTL_WORDS * 4);
