@@ -393,12 +393,15 @@ class CodecOracle:
         cb = F.normalize(w[f"{p}.codebook.weight"])
         dist = enc.pow(2).sum(1, keepdim=True) - 2 * enc @ cb.t() + cb.pow(2).sum(1, keepdim=True).t()
         idx = (-dist).max(1)[1].reshape(B, T)
+        top2 = (-dist).topk(2, dim=1).values            # test aid: how close the runner-up row was (per frame)
+        self.taps.setdefault("vq_gap", []).append((top2[:, 0] - top2[:, 1]).reshape(B, T))
         zq = F.conv1d(F.embedding(idx, w[f"{p}.codebook.weight"]).transpose(1, 2), w[f"{p}.out_proj.weight"], w[f"{p}.out_proj.bias"])
         return zq, idx
 
     def quantizer_encode(self, z):
         """vocoder.py:765-783: downsample, pre_module, semantic VQ, residual VQ over the rest -> (B, 1+n, T') indices."""
         c, w = self.c, self.w
+        self.taps["vq_gap"] = []                         # one (B, T) tensor of top-1/top-2 score gaps per codebook, in order
         for j, f in enumerate(c.upsample):
             p = f"quantizer.downsample.{j}"
             z = causal_conv_strided(z, w[f"{p}.0.conv.weight"], w[f"{p}.0.conv.bias"], f)

@@ -571,3 +571,161 @@ def test_state_dict_with_extra_keys_loads_like_strict_false():
     with pytest.raises(HipError):
         eng.load_state_dict(missing)
     eng.close()
+
+
+@pytest.mark.parametrize("tag,precision", [("f32", "fp32"), ("bf16", "bf16")])
+def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
+    """The real shapes (28+4 layers, V = 155 776): 17 frames the REFERENCE generated (fp32 and bf16, repetition penalty
+    1.0, tests/golden/make_golden_s1mini_tf.py).  For every k the engine prefills prompt + golden[:k] and yields frame k;
+    each of its eleven decisions is judged against the margin the oracle recorded for that very decision, so a legitimate
+    flip early on hides nothing behind it (the next k starts from the golden tokens again).  The slow logits of every
+    frame are compared with the reference's top-8 values.  fp32: every index equal (margin bound 1e-4 of the logit
+    range: the reference's own exact ties only); bf16: the evaluation-order tolerance 0.03 x range, as elsewhere."""
+    from fish_tts_amd.ar_engine import ARHipEngine
+    from tests.shapes import s1mini_shape
+    g = np.load(os.path.join(G, "ar_s1mini_tf.npz"))
+    shape = s1mini_shape()
+    dtype = torch.float32 if precision == "fp32" else torch.bfloat16
+    w = O.random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]), dtype=dtype)
+    eng = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,
+                      precision=precision, device=0, max_batch=1, max_new_tokens=8)
+    eng.load_state_dict(w)
+    del w
+    prompt, seq = g["prompt"], g[f"{tag}.seq"]
+    margins, top_idx, top_val = g[f"{tag}.margins"], g[f"{tag}.slow_top8"], g[f"{tag}.slow_top8_logits"]
+    T, n_new = prompt.shape[1], int(g["n_new"])
+    absmax = max(1.0, float(g[f"{tag}.logit_absmax"]))
+    tol = (1e-4 if precision == "fp32" else 0.03) * absmax
+    ltol = (2e-3 if precision == "fp32" else 0.05) * absmax
+    sp = eng._sampling(0.7, 1e-6, 1.0)
+    flips, judged = [], 0
+    for k in range(n_new):
+        first = eng.prefill(np.ascontiguousarray(seq[:, : T + k]), sp)
+        logits, _ = eng.debug_state()
+        assert np.max(np.abs(logits[top_idx[k]] - top_val[k])) <= ltol, (k, logits[top_idx[k]], top_val[k])
+        want = seq[:, T + k]
+        for row in range(seq.shape[0]):
+            if first[row] != want[row]:
+                cb = 0 if row <= 1 else row - 1
+                assert float(margins[k, cb]) <= tol, f"frame {k} row {row}: {first[row]} != {want[row]}, margin {margins[k, cb]}"
+                flips.append((k, row, round(float(margins[k, cb]), 4)))
+                break                     # the later codebooks of this frame were drawn after a different code
+            judged += 1
+    print(f"{tag}: {judged} decisions equal, legitimate flips (frame, row, reference margin) at {flips}")
+    # (random weights at this width give many near-ties in bf16: 2-7 of a frame's 10 decisions have a margin inside the
+    # tolerance; a flip ends the judging of its frame only, the next frame is forced back onto the golden tokens)
+    assert judged >= 0.6 * n_new * seq.shape[0]
+    if precision == "fp32":
+        assert len(flips) <= 1
+    eng.close()
+
+
+def test_batch32_wide_path_at_full_depth_vs_oracle_and_single_runs():
+    """BASELINE configs[2]'s product path at the real depth: 32 mixed-length utterances decoded in lock step on the MFMA
+    skinny GEMMs (no FT_NO_WIDE), 28+4 layers.  That path sums in another order than the single-utterance one, and random
+    weights at this width leave 2-7 of a frame's 10 bf16 decisions inside the evaluation-order tolerance, so rows do part
+    from their single runs; what is asserted: (1) three of the rows (first, middle, last slot) follow the ORACLE up to a
+    decision - semantic or codebook - whose top-1/top-2 margin in the oracle is inside that tolerance; (2) every row that
+    leaves its single run at a SEMANTIC decision does so inside the margin read back from the single run's own logits."""
+    from fish_tts_amd.ar_engine import ARHipEngine
+    from tests.shapes import s1mini_shape
+    shape = s1mini_shape(max_seq_len=1024)
+    w = O.random_weights(shape, seed=0, std=0.05, dtype=torch.bfloat16)
+    B, n_dec = 32, 3
+    eng = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,
+                      precision="bf16", device=0, max_batch=B, max_new_tokens=16)
+    eng.load_state_dict(w)
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    sp = eng._sampling(0.7, 1e-6, 1.1)
+    prompts = [make_prompt(shape, 8 + (5 * i) % 33, seed=500 + i, n_vq=i % 3) for i in range(B)]
+    singles = [eng.generate(p.numpy(), n_dec + 1, **kw) for p in prompts]
+    assert eng.engine_state()[0] == 3
+    firsts = [eng.prefill(p.numpy(), sp, slot=i) for i, p in enumerate(prompts)]
+    frames, n = eng.decode(n_dec, [sp] * B, poll=n_dec)
+    got = [np.concatenate([p.numpy(), firsts[i][:, None], frames[i, : n[i]].T], axis=1) for i, p in enumerate(prompts)]
+    same, sem_flips, cb_flips = 0, 0, 0
+    for i, p in enumerate(prompts):
+        div = first_divergence(got[i], singles[i])
+        if div is None:
+            same += 1
+            continue
+        col, row = div
+        if row <= 1:
+            f = col - p.shape[1]                      # generated frame index of the decision
+            eng.generate(p.numpy(), f + 1, **kw)      # single run stopped right after that decision
+            logits, _ = eng.debug_state()
+            fin = logits[np.isfinite(logits)]
+            top = np.sort(fin)[-2:]
+            assert top[1] - top[0] <= 0.03 * max(1.0, float(np.max(np.abs(fin)))), (i, div, top)
+            sem_flips += 1
+        else:
+            cb_flips += 1
+    print(f"B=32 wide path, {n_dec + 1} frames: {same} rows identical to their single run, {sem_flips} left it at a semantic decision inside the "
+          f"margin, {cb_flips} at a codebook decision")
+    eng.close()
+    orc = O.AROracle(shape, w, torch.bfloat16)
+    for i in (0, 13, 31):
+        taps = []
+        orc.reset()
+        want = orc.generate(prompts[i].clone(), n_dec + 1, frame_taps=taps, **kw).numpy()
+        scale = max(1.0, float(taps[0][0].float().abs().max()))
+        div = first_divergence(got[i], want)
+        if div is not None:
+            col, row = div
+            assert _margin_ok(taps, col - prompts[i].shape[1], row, 0.03 * scale), f"row {i} left the oracle at {div}\n{got[i]}\n{want}"
+
+
+def test_config4_voice_cloning_composite():
+    """BASELINE configs[4] as one flow (s1-mini widths, 2+2 layers so the oracle can follow): 8 utterances share a long
+    reference prefix (661 VQ frames + text, 728 positions) whose K/V is built once and restored into every slot, each adds
+    49 text tokens (Lp = 777), all decode in lock step with refill while their frames stream out in 10- then 20-frame
+    chunks (synthesizer.py:552-559).  Checked: the chunking rule and frame counts for all 8, and for 3 of them the
+    frames against the oracle's full-prompt run (margin-tolerant, as in test_wide_batch_vs_oracle)."""
+    import dataclasses
+    from fish_tts_amd.batch import Utterance, run_batch
+    shape = dataclasses.replace(medium_shape(), max_seq_len=2048)
+    B, n_frames = 8, 34
+    eng, orc = make_pair(shape, "bf16", std=0.05, max_batch=B, max_new_tokens=64)
+    rng = np.random.default_rng(3)
+    n_text = shape.semantic_begin_id - 15
+    ref = np.concatenate([rng.integers(0, 4096, (1, 661)), rng.integers(0, 1024, (9, 661))]).astype(np.int32)
+    head = np.zeros((11, 2 + 64 + 661 + 1), dtype=np.int32)
+    head[0, : 2 + 64] = rng.integers(0, n_text, 66)
+    head[0, 66: 66 + 661] = ref[0] + shape.semantic_begin_id
+    head[1:, 66: 66 + 661] = ref
+    head[0, -1] = shape.im_end_id
+    pf = eng.build_prefix(head)
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    utts = []
+    for i in range(B):
+        text = np.zeros((11, 49), dtype=np.int32)
+        text[0] = rng.integers(0, n_text, 49)
+        utts.append(Utterance(np.concatenate([head, text], axis=1), n_frames, seed=i, prefix=pf, **kw))
+    assert utts[0].prompt.shape[1] == 777
+    chunks = {i: [] for i in range(B)}
+    pending = {i: [] for i in range(B)}
+
+    def on_frames(i, blk):                 # the stream rule: first chunk at >= 10 frames, later ones at >= 20
+        pending[i].append(blk)
+        have = sum(b.shape[1] for b in pending[i])
+        if have >= (10 if not chunks[i] else 20):
+            chunks[i].append(np.concatenate(pending[i], axis=1))
+            pending[i] = []
+    run_batch(eng, utts, burst=5, on_frames=on_frames)
+    pf.free()
+    for i, u in enumerate(utts):
+        cols = u.columns()
+        assert cols.shape[1] == n_frames, (i, cols.shape)
+        streamed = chunks[i] + ([np.concatenate(pending[i], axis=1)] if pending[i] else [])
+        assert np.array_equal(np.concatenate(streamed, axis=1), cols)
+        assert chunks[i][0].shape[1] >= 10 and all(c.shape[1] >= 20 for c in chunks[i][1:])
+    for i in (0, 3, 7):
+        taps = []
+        orc.reset()
+        want = orc.generate(torch.from_numpy(utts[i].prompt), 8, frame_taps=taps, **kw).numpy()
+        got = np.concatenate([utts[i].prompt, utts[i].columns()[:, :8]], axis=1)
+        scale = max(1.0, float(taps[0][0].float().abs().max()))
+        div = first_divergence(got, want)
+        if div is not None:
+            assert _margin_ok(taps, div[0] - 777, div[1], 0.03 * scale), (i, div)
+    eng.close()
