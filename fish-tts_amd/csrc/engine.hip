@@ -494,8 +494,11 @@ static ft_status eng_setup(ft_ctx* ctx) {
     // [2 parities]: gx (nLf + 1), gqkv, gxb, gg (nLf each), glog (1); then one line per codebook for the drawn codes
     ctx->eng_fast_words = (2 * ((nLf + 1) + 3 * nLf + 1)) * (VB / 4) + (size_t)c.num_codebooks * ENG_LINE;
     FT_TRY(zalloc((void**)&ctx->eng_fast_g, ctx->eng_fast_words * 4 * (ctx->eng_relay ? 9 : 1)));
-    size_t ff = (size_t)c.fast_dim * 2 + fqkvN + HDf + c.fast_intermediate_size + ctx->fastV + ENG_MAX_OUT + 8 + 32 + 32 + 12 + 2048 + 4 + 4 + 16;
-    ctx->eng_lds_fast = ff * sizeof(float) + (size_t)nLf * 2 * c.num_codebooks * c.fast_n_local_heads * c.fast_head_dim * 2 + 64;
+    const int kvw = c.fast_n_local_heads * c.fast_head_dim;
+    // codebook positions 0 and 1 as two rows of one pass when the second row's buffers fit the CU's LDS
+    ctx->eng_pair = getenv("FT_NO_PAIR") == nullptr &&
+                    eng_fast_lds_bytes(c.fast_dim, fqkvN, HDf, c.fast_intermediate_size, ctx->fastV, (int)nLf, c.num_codebooks, kvw, true) <= 160 * 1024;
+    ctx->eng_lds_fast = eng_fast_lds_bytes(c.fast_dim, fqkvN, HDf, c.fast_intermediate_size, ctx->fastV, (int)nLf, c.num_codebooks, kvw, ctx->eng_pair);
     if (ctx->eng_lds_fast > 160 * 1024) return FT_OK;
     ctx->eng_lds_fast = std::max(ctx->eng_lds_fast, (size_t)82 * 1024);
     FT_HIP(ctx, hipFuncSetAttribute((const void*)fast_engine_kernel<2, 2, 6, 10, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -587,6 +590,7 @@ static void enqueue_fast_engine(Launch& L) {
     s.tok = ctx->d_tok + (size_t)m0 * R; s.pos = ctx->d_pos + m0; s.done = ctx->d_done + m0;
     p.samp = s;
     p.noise_cb_stride = ctx->fastV; p.noise_off1 = c.vocab_size;
+    p.pair = ctx->eng_pair ? 1 : 0;
     fast_engine_kernel<2, 2, 6, 10, 64><<<nb, ENG_THREADS, ctx->eng_lds_fast, L.s>>>(p);
     L.chk();
 }

@@ -275,6 +275,58 @@ __device__ __forceinline__ void eng_gather_x(const EngRelay& rl, const unsigned*
     eng_gather(rep, lay, u0, n, tag, dst, gw, ngw, lane, ctl, dead, where, dmap, dbg);
 }
 
+// Two vectors of the same length n (n % 256 == 0) gathered as ONE list of 2 * npiece pieces (the two rows of the fast
+// loop's first pass): piece P < npiece belongs to vector 0, the others to vector 1.
+struct EngSrc2 { const unsigned* g[2]; float* dst[2]; unsigned tag[2]; };
+__device__ __forceinline__ void eng_gather2(const EngSrc2& S, long delta, int n, int gw, int ngw, int lane, unsigned* ctl, int* dead,
+                                            int where) {
+    const int npiece = n >> 8, NP = 2 * npiece;
+    EngSpin sp{ctl, dead, 0, 0, where};
+    for (int p0 = gw; p0 < NP; p0 += 3 * ngw) {
+        const int c0 = p0;
+        const int c1 = p0 + ngw < NP ? p0 + ngw : c0;
+        const int c2 = p0 + 2 * ngw < NP ? p0 + 2 * ngw : c0;
+        const int s0 = c0 >= npiece, s1 = c1 >= npiece, s2 = c2 >= npiece;
+        const int i0 = (c0 - s0 * npiece) * 256 + lane * 4, i1 = (c1 - s1 * npiece) * 256 + lane * 4, i2 = (c2 - s2 * npiece) * 256 + lane * 4;
+        const unsigned* a0 = S.g[s0] + delta + i0;
+        const unsigned* a1 = S.g[s1] + delta + i1;
+        const unsigned* a2 = S.g[s2] + delta + i2;
+        const unsigned t0 = S.tag[s0], t1 = S.tag[s1], t2 = S.tag[s2];
+        U4 a, b, c;
+        for (;;) {
+            if (c1 == c0) { eng_ld1_sc1(a0, a); b = a; c = a; }
+            else eng_ld3_sc1(a0, a1, a2, a, b, c);
+            const bool oa = eng_tags_ok(a, t0), ob = c1 == c0 || eng_tags_ok(b, t1), oc = c2 == c0 || eng_tags_ok(c, t2);
+            if (__all(oa && ob && oc)) break;
+            if (sp.give_up(lane)) return;
+        }
+        eng_unpack_to_lds(S.dst[s0] + i0, a);
+        if (c1 != c0) eng_unpack_to_lds(S.dst[s1] + i1, b);
+        if (c2 != c0) eng_unpack_to_lds(S.dst[s2] + i2, c);
+    }
+}
+__device__ __forceinline__ void eng_gather_x2(const EngRelay& rl, const EngSrc2& S, int n, int gw, int ngw, int lane, unsigned* ctl,
+                                              int* dead, int where) {
+    if (!rl.on) { eng_gather2(S, 0, n, gw, ngw, lane, ctl, dead, where); return; }
+    const int npiece = n >> 8, NP = 2 * npiece;
+    for (int p = rl.rank; p < NP; p += rl.nr) {
+        if (p % ngw != gw) continue;
+        const int s = p >= npiece;
+        const int i = (p - s * npiece) * 256 + lane * 4;
+        const unsigned* src = S.g[s] + i;
+        const unsigned tg = S.tag[s];
+        EngSpin sp{ctl, dead, 0, 0, where};
+        U4 a;
+        for (;;) {
+            eng_ld1_sc1(src, a);
+            if (__all(eng_tags_ok(a, tg))) break;
+            if (sp.give_up(lane)) return;
+        }
+        *reinterpret_cast<U4*>(const_cast<unsigned*>(src) + rl.delta) = a;
+    }
+    eng_gather2(S, rl.delta, n, gw, ngw, lane, ctl, dead, where);
+}
+
 // ------------------------------------------------------------------------------------------
 // One matrix-vector phase on this workgroup's units [u_lo, u_hi) of a weight matrix [N][K] (a unit is RPU
 // consecutive rows: 1, or 2 for the interleaved (w1_i, w3_i) pairs).  Unit u_lo + cw + s * ENG_CW belongs to
@@ -326,10 +378,10 @@ typedef __attribute__((address_space(3))) int* eng_lds_int;
 // gout: this workgroup's line of the output vector's hand-off buffer, plain: optional plain f32 copy of the whole
 // vector (last phase of a launch).
 // Called by EVERY compute wave (also one without rows in this matrix).
+// the arithmetic of one input row: this wave's outputs go to vals[u - u_lo] (LDS)
 template <int NT, int RPU, int MAXS, int PRO, int EPI>
-__device__ __forceinline__ void eng_gemv(const EngW<NT, RPU, MAXS>& r, const float* xs, int K, float eps, const bf16_t* bias,
-                                         const float* resid, unsigned* gout, unsigned tag, float* plain, int u_lo, int u_hi,
-                                         int cw, int lane, EngOut& eo) {
+__device__ __forceinline__ void eng_gemv_rows(const EngW<NT, RPU, MAXS>& r, const float* xs, int K, float eps, const bf16_t* bias,
+                                              const float* resid, float* vals, int u_lo, int u_hi, int cw, int lane) {
     static_assert(EPI == EPI_SWIGLU ? RPU == 2 : RPU == 1, "a unit is a (w1, w3) pair for SwiGLU, one row otherwise");
     if (u_lo + cw < u_hi) {
         float xv[NT][8];
@@ -386,9 +438,16 @@ __device__ __forceinline__ void eng_gemv(const EngW<NT, RPU, MAXS>& r, const flo
                 if (EPI == EPI_RESID) v = round_bf16(resid[u] + v);
                 o = v;
             }
-            if (lane == 0) eo.vals[u - u_lo] = o;
+            if (lane == 0) vals[u - u_lo] = o;
         }
     }
+}
+
+template <int NT, int RPU, int MAXS, int PRO, int EPI>
+__device__ __forceinline__ void eng_gemv(const EngW<NT, RPU, MAXS>& r, const float* xs, int K, float eps, const bf16_t* bias,
+                                         const float* resid, unsigned* gout, unsigned tag, float* plain, int u_lo, int u_hi,
+                                         int cw, int lane, EngOut& eo) {
+    eng_gemv_rows<NT, RPU, MAXS, PRO, EPI>(r, xs, K, eps, bias, resid, eo.vals, u_lo, u_hi, cw, lane);
     // count in; the last wave of the workgroup to arrive publishes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     int old = 0;
@@ -406,6 +465,113 @@ __device__ __forceinline__ void eng_gemv(const EngW<NT, RPU, MAXS>& r, const flo
 #if ENG_DRAIN
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+    }
+}
+
+// eng_gemv_rows for two input rows at once (each weight register unpacked once; per row the operations of eng_gemv_rows)
+template <int NT, int RPU, int MAXS, int PRO, int EPI>
+__device__ __forceinline__ void eng_gemv_rows2(const EngW<NT, RPU, MAXS>& r, const float* xs0, const float* xs1, int K, float eps,
+                                               const bf16_t* bias, const float* resid0, const float* resid1, float* vals0, float* vals1,
+                                               int u_lo, int u_hi, int cw, int lane) {
+    static_assert(EPI == EPI_SWIGLU ? RPU == 2 : RPU == 1, "a unit is a (w1, w3) pair for SwiGLU, one row otherwise");
+    if (u_lo + cw < u_hi) {
+        float xv[2][NT][8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float* xs = q ? xs1 : xs0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float4 f0 = *reinterpret_cast<const float4*>(xs + t * 512 + lane * 8);
+                const float4 f1 = *reinterpret_cast<const float4*>(xs + t * 512 + lane * 8 + 4);
+                xv[q][t][0] = f0.x; xv[q][t][1] = f0.y; xv[q][t][2] = f0.z; xv[q][t][3] = f0.w;
+                xv[q][t][4] = f1.x; xv[q][t][5] = f1.y; xv[q][t][6] = f1.z; xv[q][t][7] = f1.w;
+            }
+        }
+        if (PRO == PRO_RMSNORM) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float ss = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss = fmaf(xv[q][t][j], xv[q][t][j], ss);
+                ss = wave_sum(ss);
+                const float inv = rsqrt_exact(ss / (float)K + eps);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float gv[8];
+                    Vec<bf16_t>::unpack(r.gain[t], gv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[q][t][j] = round_bf16(round_bf16(xv[q][t][j] * inv) * gv[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const int u = u_lo + cw + s * ENG_CW;
+            if (u >= u_hi) break;
+            float acc[2][RPU];
+#pragma unroll
+            for (int rr = 0; rr < RPU; ++rr) {
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float wv[8];
+                    Vec<bf16_t>::unpack(r.w[s][rr][t], wv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { a0 = fmaf(wv[j], xv[0][t][j], a0); a1 = fmaf(wv[j], xv[1][t][j], a1); }
+                }
+                acc[0][rr] = wave_sum(a0);
+                acc[1][rr] = wave_sum(a1);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float o;
+                if (EPI == EPI_SWIGLU) {
+                    const float a = round_bf16(acc[q][0]);
+                    const float bb = round_bf16(acc[q][RPU - 1]);
+                    const float sg = round_bf16(a / (1.0f + expf(-a)));
+                    o = round_bf16(sg * bb);
+                } else {
+                    float v = acc[q][0];
+                    if (bias) v += eng_ldg_bf16(bias, u);
+                    v = round_bf16(v);
+                    if (EPI == EPI_RESID) v = round_bf16((q ? resid1 : resid0)[u] + v);
+                    o = v;
+                }
+                if (lane == 0) (q ? vals1 : vals0)[u - u_lo] = o;
+            }
+        }
+    }
+}
+
+// Two input rows against the same rows of the matrix (the fast loop's first pass: codebook positions 0 and 1 are both
+// known when the launch starts).  Row r's outputs go to gout[r] with tag[r]; still ONE store instruction per workgroup
+// (lanes 0.. carry row 0, lanes 32.. row 1; a workgroup owns at most 32 units of a vector).
+template <int NT, int RPU, int MAXS, int PRO, int EPI>
+__device__ __forceinline__ void eng_gemv2(const EngW<NT, RPU, MAXS>& r, const float* xs0, const float* xs1, int K, float eps,
+                                          const bf16_t* bias, const float* resid0, const float* resid1, unsigned* gout0, unsigned* gout1,
+                                          unsigned tag0, unsigned tag1, int u_lo, int u_hi, int cw, int lane, EngOut& eo) {
+    if (NT <= 2) {
+        eng_gemv_rows2<NT, RPU, MAXS, PRO, EPI>(r, xs0, xs1, K, eps, bias, resid0, resid1, eo.vals, eo.vals + 32, u_lo, u_hi, cw, lane);
+    } else {
+        eng_gemv_rows<NT, RPU, MAXS, PRO, EPI>(r, xs0, K, eps, bias, resid0, eo.vals, u_lo, u_hi, cw, lane);
+        __builtin_amdgcn_sched_barrier(0);       // one row's inputs in registers at a time
+        eng_gemv_rows<NT, RPU, MAXS, PRO, EPI>(r, xs1, K, eps, bias, resid1, eo.vals + 32, u_lo, u_hi, cw, lane);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add((eng_lds_int)eo.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    eo.seq += 1;
+    if (old + 1 == eo.seq * ENG_CW) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        const int n = u_hi - u_lo;
+        const int i = lane & 31;
+        if (i < n) {
+            const float o = eo.vals[lane];
+            eng_put(lane < 32 ? gout0 : gout1, i, o, lane < 32 ? tag0 : tag1);
+        }
     }
 }
 
@@ -960,6 +1126,7 @@ struct FastEngP {
     SampP samp;                   // sampling state (cb, noise_off, last are set per step in the kernel)
     long noise_cb_stride;         // fastV
     long noise_off1;              // offset of codebook 1's noise in a row (vocab_size)
+    int pair;                     // 1: codebook positions 0 and 1 (both inputs known at launch) run as two rows of ONE pass
     unsigned long long* stamps;   // diagnostic builds only (tools/mb_engine.hip): [workgroup][step][layer][16] ticks, or nullptr
 };
 #define ENG_FSTAMP(k) do { if (p.stamps && tid == 0) p.stamps[(((size_t)b * p.ncb + cb) * nL + li) * 16 + (k)] = eng_rt(); } while (0)
@@ -1000,6 +1167,29 @@ __device__ __forceinline__ void eng_fast_attn(const float* qkvS, bf16_t* kS, bf1
         float q[EPL], kx[EPL], vx[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) { q[e] = qp[64 * e]; kx[e] = kp[64 * e]; vx[e] = vp[64 * e]; }
+        if (c == 0) {
+            // one visible position: the softmax weight is round_bf16(exp(0) / exp(0)) = 1 and the output fma(1, v, 0) = v
+            // whatever q is, so only the K/V rows of the history are produced (same operations on k as below)
+            if (h % G == 0) {
+                if (kn) {
+                    float ss = kx[0] * kx[0];
+                    if (EPL > 1) ss = kx[0] * kx[0] + kx[EPL - 1] * kx[EPL - 1];
+                    ss = wave_sum(ss);
+                    const float inv = rsqrt_exact(ss / (float)HD + eps);
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) kx[e] = round_bf16((kx[e] * inv) * eng_ldg_bf16(kn, lane + 64 * e));
+                }
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const float ko = dpp_f<DPP_XOR1>(kx[e]);
+                    kx[e] = round_bf16((lane & 1) == 0 ? kx[e] * cs[e] - ko * sn[e] : kx[e] * cs[e] + ko * sn[e]);
+                    kh[64 * e] = f32_to_bf16_bits(kx[e]); vh[64 * e] = f32_to_bf16_bits(vx[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) yS[h * HD + lane + 64 * e] = round_bf16(vx[e]);
+            continue;
+        }
         if (qn) {
             float ss = q[0] * q[0];
             if (EPL > 1) ss = q[0] * q[0] + q[EPL - 1] * q[EPL - 1];
@@ -1253,6 +1443,14 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const float* L, 
     return winner;
 }
 
+// dynamic LDS of fast_engine_kernel (host and harness use this one formula)
+inline size_t eng_fast_lds_bytes(int D, int qkvN, int HD, int F, int V, int nL, int ncb, int KVW, bool pair) {
+    size_t fl = (size_t)D * 2 + qkvN + HD + F + V + ENG_MAX_OUT + 8 + 32 + 32 + 12 + 2048 + 4 + 4 + 16;
+    size_t by = fl * sizeof(float) + (size_t)nL * 2 * ncb * KVW * 2 + 64;
+    if (pair) by += ((size_t)2 * D + (size_t)(F > qkvN + HD ? F : qkvN + HD)) * sizeof(float) + 16;
+    return by;
+}
+
 template <int NTD, int NTA, int NTF, int MAXCB, int HDIM>
 __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     constexpr int SQ = ENG_FQ, SF = ENG_FF, SO = ENG_FO;
@@ -1283,6 +1481,12 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     int* codes_s = dead + 4;                   // [MAXCB] codes of this frame as they become known
     int* reg_s = codes_s + MAXCB;              // [4] XCD, rank in it, workgroups in it
     bf16_t* kvS = reinterpret_cast<bf16_t*>(reg_s + 4);    // [n_layer][2][ncb][Hkv * hd] bf16 bits
+    // second row of the paired first pass: x, x' and ONE region that holds (q k v | y) until Wo has run and g afterwards
+    float* xA1 = smem + ((((size_t)(reinterpret_cast<float*>(kvS + (size_t)p.n_layer * 2 * p.ncb * KVW) - smem)) + 3) & ~(size_t)3);   // 16-byte aligned
+    float* xB1 = xA1 + D;
+    float* gS1 = xB1 + D;
+    float* qkvS1 = gS1;
+    float* yS1 = gS1 + p.qkvN;
     if (tid == 0) { *dead = 0; *out_count = 0; *sub_count = 0; }
     if (tid == ENG_CW * 64) {                  // one thread owns the registration words
         reg_s[0] = 0; reg_s[1] = 0; reg_s[2] = 1;
@@ -1300,6 +1504,8 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     auto blog = [&](int par) { return p.glog + (size_t)par * VSTR; };
     auto drawer = [&](int cb) { return (cb * 37) % nb; };   // the workgroup that draws codebook cb
     bool alive = true;
+    const bool pair = p.pair != 0 && p.ncb >= 2;
+    static_assert(ENG_PAD == 0, "the paired first pass assumes linear hand-off vectors");
 
     if (wave < ENG_CW) {
         // =============================== compute waves ===============================
@@ -1324,7 +1530,99 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
         }
         eng_barrier();                                                  // (registration results in LDS)
         eng_barrier();                                                  // B0
-        for (int cb = 0; cb < p.ncb && alive; ++cb) {
+        if (pair) {
+            // ---- codebook positions 0 and 1 as two rows of one pass: row 0 = (parity 0, tag of step 0), row 1 = (parity 1,
+            // tag of step 1); per row the arithmetic of the single-row pass.  Row 0 only feeds the K/V history, so its
+            // Wo / W13 / W2 phases of the last layer (and its logits, inference.py:122) are not computed.
+            const unsigned tag0 = eng_tag16(epoch), tag1 = eng_tag16(epoch + 1u);
+            float r0c[2], r0s[2], r1c[2], r1s[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int d = lane + 64 * e;
+                r0c[e] = d < hd ? p.rope[((size_t)(d >> 1)) * 2] : 1.f;
+                r0s[e] = d < hd ? p.rope[((size_t)(d >> 1)) * 2 + 1] : 0.f;
+                r1c[e] = d < hd ? p.rope[((size_t)(hd >> 1) + (d >> 1)) * 2] : 1.f;
+                r1s[e] = d < hd ? p.rope[((size_t)(hd >> 1) + (d >> 1)) * 2 + 1] : 0.f;
+            }
+            for (int li = 0; li < nL; ++li) {
+                const int cb = 1;        // (for the stamp macro)
+                // buffer bases re-read per layer: keeps the compiler from hoisting ~20 per-lane publish addresses out of the
+                // loop (they would not fit beside the weight registers and spill)
+                unsigned *gxL = p.gx, *gqL = p.gqkv, *gxbL = p.gxb, *ggL = p.gg;
+                asm volatile("" : "+s"(gxL), "+s"(gqL), "+s"(gxbL), "+s"(ggL));
+                auto bx = [&](int par, int l_) { return gxL + ((size_t)par * (nL + 1) + l_) * VSTR; };
+                auto bq = [&](int par, int l_) { return gqL + ((size_t)par * nL + l_) * VSTR; };
+                auto bxb = [&](int par, int l_) { return gxbL + ((size_t)par * nL + l_) * VSTR; };
+                auto bg = [&](int par, int l_) { return ggL + ((size_t)par * nL + l_) * VSTR; };
+                const EngLayer l = eng_layer(p.layers, li);
+                const bool more = !(p.ncb == 2 && li == nL - 1);
+                const bool tail0 = li + 1 < nL;                         // row 0 goes on after the attention
+                const EngLayer ln = eng_layer(p.layers, li + 1 < nL ? li + 1 : 0);
+                bf16_t* kL = kvS + (size_t)(li * 2) * p.ncb * KVW;
+                bf16_t* vL = kvS + (size_t)(li * 2 + 1) * p.ncb * KVW;
+                eng_barrier(); if (*dead) { alive = false; break; }     // B1: xA, xA1
+                ENG_FSTAMP(0);
+                eng_gemv2<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, xA1, D, p.eps, l.bqkv, nullptr, nullptr, bq(0, li) + eng_pub(b, q_lo),
+                                                              bq(1, li) + eng_pub(b, q_lo), tag0, tag1, q_lo, q_hi, cw, lane, eo);
+                __builtin_amdgcn_sched_barrier(0);
+                ENG_FSTAMP(1);
+                if (more) eng_issue<false>(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B1b: qkvS, qkvS1
+                ENG_FSTAMP(2);
+                eng_fast_attn<MAXCB, HDIM>(qkvS, kL, vL, yS, l.qn, l.kn, r0c, r0s, 0, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_barrier();                                          // position 0's K/V rows in LDS
+                eng_fast_attn<MAXCB, HDIM>(qkvS1, kL, vL, yS1, l.qn, l.kn, r1c, r1s, 1, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                ENG_FSTAMP(9);
+                eng_barrier();                                          // B2: yS, yS1
+                ENG_FSTAMP(3);
+                if (tail0)
+                    eng_gemv2<NTA, 1, SO, PRO_NONE, EPI_RESID>(wo, yS, yS1, HD, p.eps, l.bo, xA, xA1, bxb(0, li) + eng_pub(b, o_lo),
+                                                               bxb(1, li) + eng_pub(b, o_lo), tag0, tag1, o_lo, o_hi, cw, lane, eo);
+                else
+                    eng_gemv<NTA, 1, SO, PRO_NONE, EPI_RESID>(wo, yS1, HD, p.eps, l.bo, xA1, bxb(1, li) + eng_pub(b, o_lo), tag1, nullptr,
+                                                              o_lo, o_hi, cw, lane, eo);
+                __builtin_amdgcn_sched_barrier(0);
+                ENG_FSTAMP(4);
+                if (more) eng_issue<false>(wo, ln.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B3: xB, xB1
+                ENG_FSTAMP(5);
+                if (tail0)
+                    eng_gemv2<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, xB1, D, p.eps, nullptr, nullptr, nullptr, bg(0, li) + eng_pub(b, f_lo),
+                                                                   bg(1, li) + eng_pub(b, f_lo), tag0, tag1, f_lo, f_hi, cw, lane, eo);
+                else
+                    eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB1, D, p.eps, nullptr, nullptr, bg(1, li) + eng_pub(b, f_lo), tag1, nullptr,
+                                                                  f_lo, f_hi, cw, lane, eo);
+                __builtin_amdgcn_sched_barrier(0);
+                ENG_FSTAMP(6);
+                if (more) eng_issue<false>(wf, ln.w13, ln.ffn_norm, D, f_lo, f_hi, cw, lane, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B4: gS, gS1
+                ENG_FSTAMP(7);
+                if (tail0)
+                    eng_gemv2<NTF, 1, SO, PRO_NONE, EPI_RESID>(wd, gS, gS1, F, p.eps, nullptr, xB, xB1, bx(0, li + 1) + eng_pub(b, o_lo),
+                                                               bx(1, li + 1) + eng_pub(b, o_lo), tag0, tag1, o_lo, o_hi, cw, lane, eo);
+                else
+                    eng_gemv<NTF, 1, SO, PRO_NONE, EPI_RESID>(wd, gS1, F, p.eps, nullptr, xB1, bx(1, li + 1) + eng_pub(b, o_lo), tag1, nullptr,
+                                                              o_lo, o_hi, cw, lane, eo);
+                __builtin_amdgcn_sched_barrier(0);
+                ENG_FSTAMP(8);
+                if (more) eng_issue<false>(wd, ln.w2, (const bf16_t*)nullptr, F, o_lo, o_hi, cw, lane, 0);
+                if (li == nL - 1) eng_issue<false>(wh, p.fast_out, p.fast_norm, D, h_lo, h_hi, cw, lane, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (alive) {
+                eng_barrier();                                          // B5: xA = stack output of position 1
+                if (*dead) alive = false;
+                else {
+                    eng_gemv<NTD, 1, SO, PRO_RMSNORM, EPI_STORE>(wh, xA, D, p.eps, nullptr, nullptr, blog(1) + eng_pub(b, h_lo), tag1, nullptr,
+                                                                 h_lo, h_hi, cw, lane, eo);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        for (int cb = pair ? 2 : 0; cb < p.ncb && alive; ++cb) {
             const int par = cb & 1;
             const unsigned tag = eng_tag16(epoch + (unsigned)cb);
             float rcs[2], rsn[2];      // rotation entries of this codebook position (dimensions lane, lane + 64)
@@ -1393,7 +1691,47 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
         eng_barrier();                                                  // (registration results in LDS)
         const EngRelay rl{ENG_RELAY && p.rep_stride != 0, reg_s[1], reg_s[2], p.rep_delta0 + (long)reg_s[0] * p.rep_stride};
         eng_barrier();                                                  // B0
-        for (int cb = 0; cb < p.ncb && alive; ++cb) {
+        if (pair) {
+            const unsigned tag0 = eng_tag16(epoch), tag1 = eng_tag16(epoch + 1u);
+            float r0c[2], r0s[2], r1c[2], r1s[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int d = lane + 64 * e;
+                r0c[e] = d < hd ? p.rope[((size_t)(d >> 1)) * 2] : 1.f;
+                r0s[e] = d < hd ? p.rope[((size_t)(d >> 1)) * 2 + 1] : 0.f;
+                r1c[e] = d < hd ? p.rope[((size_t)(hd >> 1) + (d >> 1)) * 2] : 1.f;
+                r1s[e] = d < hd ? p.rope[((size_t)(hd >> 1) + (d >> 1)) * 2 + 1] : 0.f;
+            }
+            for (int li = 0; li < nL; ++li) {
+                const EngLayer l = eng_layer(p.layers, li);
+                const bool tail0 = li + 1 < nL;
+                const int wh = 1000 + 64 + li * 8;
+                bf16_t* kL = kvS + (size_t)(li * 2) * p.ncb * KVW;
+                bf16_t* vL = kvS + (size_t)(li * 2 + 1) * p.ncb * KVW;
+                if (li > 0) {
+                    eng_gather_x2(rl, EngSrc2{{bx(0, li), bx(1, li)}, {xA, xA1}, {tag0, tag1}}, D, gw, ENG_GW, lane, p.ctl, dead, wh + 0);
+                } else {
+                    for (int d = atid * 4; d < D; d += ENG_GW * 64 * 4) {
+                        *reinterpret_cast<float4*>(xA + d) = *reinterpret_cast<const float4*>(p.hid + d);
+                        *reinterpret_cast<float4*>(xA1 + d) = *reinterpret_cast<const float4*>(p.femb + d);
+                    }
+                }
+                eng_barrier(); if (*dead) { alive = false; break; }     // B1
+                eng_gather_x2(rl, EngSrc2{{bq(0, li), bq(1, li)}, {qkvS, qkvS1}, {tag0, tag1}}, p.qkvN, gw, ENG_GW, lane, p.ctl, dead, wh + 1);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B1b
+                eng_fast_attn<MAXCB, HDIM>(qkvS, kL, vL, yS, l.qn, l.kn, r0c, r0s, 0, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_barrier();
+                eng_fast_attn<MAXCB, HDIM>(qkvS1, kL, vL, yS1, l.qn, l.kn, r1c, r1s, 1, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_barrier();                                          // B2
+                if (tail0) eng_gather_x2(rl, EngSrc2{{bxb(0, li), bxb(1, li)}, {xB, xB1}, {tag0, tag1}}, D, gw, ENG_GW, lane, p.ctl, dead, wh + 2);
+                else eng_gather_x(rl, bxb(1, li), layD, 0, D, tag1, xB1, gw, ENG_GW, lane, p.ctl, dead, wh + 2);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B3
+                if (tail0) eng_gather_x2(rl, EngSrc2{{bg(0, li), bg(1, li)}, {gS, gS1}, {tag0, tag1}}, F, gw, ENG_GW, lane, p.ctl, dead, wh + 3);
+                else eng_gather_x(rl, bg(1, li), layF, 0, F, tag1, gS1, gw, ENG_GW, lane, p.ctl, dead, wh + 3);
+                eng_barrier(); if (*dead) { alive = false; break; }     // B4
+            }
+        }
+        for (int cb = pair ? 1 : 0; cb < p.ncb && alive; ++cb) {
             const int par = cb & 1;
             const unsigned tag = eng_tag16(epoch + (unsigned)cb);
             float rcs[2], rsn[2];
@@ -1403,7 +1741,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 rcs[e] = d < hd ? p.rope[((size_t)cb * (hd >> 1) + (d >> 1)) * 2] : 1.f;
                 rsn[e] = d < hd ? p.rope[((size_t)cb * (hd >> 1) + (d >> 1)) * 2 + 1] : 0.f;
             }
-            for (int li = 0; li < nL; ++li) {
+            for (int li = (pair && cb == 1) ? nL : 0; li < nL; ++li) {
                 const EngLayer l = eng_layer(p.layers, li);
                 if (li > 0) {
                     eng_gather_x(rl, bx(par, li), layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 0);

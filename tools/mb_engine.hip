@@ -186,7 +186,9 @@ static int run_fast(int nb, hipStream_t s) {
     sp.pos = (int*)zalloc(4); sp.done = (int*)zalloc(4);
     p.samp = sp; p.noise_cb_stride = V; p.noise_off1 = 8192;
     unsigned long long* stamps = (unsigned long long*)zalloc((size_t)nb * ncb * nL * 16 * 8);
-    size_t ldsb = ((size_t)D * 2 + qkvN + HD + F + V + ENG_MAX_OUT + 8 + 32 + 32 + 12 + 2048 + 4 + 4 + 16) * 4 + (size_t)nL * 2 * ncb * Hkv * hd * 2 + 64;
+    p.pair = getenv("NO_PAIR") ? 0 : 1;
+    size_t ldsb = eng_fast_lds_bytes(D, qkvN, HD, F, V, nL, ncb, Hkv * hd, p.pair != 0);
+    printf("paired first pass: %d, LDS %zu bytes\n", p.pair, ldsb);
     CK(hipFuncSetAttribute((const void*)fast_engine_kernel<2, 2, 6, 10, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     CK(hipStreamSynchronize(s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -226,6 +228,22 @@ static int run_fast(int nb, hipStream_t s) {
     }
     printf("chip-wide (steps 2.., layers 1..), us after the last workgroup finished the previous layer's W2 rows (earliest / median / latest):\n");
     for (int kk = 0; kk < 10; ++kk) { const int k = order[kk]; printf("   %-22s %7.2f %7.2f %7.2f\n", names[k], lo[k] / cnt / 100.0, md[k] / cnt / 100.0, hi[k] / cnt / 100.0); }
+    if (p.pair) {
+        double plo[10] = {0}, pmd[10] = {0}, phi[10] = {0};
+        int pc = 0;
+        for (int li = 1; li < nL - 1; ++li) {       // the last layer carries one row after the attention
+            unsigned long long t0 = 0;
+            for (int b = 0; b < nb; ++b) t0 = std::max(t0, st[(((size_t)b * ncb + 1) * nL + li - 1) * 16 + 8]);
+            for (int k = 0; k < 10; ++k) {
+                for (int b = 0; b < nb; ++b) v[b] = st[(((size_t)b * ncb + 1) * nL + li) * 16 + k];
+                std::sort(v.begin(), v.end());
+                plo[k] += (double)v[0] - (double)t0; pmd[k] += (double)v[nb / 2] - (double)t0; phi[k] += (double)v[nb - 1] - (double)t0;
+            }
+            ++pc;
+        }
+        printf("paired first pass (positions 0 and 1 as two rows), layers 1..%d, same reading:\n", nL - 2);
+        for (int kk = 0; kk < 10; ++kk) { const int k = order[kk]; printf("   %-22s %7.2f %7.2f %7.2f\n", names[k], plo[k] / pc / 100.0, pmd[k] / pc / 100.0, phi[k] / pc / 100.0); }
+    }
     // per step: time from the last layer's W2 to the next step's first B1 (head + draw + code hand-off)
     double gap = 0; int gc = 0;
     for (int cb = 2; cb < ncb; ++cb) {
