@@ -1261,6 +1261,118 @@ __device__ __forceinline__ void eng_fast_attn(const float* qkvS, bf16_t* kS, bf1
     }
 }
 
+// eng_fast_attn at head_dim 64 with far fewer instructions (the phase is issue-bound: ~450 per head above), same bits:
+//  * a wave takes ONE kv head and its G query heads (the K/V row of the new position is normalised, rotated and stored once,
+//    and every K/V row is written and read by the same wave);
+//  * the scores of 4 positions are formed at a time: lane 16 r + k holds dimensions 4k..4k+3 of position 4 ps + r and
+//    builds wave_sum's tree from them - (p0 + p1) + (p2 + p3) in the lane = its xor-1 / xor-2 steps, xor-1 / xor-2 across
+//    the lanes = its half-mirror / mirror steps (8- and 16-dimension blocks), then the four 16-blocks in order
+//    ((R0 + R1) + R2) + R3 = its readlane chain;
+//  * q (dimension per lane after the rotation) reaches that layout through the head's own slot of yS, which also
+//    carries the scores to "lane j holds score j"; the slot receives the head's output last.
+#ifndef ENG_FAST_ATTN64
+#define ENG_FAST_ATTN64 1
+#endif
+constexpr int DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108, DPP_ROW_SHL12 = 0x10C;   // lane i <- lane i + n of its 16-lane row
+template <int MAXCB>
+__device__ __forceinline__ void eng_fast_attn64(const float* qkvS, bf16_t* kS, bf16_t* vS, float* yS, const bf16_t* qn, const bf16_t* kn,
+                                                float cs, float sn, int c, int ncb, int H, int Hkv, float eps, float scale,
+                                                int w, int nw, int lane) {
+    constexpr int HD = 64;
+    const int G = H / Hkv;
+    const bool even = (lane & 1) == 0;
+    const int r = lane >> 4, k4 = (lane & 15) * 4;
+    for (int kvh = w; kvh < Hkv; kvh += nw) {
+        bf16_t* kh = kS + (size_t)kvh * ncb * HD;
+        bf16_t* vh = vS + (size_t)kvh * ncb * HD;
+        float kx = qkvS[(H + kvh) * HD + lane];
+        const float vx = qkvS[(H + Hkv + kvh) * HD + lane];
+        if (kn) {
+            const float ss = wave_sum(kx * kx);
+            const float inv = rsqrt_exact(ss / (float)HD + eps);
+            kx = round_bf16((kx * inv) * eng_ldg_bf16(kn, lane));
+        }
+        {
+            const float ko = dpp_f<DPP_XOR1>(kx);
+            kx = round_bf16(even ? kx * cs - ko * sn : kx * cs + ko * sn);
+        }
+        kh[c * HD + lane] = f32_to_bf16_bits(kx);
+        vh[c * HD + lane] = f32_to_bf16_bits(vx);
+        if (c == 0) {       // one visible position: weight round_bf16(1 / 1) = 1, output fma(1, v, 0) = v
+            for (int g = 0; g < G; ++g) yS[(kvh * G + g) * HD + lane] = round_bf16(vx);
+            continue;
+        }
+        for (int g = 0; g < G; ++g) {
+            const int h = kvh * G + g;
+            float* slot = yS + h * HD;
+            float q = qkvS[h * HD + lane];
+            if (qn) {
+                const float ss = wave_sum(q * q);
+                const float inv = rsqrt_exact(ss / (float)HD + eps);
+                q = round_bf16((q * inv) * eng_ldg_bf16(qn, lane));
+            }
+            {
+                const float qo = dpp_f<DPP_XOR1>(q);
+                q = round_bf16(even ? q * cs - qo * sn : q * cs + qo * sn);
+            }
+            slot[lane] = q;
+            __builtin_amdgcn_wave_barrier();
+            const float4 q4 = *reinterpret_cast<const float4*>(slot + k4);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ps = 0; ps < (MAXCB + 3) / 4; ++ps) {
+                if (ps * 4 <= c) {                                  // wave-uniform
+                    const int j = ps * 4 + r;
+                    const int jj = j <= c ? j : c;                  // rows past the last position re-read it (not stored)
+                    const uint2 kb = *reinterpret_cast<const uint2*>(kh + jj * HD + k4);
+                    const float k0 = __uint_as_float(kb.x << 16), k1 = __uint_as_float(kb.x & 0xffff0000u);
+                    const float k2 = __uint_as_float(kb.y << 16), k3 = __uint_as_float(kb.y & 0xffff0000u);
+                    // fast_attn_kernel's per-lane product carries an exact zero second term at head_dim <= 64
+                    const float p0 = fmaf(0.f, 0.f, q4.x * k0), p1 = fmaf(0.f, 0.f, q4.y * k1);
+                    const float p2 = fmaf(0.f, 0.f, q4.z * k2), p3 = fmaf(0.f, 0.f, q4.w * k3);
+                    float sdot = (p0 + p1) + (p2 + p3);
+                    sdot += dpp_f<DPP_XOR1>(sdot);
+                    sdot += dpp_f<DPP_XOR2>(sdot);
+                    float a = sdot + dpp_f<DPP_ROW_SHL4>(sdot);
+                    a = a + dpp_f<DPP_ROW_SHL8>(sdot);
+                    a = a + dpp_f<DPP_ROW_SHL12>(sdot);
+                    const float sj = round_bf16(round_bf16(a) * scale);
+                    if ((lane & 15) == 0 && j <= c) slot[j] = sj;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float sl = lane <= c ? slot[lane] : -INFINITY;   // lane j: score j
+            __builtin_amdgcn_wave_barrier();
+            float mx = sl;                                          // positions live in lanes 0..15 (MAXCB <= 16)
+            mx = fmaxf(mx, dpp_f<DPP_XOR1>(mx));
+            mx = fmaxf(mx, dpp_f<DPP_XOR2>(mx));
+            mx = fmaxf(mx, dpp_f<DPP_HALF_MIRROR>(mx));
+            mx = fmaxf(mx, dpp_f<DPP_MIRROR>(mx));
+            mx = lane_f(mx, 0);
+            const float el = lane <= c ? expf(sl - mx) : 0.f;
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXCB; ++j)
+                if (j <= c) sum += lane_f(el, j);
+            const float pl = lane <= c ? round_bf16(el / sum) : 0.f;
+            float o = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXCB; ++j)
+                if (j <= c) o = fmaf(lane_f(pl, j), bf16_bits_to_f32(vh[j * HD + lane]), o);
+            slot[lane] = round_bf16(o);
+        }
+    }
+}
+template <int MAXCB, int HD>
+__device__ __forceinline__ void eng_fast_attn_any(const float* qkvS, bf16_t* kS, bf16_t* vS, float* yS, const bf16_t* qn, const bf16_t* kn,
+                                                  const float (&cs)[2], const float (&sn)[2], int c, int ncb, int H, int Hkv, float eps,
+                                                  float scale, int w, int nw, int lane) {
+    if constexpr (HD == 64 && MAXCB <= 16 && ENG_FAST_ATTN64)
+        eng_fast_attn64<MAXCB>(qkvS, kS, vS, yS, qn, kn, cs[0], sn[0], c, ncb, H, Hkv, eps, scale, w, nw, lane);
+    else
+        eng_fast_attn<MAXCB, HD>(qkvS, kS, vS, yS, qn, kn, cs, sn, c, ncb, H, Hkv, eps, scale, w, nw, lane);
+}
+
 // The draw of one codebook from V <= 1024 logits in LDS by the four gathering waves (256 threads): sample_small_kernel's
 // arithmetic (ar_kernels.h), its workgroup barriers replaced by the four-wave barrier.  Returns the drawn index.
 struct EngSampLds {
@@ -1570,9 +1682,9 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 __builtin_amdgcn_sched_barrier(0);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b: qkvS, qkvS1
                 ENG_FSTAMP(2);
-                eng_fast_attn<MAXCB, HDIM>(qkvS, kL, vL, yS, l.qn, l.kn, r0c, r0s, 0, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_fast_attn_any<MAXCB, HDIM>(qkvS, kL, vL, yS, l.qn, l.kn, r0c, r0s, 0, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 eng_barrier();                                          // position 0's K/V rows in LDS
-                eng_fast_attn<MAXCB, HDIM>(qkvS1, kL, vL, yS1, l.qn, l.kn, r1c, r1s, 1, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_fast_attn_any<MAXCB, HDIM>(qkvS1, kL, vL, yS1, l.qn, l.kn, r1c, r1s, 1, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 ENG_FSTAMP(9);
                 eng_barrier();                                          // B2: yS, yS1
                 ENG_FSTAMP(3);
@@ -1646,7 +1758,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 __builtin_amdgcn_sched_barrier(0);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b: qkvS
                 ENG_FSTAMP(2);
-                eng_fast_attn<MAXCB, HDIM>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
+                eng_fast_attn_any<MAXCB, HDIM>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
                                          rcs, rsn, cb, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 ENG_FSTAMP(9);
                 eng_barrier();                                          // B2: yS
@@ -1719,9 +1831,9 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1
                 eng_gather_x2(rl, EngSrc2{{bq(0, li), bq(1, li)}, {qkvS, qkvS1}, {tag0, tag1}}, p.qkvN, gw, ENG_GW, lane, p.ctl, dead, wh + 1);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b
-                eng_fast_attn<MAXCB, HDIM>(qkvS, kL, vL, yS, l.qn, l.kn, r0c, r0s, 0, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_fast_attn_any<MAXCB, HDIM>(qkvS, kL, vL, yS, l.qn, l.kn, r0c, r0s, 0, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 eng_barrier();
-                eng_fast_attn<MAXCB, HDIM>(qkvS1, kL, vL, yS1, l.qn, l.kn, r1c, r1s, 1, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_fast_attn_any<MAXCB, HDIM>(qkvS1, kL, vL, yS1, l.qn, l.kn, r1c, r1s, 1, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 eng_barrier();                                          // B2
                 if (tail0) eng_gather_x2(rl, EngSrc2{{bxb(0, li), bxb(1, li)}, {xB, xB1}, {tag0, tag1}}, D, gw, ENG_GW, lane, p.ctl, dead, wh + 2);
                 else eng_gather_x(rl, bxb(1, li), layD, 0, D, tag1, xB1, gw, ENG_GW, lane, p.ctl, dead, wh + 2);
@@ -1761,7 +1873,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1
                 eng_gather_x(rl, bq(par, li), layQ, 0, p.qkvN, tag, qkvS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 1);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b
-                eng_fast_attn<MAXCB, HDIM>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
+                eng_fast_attn_any<MAXCB, HDIM>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
                                          rcs, rsn, cb, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 eng_barrier();                                          // B2
                 eng_gather_x(rl, bxb(par, li), layD, 0, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 2);
