@@ -1274,12 +1274,12 @@ __device__ __forceinline__ void eng_fast_attn(const float* qkvS, bf16_t* kS, bf1
 #define ENG_FAST_ATTN64 1
 #endif
 constexpr int DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108, DPP_ROW_SHL12 = 0x10C;   // lane i <- lane i + n of its 16-lane row
-template <int MAXCB>
+template <int MAXCB, int GQ>
 __device__ __forceinline__ void eng_fast_attn64(const float* qkvS, bf16_t* kS, bf16_t* vS, float* yS, const bf16_t* qn, const bf16_t* kn,
                                                 float cs, float sn, int c, int ncb, int H, int Hkv, float eps, float scale,
                                                 int w, int nw, int lane) {
+    // GQ = query heads per kv head (compile time): their independent chains are written stage by stage so they interleave
     constexpr int HD = 64;
-    const int G = H / Hkv;
     const bool even = (lane & 1) == 0;
     const int r = lane >> 4, k4 = (lane & 15) * 4;
     for (int kvh = w; kvh < Hkv; kvh += nw) {
@@ -1287,6 +1287,10 @@ __device__ __forceinline__ void eng_fast_attn64(const float* qkvS, bf16_t* kS, b
         bf16_t* vh = vS + (size_t)kvh * ncb * HD;
         float kx = qkvS[(H + kvh) * HD + lane];
         const float vx = qkvS[(H + Hkv + kvh) * HD + lane];
+        float* slot = yS + (size_t)kvh * GQ * HD;            // the GQ heads' slots are consecutive
+        float q[GQ];
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) q[g] = qkvS[(kvh * GQ + g) * HD + lane];
         if (kn) {
             const float ss = wave_sum(kx * kx);
             const float inv = rsqrt_exact(ss / (float)HD + eps);
@@ -1299,37 +1303,39 @@ __device__ __forceinline__ void eng_fast_attn64(const float* qkvS, bf16_t* kS, b
         kh[c * HD + lane] = f32_to_bf16_bits(kx);
         vh[c * HD + lane] = f32_to_bf16_bits(vx);
         if (c == 0) {       // one visible position: weight round_bf16(1 / 1) = 1, output fma(1, v, 0) = v
-            for (int g = 0; g < G; ++g) yS[(kvh * G + g) * HD + lane] = round_bf16(vx);
+#pragma unroll
+            for (int g = 0; g < GQ; ++g) slot[g * HD + lane] = round_bf16(vx);
             continue;
         }
-        for (int g = 0; g < G; ++g) {
-            const int h = kvh * G + g;
-            float* slot = yS + h * HD;
-            float q = qkvS[h * HD + lane];
-            if (qn) {
-                const float ss = wave_sum(q * q);
-                const float inv = rsqrt_exact(ss / (float)HD + eps);
-                q = round_bf16((q * inv) * eng_ldg_bf16(qn, lane));
-            }
-            {
-                const float qo = dpp_f<DPP_XOR1>(q);
-                q = round_bf16(even ? q * cs - qo * sn : q * cs + qo * sn);
-            }
-            slot[lane] = q;
-            __builtin_amdgcn_wave_barrier();
-            const float4 q4 = *reinterpret_cast<const float4*>(slot + k4);
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int ps = 0; ps < (MAXCB + 3) / 4; ++ps) {
-                if (ps * 4 <= c) {                                  // wave-uniform
-                    const int j = ps * 4 + r;
-                    const int jj = j <= c ? j : c;                  // rows past the last position re-read it (not stored)
-                    const uint2 kb = *reinterpret_cast<const uint2*>(kh + jj * HD + k4);
-                    const float k0 = __uint_as_float(kb.x << 16), k1 = __uint_as_float(kb.x & 0xffff0000u);
-                    const float k2 = __uint_as_float(kb.y << 16), k3 = __uint_as_float(kb.y & 0xffff0000u);
+        for (int g = 0; g < GQ; ++g) {
+            if (qn) {
+                const float ss = wave_sum(q[g] * q[g]);
+                const float inv = rsqrt_exact(ss / (float)HD + eps);
+                q[g] = round_bf16((q[g] * inv) * eng_ldg_bf16(qn, lane));
+            }
+            const float qo = dpp_f<DPP_XOR1>(q[g]);
+            q[g] = round_bf16(even ? q[g] * cs - qo * sn : q[g] * cs + qo * sn);
+            slot[g * HD + lane] = q[g];
+        }
+        __builtin_amdgcn_wave_barrier();
+        float4 q4[GQ];
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) q4[g] = *reinterpret_cast<const float4*>(slot + g * HD + k4);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < (MAXCB + 3) / 4; ++ps) {
+            if (ps * 4 <= c) {                                  // wave-uniform
+                const int j = ps * 4 + r;
+                const int jj = j <= c ? j : c;                  // rows past the last position re-read it (not stored)
+                const uint2 kb = *reinterpret_cast<const uint2*>(kh + jj * HD + k4);
+                const float k0 = __uint_as_float(kb.x << 16), k1 = __uint_as_float(kb.x & 0xffff0000u);
+                const float k2 = __uint_as_float(kb.y << 16), k3 = __uint_as_float(kb.y & 0xffff0000u);
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) {
                     // fast_attn_kernel's per-lane product carries an exact zero second term at head_dim <= 64
-                    const float p0 = fmaf(0.f, 0.f, q4.x * k0), p1 = fmaf(0.f, 0.f, q4.y * k1);
-                    const float p2 = fmaf(0.f, 0.f, q4.z * k2), p3 = fmaf(0.f, 0.f, q4.w * k3);
+                    const float p0 = fmaf(0.f, 0.f, q4[g].x * k0), p1 = fmaf(0.f, 0.f, q4[g].y * k1);
+                    const float p2 = fmaf(0.f, 0.f, q4[g].z * k2), p3 = fmaf(0.f, 0.f, q4[g].w * k3);
                     float sdot = (p0 + p1) + (p2 + p3);
                     sdot += dpp_f<DPP_XOR1>(sdot);
                     sdot += dpp_f<DPP_XOR2>(sdot);
@@ -1337,40 +1343,55 @@ __device__ __forceinline__ void eng_fast_attn64(const float* qkvS, bf16_t* kS, b
                     a = a + dpp_f<DPP_ROW_SHL8>(sdot);
                     a = a + dpp_f<DPP_ROW_SHL12>(sdot);
                     const float sj = round_bf16(round_bf16(a) * scale);
-                    if ((lane & 15) == 0 && j <= c) slot[j] = sj;
+                    if ((lane & 15) == 0 && j <= c) slot[g * HD + j] = sj;
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            const float sl = lane <= c ? slot[lane] : -INFINITY;   // lane j: score j
-            __builtin_amdgcn_wave_barrier();
-            float mx = sl;                                          // positions live in lanes 0..15 (MAXCB <= 16)
+        }
+        __builtin_amdgcn_wave_barrier();
+        float sl[GQ], el[GQ], sum[GQ], pl[GQ], o[GQ];
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) sl[g] = lane <= c ? slot[g * HD + lane] : -INFINITY;   // lane j: score j
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) {
+            float mx = sl[g];                                       // positions live in lanes 0..15 (MAXCB <= 16)
             mx = fmaxf(mx, dpp_f<DPP_XOR1>(mx));
             mx = fmaxf(mx, dpp_f<DPP_XOR2>(mx));
             mx = fmaxf(mx, dpp_f<DPP_HALF_MIRROR>(mx));
             mx = fmaxf(mx, dpp_f<DPP_MIRROR>(mx));
             mx = lane_f(mx, 0);
-            const float el = lane <= c ? expf(sl - mx) : 0.f;
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < MAXCB; ++j)
-                if (j <= c) sum += lane_f(el, j);
-            const float pl = lane <= c ? round_bf16(el / sum) : 0.f;
-            float o = 0.f;
-#pragma unroll
-            for (int j = 0; j < MAXCB; ++j)
-                if (j <= c) o = fmaf(lane_f(pl, j), bf16_bits_to_f32(vh[j * HD + lane]), o);
-            slot[lane] = round_bf16(o);
+            el[g] = lane <= c ? expf(sl[g] - mx) : 0.f;
+            sum[g] = 0.f; o[g] = 0.f;
         }
+#pragma unroll
+        for (int j = 0; j < MAXCB; ++j)
+            if (j <= c) {
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) sum[g] += lane_f(el[g], j);
+            }
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) pl[g] = lane <= c ? round_bf16(el[g] / sum[g]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXCB; ++j)
+            if (j <= c) {
+                const float vj = bf16_bits_to_f32(vh[j * HD + lane]);
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) o[g] = fmaf(lane_f(pl[g], j), vj, o[g]);
+            }
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) slot[g * HD + lane] = round_bf16(o[g]);
     }
 }
 template <int MAXCB, int HD>
 __device__ __forceinline__ void eng_fast_attn_any(const float* qkvS, bf16_t* kS, bf16_t* vS, float* yS, const bf16_t* qn, const bf16_t* kn,
                                                   const float (&cs)[2], const float (&sn)[2], int c, int ncb, int H, int Hkv, float eps,
                                                   float scale, int w, int nw, int lane) {
-    if constexpr (HD == 64 && MAXCB <= 16 && ENG_FAST_ATTN64)
-        eng_fast_attn64<MAXCB>(qkvS, kS, vS, yS, qn, kn, cs[0], sn[0], c, ncb, H, Hkv, eps, scale, w, nw, lane);
-    else
-        eng_fast_attn<MAXCB, HD>(qkvS, kS, vS, yS, qn, kn, cs, sn, c, ncb, H, Hkv, eps, scale, w, nw, lane);
+    if constexpr (HD == 64 && MAXCB <= 16 && ENG_FAST_ATTN64) {
+        const int G = H / Hkv;
+        if (G == 2) { eng_fast_attn64<MAXCB, 2>(qkvS, kS, vS, yS, qn, kn, cs[0], sn[0], c, ncb, H, Hkv, eps, scale, w, nw, lane); return; }
+        if (G == 1) { eng_fast_attn64<MAXCB, 1>(qkvS, kS, vS, yS, qn, kn, cs[0], sn[0], c, ncb, H, Hkv, eps, scale, w, nw, lane); return; }
+    }
+    eng_fast_attn<MAXCB, HD>(qkvS, kS, vS, yS, qn, kn, cs, sn, c, ncb, H, Hkv, eps, scale, w, nw, lane);
 }
 
 // The draw of one codebook from V <= 1024 logits in LDS by the four gathering waves (256 threads): sample_small_kernel's
