@@ -429,7 +429,7 @@ static ft_status eng_setup(ft_ctx* ctx) {
     const int qkvN = (c.n_head + 2 * c.n_local_heads) * c.head_dim;
     auto per = [&](int units) { return (units + nb - 1) / nb; };
     const bool shape_ok = c.dim == 1024 && HD == 2048 && c.intermediate_size == 3072 && c.head_dim == 128 &&
-                          c.n_head == 2 * c.n_local_heads && c.fast_dim == c.dim && c.n_layer >= 1 &&
+                          c.n_head == 2 * c.n_local_heads && c.fast_dim == c.dim && c.n_layer >= 1 && c.n_layer < ENG_EPOCH_STEP &&
                           per(qkvN) <= ENG_SQ * ENG_CW && per(c.dim) <= ENG_SO * ENG_CW && per(c.intermediate_size) <= ENG_SF * ENG_CW &&
                           qkvN % (4 * nb) == 0 && c.dim % (4 * nb) == 0 && c.intermediate_size % (4 * nb) == 0 && per(qkvN) <= ENG_LINE &&
                           c.n_local_heads * ctx->nsplit_max <= nb && c.head_dim % (4 * ctx->nsplit_max) == 0 &&

@@ -30,7 +30,12 @@ constexpr int ENG_WAVES = 8;             // waves per workgroup (one workgroup p
 constexpr int ENG_THREADS = ENG_WAVES * 64;
 constexpr int ENG_CW = 4;                // waves 0..3 own weight rows
 constexpr int ENG_GW = 4;                // waves 4..7 gather the input vector of a phase
-constexpr int ENG_EPOCH_STEP = 16;       // tags used per launch (>= num_codebooks)
+// slow stack: the hand-off vectors of layer li live in the buffers of parity li & 1 (tag = epoch + li), so the lines that
+// are polled were written two layers ago and are still in the L2 / memory-side cache instead of cold in HBM
+#ifndef ENG_SLOW_REUSE
+#define ENG_SLOW_REUSE 1
+#endif
+constexpr int ENG_EPOCH_STEP = 64;       // tags used per launch (>= num_codebooks, >= slow layers)
 #ifndef ENG_ISSUE_LATE
 #define ENG_ISSUE_LATE 0                   // 1: a matrix's next rows are requested one barrier later than its last use
 #endif
@@ -617,7 +622,7 @@ constexpr int ENG_KVST = 6;   // K/V steps of an attention workgroup held in reg
 
 // which (kv head, split) workgroup b takes in layer li, or -1: the Hkv * nsplit attention workgroups rotate with the layer
 __device__ __forceinline__ int eng_att_role(int b, int nb, int li, int natt) {
-    int a = b - (int)(((long)li * natt) % nb);
+    int a = b - (int)(((unsigned)li * (unsigned)natt) % (unsigned)nb);
     if (a < 0) a += nb;
     return a < natt ? a : -1;
 }
@@ -659,7 +664,6 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
         if (ENG_RELAY && p.rep_stride) eng_register(p.ctl, nb, reg_s, dead);
     }
     const unsigned epoch = __hip_atomic_load((eng_gu32*)(p.ctl + ENG_CTL_EPOCH), ENG_RLX);
-    const unsigned tag = eng_tag16(epoch), tag32 = eng_tag32(epoch);
     const int pos = p.pos[0] + p.pos_off;
     unsigned long long clk0 = 0, rt0 = 0;
     if (p.stamps) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = eng_rt(); }
@@ -725,6 +729,9 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
         eng_barrier();                                              // (registration results in LDS)
         eng_barrier();                                              // B0
         for (int li = 0; li < p.n_layer; ++li) {
+            const int par = ENG_SLOW_REUSE ? (li & 1) : li, parn = ENG_SLOW_REUSE ? ((li + 1) & 1) : li + 1;
+            const unsigned tag = eng_tag16(epoch + (ENG_SLOW_REUSE ? (unsigned)li : 0u));
+            const unsigned tagn = eng_tag16(epoch + (ENG_SLOW_REUSE ? (unsigned)li + 1u : 0u));    // the next layer reads W2's output
             const EngLayer l = eng_layer(p.layers, li);
             const bool more = li + 1 < p.n_layer;
             const EngLayer ln = eng_layer(p.layers, more ? li + 1 : li);
@@ -733,7 +740,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             if (li > 0) { eng_issue(wd, l.w2, (const bf16_t*)nullptr, F, d_lo, d_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
 #endif
             ENG_STAMP(0);
-            eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, p.gqkv + (size_t)li * VSTR + eng_pub(b, q_lo), tag, nullptr,
+            eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, p.gqkv + (size_t)par * VSTR + eng_pub(b, q_lo), tag, nullptr,
                                                          q_lo, q_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(1);
@@ -752,7 +759,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             if (more) { eng_issue(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
 #endif
             ENG_STAMP(3);
-            eng_gemv<NTA, 1, SO, PRO_NONE, EPI_RESID>(wo, yS, HD, p.eps, l.bo, xA, p.gxb + (size_t)li * VSTR + eng_pub(b, o_lo), tag, nullptr, o_lo, o_hi, cw, lane, eo);
+            eng_gemv<NTA, 1, SO, PRO_NONE, EPI_RESID>(wo, yS, HD, p.eps, l.bo, xA, p.gxb + (size_t)par * VSTR + eng_pub(b, o_lo), tag, nullptr, o_lo, o_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(4);
             if (p.stamps && (p.nt & 2)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ENG_STAMP(9); }   // write-through acknowledged
@@ -765,7 +772,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             if (more) { eng_issue(wo, ln.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
 #endif
             ENG_STAMP(5);
-            eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, D, p.eps, nullptr, nullptr, p.gg + (size_t)li * VSTR + eng_pub(b, f_lo), tag, nullptr, f_lo, f_hi, cw, lane, eo);
+            eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, D, p.eps, nullptr, nullptr, p.gg + (size_t)par * VSTR + eng_pub(b, f_lo), tag, nullptr, f_lo, f_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(6);
 #if !ENG_ISSUE_LATE
@@ -777,7 +784,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             if (more) { eng_issue(wf, ln.w13, ln.ffn_norm, D, f_lo, f_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
 #endif
             ENG_STAMP(7);
-            eng_gemv<NTF, 1, SO, PRO_NONE, EPI_RESID>(wd, gS, F, p.eps, nullptr, xB, p.gx + (size_t)(li + 1) * VSTR + eng_pub(b, d_lo), tag,
+            eng_gemv<NTF, 1, SO, PRO_NONE, EPI_RESID>(wd, gS, F, p.eps, nullptr, xB, p.gx + (size_t)parn * VSTR + eng_pub(b, d_lo), tagn,
                                                       li == p.n_layer - 1 ? p.x_out : nullptr, d_lo, d_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(8);
@@ -793,23 +800,43 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
         U4 kpf[ENG_KVST], vpf[ENG_KVST];
         float gq0 = 1.f, gq1 = 1.f, gk0 = 1.f, gk1 = 1.f;   // q / k norm gains (elements 2 lane, 2 lane + 1) of that layer
         int att_next = -1;    // the layer those rows belong to
-        auto kv_prefetch = [&](int from_layer) {
-            att_next = -1;
-            for (int l2 = from_layer; l2 < p.n_layer; ++l2)
-                if (eng_att_role(b, nb, l2, natt) >= 0) { att_next = l2; break; }
+        // planning (which layer is this workgroup's next turn, where are its cache rows and gains) is done EARLY - at kernel
+        // entry and at the start of a turn for the turn after it - so that the loads can be issued at B2 without any
+        // dependent scalar fetch or division in front of them: every workgroup produces rows in every phase, a
+        // microsecond lost by one of them here is lost by all (measured: the x' hand-off completed 0.9 us later)
+        int plan_layer = -1;
+        const bf16_t *plan_kc = nullptr, *plan_vc = nullptr, *plan_qn = nullptr, *plan_kn = nullptr;
+        const int period = (natt > 0 && nb % natt == 0) ? nb / natt : 0;
+        auto kv_plan = [&](int from_layer) {
+            plan_layer = -1;
+            if (from_layer >= p.n_layer) return;
+            if (period > 0) {
+                const int phase = b / natt;                          // this workgroup holds a role in layers == phase (mod period)
+                int d = phase - from_layer % period;
+                if (d < 0) d += period;
+                if (from_layer + d < p.n_layer) plan_layer = from_layer + d;
+            } else {
+                for (int l2 = from_layer; l2 < p.n_layer; ++l2)
+                    if (eng_att_role(b, nb, l2, natt) >= 0) { plan_layer = l2; break; }
+            }
+            if (plan_layer < 0) return;
+            const EngLayer l2 = eng_layer(p.layers, plan_layer);
+            plan_kc = l2.kc; plan_vc = l2.vc; plan_qn = l2.qn; plan_kn = l2.kn;
+        };
+        auto kv_issue = [&]() {
+            att_next = plan_layer;
 #pragma unroll
             for (int st = 0; st < ENG_KVST; ++st) { kpf[st] = U4{0u, 0u, 0u, 0u}; vpf[st] = U4{0u, 0u, 0u, 0u}; }
             if (att_next < 0) return;
             const int a = eng_att_role(b, nb, att_next, natt);
             const int kvh = a / p.nsplit, split = a % p.nsplit;
             const int lo = split * chunk, hi = min(lo + chunk, pos + 1);
-            const EngLayer l2 = eng_layer(p.layers, att_next);
             if (lane < hp) {
-                if (l2.qn) { gq0 = eng_ldg_bf16(l2.qn, 2 * lane); gq1 = eng_ldg_bf16(l2.qn, 2 * lane + 1); }
-                if (l2.kn) { gk0 = eng_ldg_bf16(l2.kn, 2 * lane); gk1 = eng_ldg_bf16(l2.kn, 2 * lane + 1); }
+                if (plan_qn) { gq0 = eng_ldg_bf16(plan_qn, 2 * lane); gq1 = eng_ldg_bf16(plan_qn, 2 * lane + 1); }
+                if (plan_kn) { gk0 = eng_ldg_bf16(plan_kn, 2 * lane); gk1 = eng_ldg_bf16(plan_kn, 2 * lane + 1); }
             }
-            const bf16_t* kc = l2.kc + p.cache_off + (size_t)kvh * p.n_slots * hd;
-            const bf16_t* vc = l2.vc + p.cache_off + (size_t)kvh * p.n_slots * hd;
+            const bf16_t* kc = plan_kc + p.cache_off + (size_t)kvh * p.n_slots * hd;
+            const bf16_t* vc = plan_vc + p.cache_off + (size_t)kvh * p.n_slots * hd;
 #pragma unroll
             for (int st = 0; st < ENG_KVST; ++st) {
                 const int j = lo + st * NSLOT + gw * PPW + grp;
@@ -819,7 +846,8 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 }
             }
         };
-        kv_prefetch(0);
+        kv_plan(0);
+        kv_issue();
         eng_barrier();                                              // (registration results in LDS)
         const EngRelay rl{ENG_RELAY && p.rep_stride != 0, reg_s[1], reg_s[2], p.rep_delta0 + (long)reg_s[0] * p.rep_stride};
         // rotation entries of this position (the same for every layer)
@@ -827,21 +855,24 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
         if (lane < hp) { rope_c = p.rope[((size_t)pos * hp + lane) * 2]; rope_s = p.rope[((size_t)pos * hp + lane) * 2 + 1]; }
         eng_barrier();                                              // B0
         for (int li = 0; li < p.n_layer; ++li) {
+            const int par = ENG_SLOW_REUSE ? (li & 1) : li;
+            const unsigned tag = eng_tag16(epoch + (ENG_SLOW_REUSE ? (unsigned)li : 0u)), tag32 = eng_tag32(epoch + (ENG_SLOW_REUSE ? (unsigned)li : 0u));
             const EngLayer l = eng_layer(p.layers, li);
             if (li > 0) {
-                eng_gather_x(rl, p.gx + (size_t)li * VSTR, layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 0);
+                eng_gather_x(rl, p.gx + (size_t)par * VSTR, layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 0);
                 eng_barrier(); if (*dead) break;                    // B1
             }
             // ---- attention (attn_decode_kernel's arithmetic; these four waves stand in for its 256 threads)
             const int a = eng_att_role(b, nb, li, natt);
             if (a >= 0) {     // (workgroup-uniform)
+                kv_plan(li + 1);                                    // the turn after this one (scalar fetches land during this turn)
                 const int kvh = a / p.nsplit, split = a % p.nsplit;
                 const int lo = split * chunk;
                 const int hi = min(lo + chunk, pos + 1);
                 bf16_t* kc = l.kc + p.cache_off + (size_t)kvh * p.n_slots * hd;
                 bf16_t* vc = l.vc + p.cache_off + (size_t)kvh * p.n_slots * hd;
                 const int slot = gw * PPW + grp;
-                const unsigned* gq = p.gqkv + (size_t)li * VSTR;
+                const unsigned* gq = p.gqkv + (size_t)par * VSTR;
                 // q heads of the group (G*hd granules), new k, new v (hd each): one gathering wave per piece
                 if (gw == 0) eng_gather(gq, layQ, kvh * G * hd, G * hd, tag, qS, 0, 1, lane, p.ctl, dead, li * 8 + 1);
                 if (gw == 1) eng_gather(gq, layQ, (p.H + kvh) * hd, hd, tag, qS + G * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
@@ -976,9 +1007,9 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                         }
                         const int head = kvh * G + g;
                         if (p.nsplit == 1) {
-                            eng_put(p.gy + (size_t)li * HD, head * hd + e, round_bf16(O / L), tag);
+                            eng_put(p.gy + (size_t)par * HD, head * hd + e, round_bf16(O / L), tag);
                         } else {
-                            unsigned long long* gp = p.gpart + (((size_t)li * p.H + head) * p.nsplit + split) * (hd + 2);
+                            unsigned long long* gp = p.gpart + (((size_t)par * p.H + head) * p.nsplit + split) * (hd + 2);
                             eng_put64(gp, e, O, tag32);
                             if (e == 0) { eng_put64(gp, hd, M, tag32); eng_put64(gp, hd + 1, L, tag32); }
                         }
@@ -1000,7 +1031,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                         const int g = item_on ? it / e4n : 0;
                         const int e = split * epb + (item_on ? (it % e4n) * 4 : 0);
                         const int head = kvh * G + g;
-                        const unsigned long long* gp = p.gpart + ((size_t)li * p.H + head) * p.nsplit * (hd + 2);
+                        const unsigned long long* gp = p.gpart + ((size_t)par * p.H + head) * p.nsplit * (hd + 2);
                         float M = -INFINITY, L = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
                         for (int c0 = 0; c0 < p.nsplit && alive; c0 += 8) {
                             const bool son = item_on && c0 + s8 < p.nsplit;
@@ -1046,7 +1077,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                             __builtin_amdgcn_wave_barrier();
                         }
                         if (alive && s8 == 0 && item_on) {
-                            unsigned* gy = p.gy + (size_t)li * HD + (size_t)a * (G * epb) + g * epb + (e - split * epb);
+                            unsigned* gy = p.gy + (size_t)par * HD + (size_t)a * (G * epb) + g * epb + (e - split * epb);
                             eng_put4(gy, round_bf16(a0 / L), round_bf16(a1 / L), round_bf16(a2 / L), round_bf16(a3 / L), tag);
                         }
                     }
@@ -1057,15 +1088,15 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 const int epb = hd / p.nsplit, ns = p.nsplit;
                 auto ymap = [=](int i) { const int a2 = i / (G * epb), r2 = i % (G * epb), g2 = r2 / epb, eo = r2 % epb;
                                          return ((a2 / ns) * G + g2) * hd + (a2 % ns) * epb + eo; };
-                eng_gather_x(rl, p.gy + (size_t)li * HD, layLin, 0, HD, tag, yS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 3, ymap);
+                eng_gather_x(rl, p.gy + (size_t)par * HD, layLin, 0, HD, tag, yS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 3, ymap);
             }
             eng_barrier(); if (*dead) break;                        // B2
             // the K/V rows (and norm gains) of this workgroup's next attention turn start their trip now: the polls
             // for x' wait at least a Wo phase anyway (vmcnt is in order: requested right after the partials they would
             // sit in front of the merge polls and of the y polls)
-            if (a >= 0) kv_prefetch(li + 1);
+            if (a >= 0) kv_issue();
             const unsigned long long t_poll0 = p.stamps ? eng_rt() : 0ull;   // kept in a register: a store here would sit in front of the polls
-            eng_gather_x(rl, p.gxb + (size_t)li * VSTR, layD, 0, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 4, EngIdent(),
+            eng_gather_x(rl, p.gxb + (size_t)par * VSTR, layD, 0, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 4, EngIdent(),
                        (p.stamps && gw == 0) ? p.stamps + ((size_t)b * p.n_layer + li) * 16 + 13 : nullptr);
             const unsigned long long t_poll1 = p.stamps ? eng_rt() : 0ull;
             eng_barrier(); if (*dead) break;                        // B3
@@ -1073,7 +1104,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 unsigned long long* q = p.stamps + ((size_t)b * p.n_layer + li) * 16;
                 q[10] = t_poll0; q[11] = t_poll1; q[12] = eng_rt();
             }
-            eng_gather_x(rl, p.gg + (size_t)li * VSTR, layF, 0, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 5);
+            eng_gather_x(rl, p.gg + (size_t)par * VSTR, layF, 0, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 5);
             eng_barrier(); if (*dead) break;                        // B4
         }
     }
