@@ -615,6 +615,9 @@ struct SlowEngP {
     unsigned long long* stamps;   // diagnostic builds only (tools/mb_engine.hip): [workgroup][layer][16] s_memrealtime ticks, or nullptr
 };
 #define ENG_STAMP(k) do { if (p.stamps && tid == 0) p.stamps[((size_t)b * p.n_layer + li) * 16 + (k)] = eng_rt(); } while (0)
+// attention-turn stamps of the gathering waves (second region of the stamp array), written by lane 0 of wave `wv`
+#define ENG_ASTAMP(wv, k) do { if (p.stamps && gw == (wv) && lane == 0) \
+    p.stamps[((size_t)nb * p.n_layer + (size_t)b * p.n_layer + li) * 16 + (k)] = eng_rt(); } while (0)
 
 // units per compute wave and matrix at 256 workgroups: QKV 16 rows -> 4, W13 12 pairs -> 3, Wo / W2 4 rows -> 1
 constexpr int ENG_SQ = 4, ENG_SF = 3, ENG_SO = 1;
@@ -873,11 +876,13 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 bf16_t* vc = l.vc + p.cache_off + (size_t)kvh * p.n_slots * hd;
                 const int slot = gw * PPW + grp;
                 const unsigned* gq = p.gqkv + (size_t)par * VSTR;
+                ENG_ASTAMP(0, 0);
                 // q heads of the group (G*hd granules), new k, new v (hd each): one gathering wave per piece
                 if (gw == 0) eng_gather(gq, layQ, kvh * G * hd, G * hd, tag, qS, 0, 1, lane, p.ctl, dead, li * 8 + 1);
                 if (gw == 1) eng_gather(gq, layQ, (p.H + kvh) * hd, hd, tag, qS + G * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
                 if (gw == 2) eng_gather(gq, layQ, (p.H + p.Hkv + kvh) * hd, hd, tag, qS + (G + 1) * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
                 eng_barrier(); if (*dead) break;                    // BA
+                ENG_ASTAMP(0, 1);
                 if (gw >= 0) {
                     for (int item = gw; item < G + 2; item += 4) {
                         const float* src = qS + item * hd;
@@ -907,6 +912,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                     }
                 }
                 eng_barrier();
+                ENG_ASTAMP(0, 2);
                 if (gw >= 0) {
                     if (pos >= lo && pos < hi) {
                         for (int e = atid; e < hd; e += 256) {
@@ -992,26 +998,52 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                     }
                 }
                 eng_barrier();
+                ENG_ASTAMP(0, 3);
                 if (gw >= 0) {
-                    for (int idx = atid; idx < G * hd; idx += 256) {
-                        const int g = idx / hd, e = idx % hd;
-                        float M = -INFINITY;
-                        for (int s = 0; s < NSLOT; ++s) M = fmaxf(M, ml_s[(s * G + g) * 2]);
-                        float L = 0.f, O = 0.f;
-                        if (M > -INFINITY) {
-                            for (int s = 0; s < NSLOT; ++s) {
-                                const float w = expf(ml_s[(s * G + g) * 2] - M);
-                                L += ml_s[(s * G + g) * 2 + 1] * w;
-                                O += acc_s[(size_t)(s * G + g) * hd + e] * w;
+                    // the combination of the NSLOT running (max, sum, acc) triples (attn_decode_kernel's): the weight of a
+                    // slot does not depend on the element, so lane s computes slot s's once and every lane reads it from
+                    // there (was: 16 exponentials per element and lane, 2.6 us on the path of every layer)
+                    const bool quick = NSLOT == 16 && (hd & 63) == 0;
+                    for (int idx0 = gw * 64; idx0 < G * hd; idx0 += 256) {
+                        const int idx = idx0 + lane;
+                        const int g = quick ? idx0 / hd : idx / hd, e = idx % hd;
+                        float M = -INFINITY, L = 0.f, O = 0.f;
+                        if (quick) {
+                            const int sl = lane & 15;
+                            const float m_l = ml_s[(sl * G + g) * 2], l_l = ml_s[(sl * G + g) * 2 + 1];
+                            M = m_l;
+                            M = fmaxf(M, dpp_f<DPP_XOR1>(M));
+                            M = fmaxf(M, dpp_f<DPP_XOR2>(M));
+                            M = fmaxf(M, dpp_f<DPP_HALF_MIRROR>(M));
+                            M = fmaxf(M, dpp_f<DPP_MIRROR>(M));
+                            if (M > -INFINITY) {
+                                const float w_l = expf(m_l - M);
+#pragma unroll
+                                for (int s2 = 0; s2 < 16; ++s2) {
+                                    const float w = lane_f(w_l, s2);
+                                    L += lane_f(l_l, s2) * w;
+                                    O += acc_s[(size_t)(s2 * G + g) * hd + e] * w;
+                                }
+                            }
+                        } else if (idx < G * hd) {
+                            for (int s2 = 0; s2 < NSLOT; ++s2) M = fmaxf(M, ml_s[(s2 * G + g) * 2]);
+                            if (M > -INFINITY) {
+                                for (int s2 = 0; s2 < NSLOT; ++s2) {
+                                    const float w = expf(ml_s[(s2 * G + g) * 2] - M);
+                                    L += ml_s[(s2 * G + g) * 2 + 1] * w;
+                                    O += acc_s[(size_t)(s2 * G + g) * hd + e] * w;
+                                }
                             }
                         }
-                        const int head = kvh * G + g;
-                        if (p.nsplit == 1) {
-                            eng_put(p.gy + (size_t)par * HD, head * hd + e, round_bf16(O / L), tag);
-                        } else {
-                            unsigned long long* gp = p.gpart + (((size_t)par * p.H + head) * p.nsplit + split) * (hd + 2);
-                            eng_put64(gp, e, O, tag32);
-                            if (e == 0) { eng_put64(gp, hd, M, tag32); eng_put64(gp, hd + 1, L, tag32); }
+                        if (idx < G * hd) {
+                            const int head = kvh * G + g;
+                            if (p.nsplit == 1) {
+                                eng_put(p.gy + (size_t)par * HD, head * hd + e, round_bf16(O / L), tag);
+                            } else {
+                                unsigned long long* gp = p.gpart + (((size_t)par * p.H + head) * p.nsplit + split) * (hd + 2);
+                                eng_put64(gp, e, O, tag32);
+                                if (e == 0) { eng_put64(gp, hd, M, tag32); eng_put64(gp, hd + 1, L, tag32); }
+                            }
                         }
                     }
                 }
@@ -1019,6 +1051,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 // [split * hd / nsplit, (split + 1) * hd / nsplit) of its G heads.  An item = 4 consecutive elements of
                 // one head; lane 8 * i + s polls split c0 + s of item i (O[0..3], m, l = three 16-byte loads), the
                 // values cross to the item's first lane through LDS, which merges in split order.
+                ENG_ASTAMP(0, 4);
                 if (p.nsplit > 1 && gw == 3) {
                     const int epb = hd / p.nsplit;            // elements per workgroup and head (multiple of 4)
                     const int e4n = epb >> 2;
@@ -1046,41 +1079,39 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                                 __builtin_amdgcn_s_sleep(ENG_POLL_SLEEP);
                             }
                             if (!alive) break;
-                            float* ms = mscr + lane * 6;
-                            ms[0] = son ? __uint_as_float(C.x) : -INFINITY;
-                            ms[1] = son ? __uint_as_float(C.z) : 0.f;
-                            ms[2] = __uint_as_float(A.x); ms[3] = __uint_as_float(A.z);
-                            ms[4] = __uint_as_float(B.x); ms[5] = __uint_as_float(B.z);
-                            __builtin_amdgcn_wave_barrier();
-                            if (s8 == 0 && item_on) {
-                                const float* mi = mscr + lane * 6;
-                                float Mc = -INFINITY;
-#pragma unroll
-                                for (int s = 0; s < 8; ++s) Mc = fmaxf(Mc, mi[s * 6]);
-                                if (Mc > -INFINITY) {
-                                    const float Mn = fmaxf(M, Mc);
-                                    if (c0 > 0 && M > -INFINITY) {
-                                        const float rr = expf(M - Mn);
-                                        L *= rr; a0 *= rr; a1 *= rr; a2 *= rr; a3 *= rr;
-                                    }
-                                    M = Mn;
-#pragma unroll
-                                    for (int s = 0; s < 8; ++s) {
-                                        const float m_ = mi[s * 6];
-                                        const float w = m_ > -INFINITY ? expf(m_ - M) : 0.f;
-                                        L += mi[s * 6 + 1] * w;
-                                        a0 += mi[s * 6 + 2] * w; a1 += mi[s * 6 + 3] * w;
-                                        a2 += mi[s * 6 + 4] * w; a3 += mi[s * 6 + 5] * w;
-                                    }
+                            if (ib + 8 >= nitem && c0 + 8 >= p.nsplit) ENG_ASTAMP(3, 5);      // last partials seen
+                            // lane 8 i + s holds split c0 + s of item i: the weights are formed in parallel, the sums are
+                            // taken in split order by the item's first lane (row_shl reads lane + s of the 16-lane row)
+                            const float m_ = son ? __uint_as_float(C.x) : -INFINITY;
+                            const float l_ = son ? __uint_as_float(C.z) : 0.f;
+                            float Mc = m_;
+                            Mc = fmaxf(Mc, dpp_f<DPP_XOR1>(Mc));
+                            Mc = fmaxf(Mc, dpp_f<DPP_XOR2>(Mc));
+                            Mc = fmaxf(Mc, dpp_f<DPP_HALF_MIRROR>(Mc));
+                            if (Mc > -INFINITY) {
+                                const float Mn = fmaxf(M, Mc);
+                                if (c0 > 0 && M > -INFINITY) {
+                                    const float rr = expf(M - Mn);
+                                    L *= rr; a0 *= rr; a1 *= rr; a2 *= rr; a3 *= rr;
                                 }
+                                M = Mn;
+                                const float w = m_ > -INFINITY ? expf(m_ - M) : 0.f;
+                                const float pl = l_ * w;
+                                const float p0 = __uint_as_float(A.x) * w, p1 = __uint_as_float(A.z) * w;
+                                const float p2 = __uint_as_float(B.x) * w, p3 = __uint_as_float(B.z) * w;
+                                L += pl; a0 += p0; a1 += p1; a2 += p2; a3 += p3;
+#define ENG_MSTEP(n) L += dpp_f<0x100 + n>(pl); a0 += dpp_f<0x100 + n>(p0); a1 += dpp_f<0x100 + n>(p1); \
+                     a2 += dpp_f<0x100 + n>(p2); a3 += dpp_f<0x100 + n>(p3);
+                                ENG_MSTEP(1) ENG_MSTEP(2) ENG_MSTEP(3) ENG_MSTEP(4) ENG_MSTEP(5) ENG_MSTEP(6) ENG_MSTEP(7)
+#undef ENG_MSTEP
                             }
-                            __builtin_amdgcn_wave_barrier();
                         }
                         if (alive && s8 == 0 && item_on) {
                             unsigned* gy = p.gy + (size_t)par * HD + (size_t)a * (G * epb) + g * epb + (e - split * epb);
                             eng_put4(gy, round_bf16(a0 / L), round_bf16(a1 / L), round_bf16(a2 / L), round_bf16(a3 / L), tag);
                         }
                     }
+                    ENG_ASTAMP(3, 6);
                 }
             }
             {
@@ -1438,10 +1469,34 @@ struct EngSampLds {
     uint32_t* keyL;  // [1024]
     uint32_t* cut;   // [3]: k, nk, all
 };
-__device__ __forceinline__ int eng_sample_small(const SampP& p, const float* L, const EngSampLds& S, EngSub& sub, int tid, int lane, int wave) {
+// What a draw needs besides the logits - sampling controls, frame number, this thread's id of the repetition window, this
+// thread's four noise values - is fetched / generated at the START of the codebook step, not between the arrival of the
+// logits and the draw (two dependent global loads and a Philox call were on that path)
+struct EngDrawPre {
+    RowCtl ctl;
+    int nfv;
+    int pen;        // thread < 16: its id of the 16-frame window of codebook cb (or -1)
+    float q4[4];
+};
+__device__ __forceinline__ EngDrawPre eng_draw_pre(const SampP& p, int tid) {
+    EngDrawPre d;
+    d.ctl = p.ctl[0];
+    d.nfv = p.nf[0];
+    d.pen = -1;
+    if (d.nfv > 0 && p.cb != 0 && tid < 16) {
+        const int it = d.nfv - 1;
+        const int ws = it < 16 ? 0 : it - 16;
+        d.pen = p.seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
+    }
+    const float* qrow = nullptr;
+    if (p.noise && d.nfv < p.noise_rows) qrow = p.noise + (size_t)d.nfv * p.noise_row_len + p.noise_off;
+    draw_noise4(p, d.ctl, qrow, 4 * tid, d.nfv, 0, p.V, d.q4);
+    return d;
+}
+__device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre& pre, const float* L, const EngSampLds& S, EngSub& sub, int tid, int lane, int wave) {
     const int V = p.V;
-    const RowCtl ctl = p.ctl[0];
-    const int nfv = p.nf[0];
+    const RowCtl ctl = pre.ctl;
+    const int nfv = pre.nfv;
     const int R = p.ncb + 1;
     const int* seq = p.seq;
     int red_phase = 0;
@@ -1461,8 +1516,9 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const float* L, 
         const int it = nfv - 1;
         const int ws = it < 16 ? 0 : it - 16;
         const int npen = p.cb == 0 ? R : 16;
+        (void)ws;
         if (tid < npen) {
-            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
+            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : pre.pen;
             S.pen_id[tid] = -1;
             if (id >= 0 && id < V) {
                 const float sv = L[id];
@@ -1589,16 +1645,12 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const float* L, 
             z2 += et[e];
         }
         const float Z2 = red_sum(z2);
-        const float* qrow = nullptr;
-        if (p.noise && nfv < p.noise_rows) qrow = p.noise + (size_t)nfv * p.noise_row_len + p.noise_off;
-        float q4[4];
-        draw_noise4(p, ctl, qrow, i0, nfv, 0, V, q4);
         ArgMax best{-1.f, 0x7fffffff};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (i0 + e < V) {
                 const float prob = keep[e] ? round_bf16(et[e] / Z2) : 0.f;
-                best = better(best, ArgMax{round_bf16(prob / round_bf16(q4[e])), i0 + e});
+                best = better(best, ArgMax{round_bf16(prob / round_bf16(pre.q4[e])), i0 + e});
             }
         }
         winner = block_best(best).i;
@@ -1905,6 +1957,12 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 rcs[e] = d < hd ? p.rope[((size_t)cb * (hd >> 1) + (d >> 1)) * 2] : 1.f;
                 rsn[e] = d < hd ? p.rope[((size_t)cb * (hd >> 1) + (d >> 1)) * 2 + 1] : 0.f;
             }
+            EngDrawPre pre{};
+            if (cb >= 1) {
+                sp.cb = cb;
+                sp.noise_off = p.noise_off1 + (long)(cb - 1) * p.noise_cb_stride;
+                pre = eng_draw_pre(sp, atid);
+            }
             for (int li = (pair && cb == 1) ? nL : 0; li < nL; ++li) {
                 const EngLayer l = eng_layer(p.layers, li);
                 if (li > 0) {
@@ -1944,12 +2002,10 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                     eng_gather_x(rl, blog(par), layV, 0, p.V, tag, logS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 57);
                     sub.sync(lane);
                     if (!*dead) {
-                        sp.cb = cb;
-                        sp.noise_off = p.noise_off1 + (long)(cb - 1) * p.noise_cb_stride;
                         const int last = cb == p.ncb - 1;
-                        const int nfv = sp.nf[0];
+                        const int nfv = pre.nfv;
                         EngSampLds S{redbuf, pen_id, pen_val, amv, ami, wcnt, prL, keyL, cut};
-                        const int code = eng_sample_small(sp, logS, S, sub, atid, lane, gw);
+                        const int code = eng_sample_small(sp, pre, logS, S, sub, atid, lane, gw);
                         const int R = p.ncb + 1;
                         if (atid == 0) codes_s[cb] = code;
                         sub.sync(lane);      // the next step's first read of codes_s comes from all four waves

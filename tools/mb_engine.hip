@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
     p.gpart = (unsigned long long*)carve((size_t)n_layer * H * 32 * (hd + 2) * 8);
     p.ctl = (unsigned*)carve(ENG_CTL_WORDS * 4);
     float* xo; CK(hipMalloc(&xo, D * 4)); p.x_out = xo; p.nt = 1;
-    unsigned long long* stamps = (unsigned long long*)zalloc((size_t)nb * n_layer * 16 * 8);
+    unsigned long long* stamps = (unsigned long long*)zalloc((size_t)nb * n_layer * 16 * 8 * 2);
     const size_t lds = 82 * 1024;
     CK(hipFuncSetAttribute((const void*)slow_engine_kernel<2, 4, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipStreamSynchronize(s));
@@ -95,7 +95,7 @@ int main(int argc, char** argv) {
                sum / reps * 1e3 / n_layer, h[ENG_CTL_ABORT] ? "  ABORTED" : "");
         if (h[ENG_CTL_ABORT]) { printf("abort at phase %u\n", h[ENG_CTL_WHERE]); return 1; }
     }
-    std::vector<unsigned long long> st((size_t)nb * n_layer * 16);
+    std::vector<unsigned long long> st((size_t)nb * n_layer * 16 * 2);
     CK(hipMemcpy(st.data(), stamps, st.size() * 8, hipMemcpyDeviceToHost));
     const char* names[13] = {"x gathered", "QKV rows done", "attention section left", "y gathered", "Wo rows done", "x' gathered", "W13 rows done", "g gathered", "W2 rows done", "W2 re-issued (mode 2: Wo granule stores acknowledged)", "gw0: starts polling x'", "gw0: x' pieces seen", "gw0: past barrier B3"};
     for (int b : {0, 100, nb - 1}) {
@@ -132,6 +132,28 @@ int main(int argc, char** argv) {
         }
         printf("chip-wide, us after the last workgroup finished the previous layer (earliest / median / latest workgroup):\n");
         for (int k = 0; k < 13; ++k) printf("   %-24s %7.2f %7.2f %7.2f\n", names[k], lo[k] / cnt / 100.0, md[k] / cnt / 100.0, hi[k] / cnt / 100.0);
+    }
+    {   // the attention turn seen by the workgroups that hold a (kv head, split) role in the layer
+        const char* an[7] = {"turn starts (polls q k v)", "q k v gathered (BA)", "norm + rotation done (BB)", "scores + values done (BC)", "partials published",
+                             "merger: last partials seen", "merger: y published"};
+        double lo[7] = {0}, md[7] = {0}, hi[7] = {0};
+        int cnt = 0;
+        const size_t off = (size_t)nb * n_layer * 16;
+        for (int li = 4; li < n_layer; ++li) {
+            unsigned long long t0 = 0;
+            for (int b = 0; b < nb; ++b) t0 = std::max(t0, st[((size_t)b * n_layer + li - 1) * 16 + 8]);
+            std::vector<unsigned long long> v;
+            for (int k = 0; k < 7; ++k) {
+                v.clear();
+                for (int b = 0; b < nb; ++b) { const unsigned long long x = st[off + ((size_t)b * n_layer + li) * 16 + k]; if (x) v.push_back(x); }
+                if (v.empty()) continue;
+                std::sort(v.begin(), v.end());
+                lo[k] += (double)v[0] - (double)t0; md[k] += (double)v[v.size() / 2] - (double)t0; hi[k] += (double)v.back() - (double)t0;
+            }
+            ++cnt;
+        }
+        printf("attention turn (role workgroups only), same reading:\n");
+        for (int k = 0; k < 7; ++k) printf("   %-28s %7.2f %7.2f %7.2f\n", an[k], lo[k] / cnt / 100.0, md[k] / cnt / 100.0, hi[k] / cnt / 100.0);
     }
     printf("shader clock during the launch: %.2f GHz\n", (double)st[14] / (double)st[15] * 0.1);
     {   // the x' gather of gw0: first-pass round trip, passes needed
