@@ -1193,6 +1193,7 @@ struct FastEngP {
 };
 #define ENG_FSTAMP(k) do { if (p.stamps && tid == 0) p.stamps[(((size_t)b * p.ncb + cb) * nL + li) * 16 + (k)] = eng_rt(); } while (0)
 
+#define ENG_GSTAMP(k) do { if (p.stamps && atid == 0) p.stamps[(((size_t)b * p.ncb + cb) * nL + nL - 1) * 16 + (k)] = eng_rt(); } while (0)
 constexpr int ENG_FQ = 2, ENG_FF = 3, ENG_FO = 1;   // units per compute wave: QKV 8 rows -> 2, W13 12 pairs -> 3, Wo / W2 / head 4 rows -> 1
 
 // barrier among the four gathering waves only (LDS counter, never reset)
@@ -1462,8 +1463,8 @@ struct EngSampLds {
     float* redbuf;   // [8]
     int* pen_id;     // [32]
     float* pen_val;  // [32]
-    float* amv;      // [4]
-    int* ami;        // [4]
+    float* amv;      // [2][4]
+    int* ami;        // [2][4]
     int* wcnt;       // [4]
     float* prL;      // [1024]
     uint32_t* keyL;  // [1024]
@@ -1493,7 +1494,8 @@ __device__ __forceinline__ EngDrawPre eng_draw_pre(const SampP& p, int tid) {
     draw_noise4(p, d.ctl, qrow, 4 * tid, d.nfv, 0, p.V, d.q4);
     return d;
 }
-__device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre& pre, const float* L, const EngSampLds& S, EngSub& sub, int tid, int lane, int wave) {
+__device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre& pre, const float* L, const EngSampLds& S, EngSub& sub, int tid, int lane, int wave,
+                                                unsigned long long* stp = nullptr) {
     const int V = p.V;
     const RowCtl ctl = pre.ctl;
     const int nfv = pre.nfv;
@@ -1527,12 +1529,29 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre
             }
         }
         sub.sync(lane);
-        for (int k = 0; k < npen; ++k) {
-            const int id = S.pen_id[k];
-            if (id >= i0 && id < i0 + 4) {
-                const float nv = S.pen_val[k];
+        if (p.cb != 0) {        // the 16-frame window of one codebook: ids and values as eight 16-byte LDS reads, applied in order
+            int ids[16]; float nvs[16];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (i0 + e == id) l[e] = nv;
+            for (int k = 0; k < 16; k += 4) {
+                const int4 a = *reinterpret_cast<const int4*>(S.pen_id + k);
+                const float4 v = *reinterpret_cast<const float4*>(S.pen_val + k);
+                ids[k] = a.x; ids[k + 1] = a.y; ids[k + 2] = a.z; ids[k + 3] = a.w;
+                nvs[k] = v.x; nvs[k + 1] = v.y; nvs[k + 2] = v.z; nvs[k + 3] = v.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const unsigned d = (unsigned)(ids[k] - i0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (d == (unsigned)e) l[e] = nvs[k];
+            }
+        } else {
+            for (int k = 0; k < npen; ++k) {
+                const int id = S.pen_id[k];
+                if (id >= i0 && id < i0 + 4) {
+                    const float nv = S.pen_val[k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (i0 + e == id) l[e] = nv;
+                }
             }
         }
     }
@@ -1540,19 +1559,24 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (i0 + e == p.im_end) l[e] = -INFINITY;
     }
-    auto block_best = [&](ArgMax a) {
+    int bb_phase = 0;
+    auto block_best = [&](ArgMax a) {       // the per-wave results alternate between two slot sets: one barrier per call
         a = wave_argmax(a);
+        float* av = S.amv + 4 * (bb_phase & 1);
+        int* ai = S.ami + 4 * (bb_phase & 1);
+        ++bb_phase;
+        if (lane == 0) { av[wave] = a.v; ai[wave] = a.i; }
         sub.sync(lane);
-        if (lane == 0) { S.amv[wave] = a.v; S.ami[wave] = a.i; }
-        sub.sync(lane);
-        ArgMax t{S.amv[0], S.ami[0]};
-        for (int w = 1; w < 4; ++w) t = better(t, ArgMax{S.amv[w], S.ami[w]});
+        ArgMax t{av[0], ai[0]};
+#pragma unroll
+        for (int w = 1; w < 4; ++w) t = better(t, ArgMax{av[w], ai[w]});
         return t;
     };
     ArgMax am{-INFINITY, 0x7fffffff};
 #pragma unroll
     for (int e = 0; e < 4; ++e) if (i0 + e < V) am = better(am, ArgMax{l[e], i0 + e});
     am = block_best(am);
+    if (stp && tid == 0) stp[12] = eng_rt();
     const float Lmax = am.v;
     float ex[4], z = 0.f;
 #pragma unroll
@@ -1573,6 +1597,13 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre
     int winner = am.i;
     if (!only_top) {
         sub.sync(lane);
+        const float Tc = fmaxf(ctl.temperature, 1e-5f);
+        const float Mt = round_bf16(Lmax / Tc);
+        float etp[4];           // expf of the tempered logits: needed for the kept ones, formed while wave 0 finds the cut
+        if (wave != 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) etp[e] = expf(round_bf16(l[e] / Tc) - Mt);
+        }
         if (wave == 0) {
             float pr[16];
             uint32_t ky[16];
@@ -1614,11 +1645,14 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre
             if (lane == 0) { S.cut[0] = kstar; S.cut[1] = (uint32_t)nk; S.cut[2] = (uint32_t)all_kept; }
         }
         sub.sync(lane);
+        if (stp && tid == 0) stp[13] = eng_rt();
         const uint32_t kstar = S.cut[0];
         const int nk = (int)S.cut[1];
         const bool all_kept = S.cut[2] != 0;
-        const float Tc = fmaxf(ctl.temperature, 1e-5f);
-        const float Mt = round_bf16(Lmax / Tc);
+        if (wave == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) etp[e] = expf(round_bf16(l[e] / Tc) - Mt);
+        }
         bool mem[4];
         int mine = 0;
 #pragma unroll
@@ -1641,7 +1675,7 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre
         for (int e = 0; e < 4; ++e) {
             keep[e] = (i0 + e) < V && (all_kept || key[e] > kstar || (mem[e] && rank < nk));
             rank += mem[e] ? 1 : 0;
-            et[e] = keep[e] ? expf(round_bf16(l[e] / Tc) - Mt) : 0.f;
+            et[e] = keep[e] ? etp[e] : 0.f;
             z2 += et[e];
         }
         const float Z2 = red_sum(z2);
@@ -1655,13 +1689,12 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre
         }
         winner = block_best(best).i;
     }
-    sub.sync(lane);
-    return winner;
+    return winner;      // every thread of the four waves holds it (no barrier: the LDS scratch is next touched a step later)
 }
 
 // dynamic LDS of fast_engine_kernel (host and harness use this one formula)
 inline size_t eng_fast_lds_bytes(int D, int qkvN, int HD, int F, int V, int nL, int ncb, int KVW, bool pair) {
-    size_t fl = (size_t)D * 2 + qkvN + HD + F + V + ENG_MAX_OUT + 8 + 32 + 32 + 12 + 2048 + 4 + 4 + 16;
+    size_t fl = (size_t)D * 2 + qkvN + HD + F + V + ENG_MAX_OUT + 8 + 32 + 32 + 20 + 2048 + 4 + 4 + 16;
     size_t by = fl * sizeof(float) + (size_t)nL * 2 * ncb * KVW * 2 + 64;
     if (pair) by += ((size_t)2 * D + (size_t)(F > qkvN + HD ? F : qkvN + HD)) * sizeof(float) + 16;
     return by;
@@ -1685,9 +1718,9 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     float* redbuf = outS + ENG_MAX_OUT;        // sampling scratch ...
     int* pen_id = reinterpret_cast<int*>(redbuf + 8);
     float* pen_val = reinterpret_cast<float*>(pen_id + 32);
-    float* amv = pen_val + 32;
-    int* ami = reinterpret_cast<int*>(amv + 4);
-    int* wcnt = ami + 4;
+    float* amv = pen_val + 32;                 // [2][4]
+    int* ami = reinterpret_cast<int*>(amv + 8);   // [2][4]
+    int* wcnt = ami + 8;
     float* prL = reinterpret_cast<float*>(wcnt + 4);
     uint32_t* keyL = reinterpret_cast<uint32_t*>(prL + 1024);
     uint32_t* cut = keyL + 1024;
@@ -1904,6 +1937,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
         // ====================== gathering waves: inputs, attention share, the draws ======================
         EngSub sub{sub_count, 0};
         SampP sp = p.samp;
+        int prev_code = 0;
         eng_barrier();                                                  // (registration results in LDS)
         const EngRelay rl{ENG_RELAY && p.rep_stride != 0, reg_s[1], reg_s[2], p.rep_delta0 + (long)reg_s[0] * p.rep_stride};
         eng_barrier();                                                  // B0
@@ -1972,7 +2006,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                     for (int d = atid * 4; d < D; d += ENG_GW * 64 * 4) *reinterpret_cast<float4*>(xA + d) = *reinterpret_cast<const float4*>(src + d);
                 } else {
                     // the code this workgroup drew in the previous step: that row of the codebook-embedding table
-                    const int code = codes_s[cb - 1];
+                    const int code = prev_code;
                     for (int d = atid * 8; d < D; d += ENG_GW * 64 * 8) {
                         float e8[8];
                         Vec<bf16_t>::unpack(eng_ldg16<false>(p.fast_emb + (size_t)code * D + d), e8);
@@ -1995,20 +2029,24 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
             if (cb >= 1) {
                 eng_gather_x(rl, bx(par, nL), layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 56);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B5
+                ENG_GSTAMP(10);
                 {
                     // ---- the draw of codebook cb (inference.py:134-149).  EVERY workgroup gathers the logits and draws (the
                     // draw is a deterministic function of logits, frame and seed): no hand-off of the code, the next step's
                     // embedding row can be fetched at once.  Workgroup drawer(cb) alone does the frame bookkeeping (finish_draw).
                     eng_gather_x(rl, blog(par), layV, 0, p.V, tag, logS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 57);
                     sub.sync(lane);
+                    ENG_GSTAMP(11);
                     if (!*dead) {
                         const int last = cb == p.ncb - 1;
                         const int nfv = pre.nfv;
                         EngSampLds S{redbuf, pen_id, pen_val, amv, ami, wcnt, prL, keyL, cut};
-                        const int code = eng_sample_small(sp, pre, logS, S, sub, atid, lane, gw);
+                        const int code = eng_sample_small(sp, pre, logS, S, sub, atid, lane, gw,
+                                                          p.stamps ? p.stamps + (((size_t)b * p.ncb + cb) * nL + nL - 1) * 16 : nullptr);
+                        ENG_GSTAMP(14);
                         const int R = p.ncb + 1;
                         if (atid == 0) codes_s[cb] = code;
-                        sub.sync(lane);      // the next step's first read of codes_s comes from all four waves
+                        prev_code = code;    // (every thread holds the drawn code: the next step's embedding row is fetched from it)
                         if (b == drawer(cb)) {
                             if (atid == 0) sp.tokn[cb + 1] = code;
                             if (last) {

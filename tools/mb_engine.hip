@@ -274,5 +274,21 @@ static int run_fast(int nb, hipStream_t s) {
         gap += (double)t1 - (double)t0; ++gc;
     }
     printf("head + draw + code hand-off between two steps: %.2f us\n", gap / gc / 100.0);
+    {   // inside that gap (gathering wave 0): chip-wide medians relative to the last workgroup's W2 of the step
+        const char* dn[5] = {"head input gathered (B5)", "logits gathered", "argmax known", "top-p cut known", "code drawn"};
+        const int dk[5] = {10, 11, 12, 13, 14};
+        double md[5] = {0}, hi2[5] = {0}; int dc = 0;
+        for (int cb = 2; cb < ncb; ++cb) {
+            unsigned long long t0 = 0;
+            for (int b = 0; b < nb; ++b) t0 = std::max(t0, st[(((size_t)b * ncb + cb) * nL + nL - 1) * 16 + 8]);
+            for (int k = 0; k < 5; ++k) {
+                for (int b = 0; b < nb; ++b) v[b] = st[(((size_t)b * ncb + cb) * nL + nL - 1) * 16 + dk[k]];
+                std::sort(v.begin(), v.end());
+                md[k] += (double)v[nb / 2] - (double)t0; hi2[k] += (double)v[nb - 1] - (double)t0;
+            }
+            ++dc;
+        }
+        for (int k = 0; k < 5; ++k) printf("   %-26s %7.2f %7.2f   (median / latest workgroup)\n", dn[k], md[k] / dc / 100.0, hi2[k] / dc / 100.0);
+    }
     return 0;
 }
