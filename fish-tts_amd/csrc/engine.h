@@ -110,6 +110,7 @@ struct ft_ctx {
     unsigned* eng_ctl = nullptr;
     size_t eng_lds_slow = 0, eng_lds_fast = 0, eng_fast_words = 0, eng_pool_words = 0;
     bool eng_relay = true;        // per-XCD replicas of the hand-off buffers (FT_NO_RELAY: every workgroup polls the source)
+    void* eng_qkv0_tab = nullptr;   // fast layer 0's q k v per codebook-embedding row (bf16 [fastV][qkvN])
     bool eng_pair = false;          // fast loop: positions 0 and 1 as two rows of the first pass
 
     std::map<int, hipGraphExec_t> graphs;

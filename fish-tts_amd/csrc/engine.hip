@@ -284,7 +284,7 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     if (ctx->samp_part_score) hipFree(ctx->samp_part_score);
     if (ctx->samp_part_idx) hipFree(ctx->samp_part_idx);
     { void* eb[] = {ctx->eng_layers, ctx->eng_flayers, ctx->eng_gx /* pool: gxb, gg, gy, gqkv live in it */,
-                    ctx->eng_gpart, ctx->eng_fast_g, ctx->eng_ctl}; for (void* q : eb) if (q) hipFree(q); }
+                    ctx->eng_gpart, ctx->eng_fast_g, ctx->eng_ctl, ctx->eng_qkv0_tab}; for (void* q : eb) if (q) hipFree(q); }
     if (ctx->h_pin) hipHostFree(ctx->h_pin);
     for (auto e : ctx->prof_ev) hipEventDestroy(e);
     codec_destroy(ctx);
@@ -503,6 +503,18 @@ static ft_status eng_setup(ft_ctx* ctx) {
     ctx->eng_lds_fast = std::max(ctx->eng_lds_fast, (size_t)82 * 1024);
     FT_HIP(ctx, hipFuncSetAttribute((const void*)fast_engine_kernel<2, 2, 6, 10, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)ctx->eng_lds_fast));
+    // layer 0's q k v of every codebook-embedding row a draw can select (codes < fastV): 4 MB at the s1-mini widths
+    if (getenv("FT_NO_QKV0") == nullptr && c.num_codebooks > 2) {
+        const size_t tb = (size_t)ctx->fastV * fqkvN * sizeof(bf16_t);
+        FT_HIP(ctx, hipMalloc((void**)&ctx->eng_qkv0_tab, tb));
+        const FtLayer& l0 = ctx->flayers[0];
+        const size_t lds = ((size_t)c.fast_dim + ENG_MAX_OUT) * sizeof(float);
+        eng_qkv0_table_kernel<2><<<dim3(fqkvN / (ENG_FQ * ENG_CW), 16), ENG_CW * 64, lds, ctx->stream>>>(
+            (const bf16_t*)l0.wqkv, (const bf16_t*)l0.bqkv, (const bf16_t*)l0.attn_norm, (const bf16_t*)ctx->fast_emb,
+            (bf16_t*)ctx->eng_qkv0_tab, c.fast_dim, fqkvN, ctx->fastV, c.norm_eps);
+        FT_HIP(ctx, hipGetLastError());
+        FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ctx->eng_fast_on = true;
     return FT_OK;
 }
@@ -570,6 +582,7 @@ static void enqueue_fast_engine(Launch& L) {
     p.eps = c.norm_eps; p.scale = (float)(1.0 / sqrt((double)c.fast_head_dim));
     p.rope = ctx->frope; p.fast_norm = (const bf16_t*)ctx->fast_norm; p.fast_out = (const bf16_t*)ctx->fast_out;
     p.fast_emb = (const bf16_t*)ctx->fast_emb;
+    p.qkv0_tab = (const bf16_t*)ctx->eng_qkv0_tab;
     p.hid = ctx->hid + (size_t)m0 * c.fast_dim; p.femb = ctx->femb + (size_t)m0 * c.fast_dim;
     unsigned* g = ctx->eng_fast_g;
     p.gx = g; g += 2 * (nLf + 1) * VW;

@@ -1189,6 +1189,8 @@ struct FastEngP {
     long noise_cb_stride;         // fastV
     long noise_off1;              // offset of codebook 1's noise in a row (vocab_size)
     int pair;                     // 1: codebook positions 0 and 1 (both inputs known at launch) run as two rows of ONE pass
+    const bf16_t* qkv0_tab;       // [V][qkvN] bf16 or nullptr: layer 0's q k v of every codebook-embedding row (eng_qkv0_table_kernel):
+                                  // from position 2 on the layer-0 input is one of V table rows, so its QKV phase and hand-off are a lookup
     unsigned long long* stamps;   // diagnostic builds only (tools/mb_engine.hip): [workgroup][step][layer][16] ticks, or nullptr
 };
 #define ENG_FSTAMP(k) do { if (p.stamps && tid == 0) p.stamps[(((size_t)b * p.ncb + cb) * nL + li) * 16 + (k)] = eng_rt(); } while (0)
@@ -1692,6 +1694,37 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre
     return winner;      // every thread of the four waves holds it (no barrier: the LDS scratch is next touched a step later)
 }
 
+// q k v of fast layer 0 for every row of the codebook-embedding table, with the fast engine's own phase code (same
+// loads, eng_gemv_rows, same rounding): grid (qkvN / (ENG_FQ * ENG_CW), code chunks), 256 threads.
+template <int NTD>
+__global__ __launch_bounds__(ENG_CW * 64) void eng_qkv0_table_kernel(const bf16_t* wqkv, const bf16_t* bqkv, const bf16_t* attn_norm,
+                                                                      const bf16_t* fast_emb, bf16_t* tab, int D, int qkvN, int ncodes,
+                                                                      float eps) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;            // [D]
+    float* vals = xs + D;        // [ENG_MAX_OUT]
+    const int tid = threadIdx.x, lane = tid & 63, cw = tid >> 6;
+    int q_lo, q_hi;
+    eng_units(qkvN, blockIdx.x, gridDim.x, q_lo, q_hi);
+    EngW<NTD, 1, ENG_FQ> wq;
+    eng_issue<false>(wq, wqkv, attn_norm, D, q_lo, q_hi, cw, lane, 0);
+    const int per = (ncodes + gridDim.y - 1) / gridDim.y;
+    const int c_lo = blockIdx.y * per, c_hi = min(c_lo + per, ncodes);
+    for (int code = c_lo; code < c_hi; ++code) {
+        for (int d = tid * 8; d < D; d += ENG_CW * 64 * 8) {
+            float e8[8];
+            Vec<bf16_t>::unpack(eng_ldg16<false>(fast_emb + (size_t)code * D + d), e8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xs[d + j] = e8[j];
+        }
+        __syncthreads();
+        eng_gemv_rows<NTD, 1, ENG_FQ, PRO_RMSNORM, EPI_STORE>(wq, xs, D, eps, bqkv, nullptr, vals, q_lo, q_hi, cw, lane);
+        __syncthreads();
+        if (tid < q_hi - q_lo) tab[(size_t)code * qkvN + q_lo + tid] = f32_to_bf16_bits(vals[tid]);
+        __syncthreads();
+    }
+}
+
 // dynamic LDS of fast_engine_kernel (host and harness use this one formula)
 inline size_t eng_fast_lds_bytes(int D, int qkvN, int HD, int F, int V, int nL, int ncb, int KVW, bool pair) {
     size_t fl = (size_t)D * 2 + qkvN + HD + F + V + ENG_MAX_OUT + 8 + 32 + 32 + 20 + 2048 + 4 + 4 + 16;
@@ -1815,7 +1848,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                                                               bq(1, li) + eng_pub(b, q_lo), tag0, tag1, q_lo, q_hi, cw, lane, eo);
                 __builtin_amdgcn_sched_barrier(0);
                 ENG_FSTAMP(1);
-                if (more) eng_issue<false>(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, 0);
+                if (more && !(li == nL - 1 && p.qkv0_tab != nullptr)) eng_issue<false>(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b: qkvS, qkvS1
                 ENG_FSTAMP(2);
@@ -1881,17 +1914,20 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 rcs[e] = d < hd ? p.rope[((size_t)cb * (hd >> 1) + (d >> 1)) * 2] : 1.f;
                 rsn[e] = d < hd ? p.rope[((size_t)cb * (hd >> 1) + (d >> 1)) * 2 + 1] : 0.f;
             }
+            const bool tab0 = p.qkv0_tab != nullptr && cb >= 2;
             for (int li = 0; li < nL; ++li) {
                 const EngLayer l = eng_layer(p.layers, li);
                 const bool more = !(cb == p.ncb - 1 && li == nL - 1);
                 const EngLayer ln = eng_layer(p.layers, li + 1 < nL ? li + 1 : 0);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1: xA
                 ENG_FSTAMP(0);
-                eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, bq(par, li) + eng_pub(b, q_lo), tag,
-                                                             nullptr, q_lo, q_hi, cw, lane, eo);
+                if (!(li == 0 && tab0))      // (table steps: q k v of layer 0 were looked up by the gathering waves)
+                    eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, bq(par, li) + eng_pub(b, q_lo), tag,
+                                                                 nullptr, q_lo, q_hi, cw, lane, eo);
                 __builtin_amdgcn_sched_barrier(0);
                 ENG_FSTAMP(1);
-                if (more) eng_issue<false>(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, 0);
+                if (more && !(li == nL - 1 && p.qkv0_tab != nullptr && cb + 1 >= 2))
+                    eng_issue<false>(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b: qkvS
                 ENG_FSTAMP(2);
@@ -2007,15 +2043,43 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 } else {
                     // the code this workgroup drew in the previous step: that row of the codebook-embedding table
                     const int code = prev_code;
-                    for (int d = atid * 8; d < D; d += ENG_GW * 64 * 8) {
-                        float e8[8];
-                        Vec<bf16_t>::unpack(eng_ldg16<false>(p.fast_emb + (size_t)code * D + d), e8);
+                    const int d0 = atid * 8;
+                    if (p.qkv0_tab && D <= ENG_GW * 64 * 8 && p.qkvN <= ENG_GW * 64 * 8) {
+                        // the embedding row and layer 0's q k v of that row (a lookup instead of a phase and a hand-off):
+                        // both loads in flight together
+                        const U4 ue = eng_ldg16<false>(p.fast_emb + (size_t)code * D + (d0 < D ? d0 : 0));
+                        const U4 uq = eng_ldg16<false>(p.qkv0_tab + (size_t)code * p.qkvN + (d0 < p.qkvN ? d0 : 0));
+                        float e8[8], q8[8];
+                        Vec<bf16_t>::unpack(ue, e8);
+                        Vec<bf16_t>::unpack(uq, q8);
+                        if (d0 < D) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) xA[d + j] = e8[j];
+                            for (int j = 0; j < 8; ++j) xA[d0 + j] = e8[j];
+                        }
+                        if (d0 < p.qkvN) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) qkvS[d0 + j] = q8[j];
+                        }
+                    } else {
+                        for (int d = d0; d < D; d += ENG_GW * 64 * 8) {
+                            float e8[8];
+                            Vec<bf16_t>::unpack(eng_ldg16<false>(p.fast_emb + (size_t)code * D + d), e8);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) xA[d + j] = e8[j];
+                        }
+                        if (p.qkv0_tab) {
+                            for (int d = d0; d < p.qkvN; d += ENG_GW * 64 * 8) {
+                                float e8[8];
+                                Vec<bf16_t>::unpack(eng_ldg16<false>(p.qkv0_tab + (size_t)code * p.qkvN + d), e8);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) qkvS[d + j] = e8[j];
+                            }
+                        }
                     }
                 }
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1
-                eng_gather_x(rl, bq(par, li), layQ, 0, p.qkvN, tag, qkvS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 1);
+                if (!(li == 0 && cb >= 2 && p.qkv0_tab))
+                    eng_gather_x(rl, bq(par, li), layQ, 0, p.qkvN, tag, qkvS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 1);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b
                 eng_fast_attn_any<MAXCB, HDIM>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
                                          rcs, rsn, cb, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);

@@ -209,6 +209,15 @@ static int run_fast(int nb, hipStream_t s) {
     p.samp = sp; p.noise_cb_stride = V; p.noise_off1 = 8192;
     unsigned long long* stamps = (unsigned long long*)zalloc((size_t)nb * ncb * nL * 16 * 8);
     p.pair = getenv("NO_PAIR") ? 0 : 1;
+    p.qkv0_tab = nullptr;
+    if (!getenv("NO_QKV0")) {
+        bf16_t* tab; CK(hipMalloc(&tab, (size_t)V * qkvN * 2));
+        const EngLayer l0 = hl[0];
+        eng_qkv0_table_kernel<2><<<dim3(qkvN / (ENG_FQ * ENG_CW), 16), ENG_CW * 64, ((size_t)D + ENG_MAX_OUT) * 4, s>>>(
+            l0.wqkv, l0.bqkv, l0.attn_norm, p.fast_emb, tab, D, qkvN, V, p.eps);
+        CK(hipGetLastError()); CK(hipStreamSynchronize(s));
+        p.qkv0_tab = tab;
+    }
     size_t ldsb = eng_fast_lds_bytes(D, qkvN, HD, F, V, nL, ncb, Hkv * hd, p.pair != 0);
     printf("paired first pass: %d, LDS %zu bytes\n", p.pair, ldsb);
     CK(hipFuncSetAttribute((const void*)fast_engine_kernel<2, 2, 6, 10, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
