@@ -1466,6 +1466,7 @@ struct SampBigP {
     SampP s;
     unsigned* hist;      // [M][65536 + 1024]: class counts, then counts per group of 64 classes
     SampCut* cut;        // [M]
+    unsigned* ticket;    // [M] arrival counter of samp_cut_fused_kernel (zero between launches)
     int* chunk_cnt;      // [M][nchunk]
     float* part_score;   // [M][nchunk]
     int* part_idx;       // [M][nchunk]
@@ -1680,13 +1681,18 @@ __device__ __forceinline__ void samp_cut_from_image(const SampBigP& b, const int
     }
 }
 
-static __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cimg[];
-    __shared__ SampThShared sh;
-    const SampP& p = b.s;
-    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const RowCtl ctl = p.ctl[m];
+// Builds the LDS image of row m's class histogram from the replicated global counters (and clears them), then runs the
+// cut search.  COH: the counters were filled by atomics of blocks of THIS launch (samp_cut_fused_kernel), so they are
+// read with agent-scope loads (past this XCD's L2, which may hold last frame's lines); the clearing stores reach memory at
+// the end of the kernel either way.
+template <bool COH>
+__device__ __forceinline__ void samp_threshold_body(const SampBigP& b, const int m, uint32_t* cimg, SampThShared& sh) {
+    const int tid = threadIdx.x;
     unsigned* hist0 = b.hist + (size_t)m * SAMP_HIST_STRIDE;
+    auto ld = [&](const unsigned* q) -> unsigned {
+        if (COH) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return *q;
+    };
     if (tid == 0) sh.ovf_n = 0;
     __syncthreads();
     // ---- stage: thread t owns group t (classes [64 t, 64 t + 64)); replicas are summed, then cleared
@@ -1695,7 +1701,7 @@ static __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b)
     unsigned gtot = 0;
     unsigned gr[SAMP_REP];
 #pragma unroll
-    for (int r = 0; r < SAMP_REP; ++r) { gr[r] = hist0[(size_t)r * SAMP_REP_STRIDE + 65536 + tid]; gtot += gr[r]; }
+    for (int r = 0; r < SAMP_REP; ++r) { gr[r] = ld(hist0 + (size_t)r * SAMP_REP_STRIDE + 65536 + tid); gtot += gr[r]; }
     const bool has = gtot != 0u;
     if (has) {
 #pragma unroll
@@ -1709,9 +1715,24 @@ static __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b)
                     unsigned* hr = hist0 + (size_t)r * SAMP_REP_STRIDE;
                     if (half == 1) hr[65536 + tid] = 0u;
                     U4* h4 = reinterpret_cast<U4*>(hr + 64 * tid + 32 * half);
+                    U4 q8[8];
+                    if (COH) {
+                        // eight 16-byte loads past the L2 in flight together (one agent-scope atomic load per counter
+                        // is a full memory round trip each: 512 of them in a row per active group cost 135 us)
+                        asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+                                     "global_load_dwordx4 %2, %8, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
+                                     "global_load_dwordx4 %4, %8, off offset:64 sc1\n\tglobal_load_dwordx4 %5, %8, off offset:80 sc1\n\t"
+                                     "global_load_dwordx4 %6, %8, off offset:96 sc1\n\tglobal_load_dwordx4 %7, %8, off offset:112 sc1\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(q8[0]), "=&v"(q8[1]), "=&v"(q8[2]), "=&v"(q8[3]), "=&v"(q8[4]), "=&v"(q8[5]), "=&v"(q8[6]), "=&v"(q8[7])
+                                     : "v"(h4) : "memory");
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) q8[v] = h4[v];
+                    }
 #pragma unroll
                     for (int v = 0; v < 8; ++v) {
-                        const U4 q = h4[v];
+                        const U4 q = q8[v];
                         h4[v] = U4{0u, 0u, 0u, 0u};
                         cs[4 * v] += q.x; cs[4 * v + 1] += q.y; cs[4 * v + 2] += q.z; cs[4 * v + 3] += q.w;
                     }
@@ -1730,6 +1751,89 @@ static __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b)
         }
     }
     samp_cut_from_image(b, m, cimg, sh, has, kmax_t);
+}
+
+static __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cimg[];
+    __shared__ SampThShared sh;
+    samp_threshold_body<false>(b, blockIdx.x, cimg, sh);
+}
+
+// samp_hist_kernel and samp_threshold_kernel as ONE launch: blocks of 1024 threads count 4096 logits each into the
+// replicated global histogram (one atomic per distinct class and wave); the block whose ticket comes last builds the
+// image and searches the cut.  The single-block samp_cut_kernel spends ~30 of its 40 us walking the 155 776 logits of
+// the vocabulary row with LDS atomics on one CU; here 39 CUs do that part.
+static __global__ __launch_bounds__(1024) void samp_cut_fused_kernel(SampBigP b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cimg[];
+    __shared__ SampThShared sh;
+    __shared__ int pen_id[32];
+    __shared__ float pen_val[32];
+    __shared__ int is_last;
+    unsigned* grp_s = cimg;       // [1024] group counts of this block (the image is built later, by the last block only)
+    const SampP& p = b.s;
+    const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int c0 = blockIdx.x * 4096;
+    float* L = p.logits + (size_t)m * p.ldl;
+    const int V = p.V;
+    const RowCtl ctl = p.ctl[m];
+    const int nfv = p.nf[m];
+    const int R = p.ncb + 1;
+    const int* seq = p.seq + (size_t)m * R * p.cap;
+    if (nfv > 0) {
+        const int it = nfv - 1;
+        const int ws = it < 16 ? 0 : it - 16;
+        const int npen = p.cb == 0 ? R : 16;
+        if (tid < npen) {
+            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
+            pen_id[tid] = -1;
+            if (id >= c0 && id < c0 + 4096 && id < V) {
+                const float sv = L[id];
+                pen_id[tid] = id;
+                pen_val[tid] = sv < 0.f ? round_bf16(sv * ctl.rep) : round_bf16(sv / ctl.rep);
+            }
+        }
+        __syncthreads();
+        if (tid < npen && pen_id[tid] >= 0) L[pen_id[tid]] = pen_val[tid];
+    }
+    if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end >= c0 && p.im_end < c0 + 4096 && p.im_end < V)
+        L[p.im_end] = -INFINITY;
+    grp_s[tid] = 0u;
+    __syncthreads();
+    unsigned* hist = b.hist + (size_t)m * SAMP_HIST_STRIDE + (size_t)(blockIdx.x % SAMP_REP) * SAMP_REP_STRIDE;
+    unsigned* grp = hist + 65536;
+    float lv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int i = c0 + e * 1024 + tid; lv[e] = i < V ? L[i] : 0.f; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = c0 + e * 1024 + tid;
+        const bool valid = i < V;
+        const unsigned k = valid ? order_key(lv[e]) >> 16 : 0u;
+        unsigned long long active = __ballot(valid);
+        while (active) {
+            const int leader = __ffsll((long long)active) - 1;
+            const unsigned kk = (unsigned)__builtin_amdgcn_readlane((int)k, leader);
+            const unsigned long long same = __ballot(valid && k == kk);
+            if (lane == leader) {
+                const unsigned n = (unsigned)__popcll(same);
+                atomicAdd(&hist[kk], n);
+                atomicAdd(&grp_s[kk >> 6], n);
+            }
+            active &= ~same;
+        }
+    }
+    __syncthreads();
+    { const unsigned n = grp_s[tid]; if (n) atomicAdd(&grp[tid], n); }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = atomicAdd(&b.ticket[m], 1u);
+        is_last = t == gridDim.x - 1 ? 1 : 0;
+        if (is_last) __hip_atomic_store(&b.ticket[m], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    samp_threshold_body<true>(b, m, cimg, sh);
 }
 
 // Histogram and cut search of one row in ONE block: the 65 536 class counters live in LDS as packed u16 pairs (the

@@ -91,6 +91,7 @@ struct ft_ctx {
 
     // large-vocabulary sampler scratch
     unsigned* samp_hist = nullptr;
+    unsigned* samp_ticket = nullptr;
     ft::SampCut* samp_cut = nullptr;
     int* samp_chunk_cnt = nullptr;
     float* samp_part_score = nullptr;

@@ -210,6 +210,8 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     }
     const size_t nchunk = ((size_t)c.vocab_size + 1023) / 1024;
     FT_TRY(dmalloc(ctx, &ctx->samp_hist, M * SAMP_HIST_STRIDE));
+    FT_TRY(dmalloc(ctx, &ctx->samp_ticket, M));
+    FT_HIP(ctx, hipMemset(ctx->samp_ticket, 0, M * sizeof(unsigned)));
     FT_TRY(dmalloc(ctx, &ctx->samp_cut, M));
     FT_TRY(dmalloc(ctx, &ctx->samp_chunk_cnt, M * nchunk));
     FT_TRY(dmalloc(ctx, &ctx->samp_part_score, M * nchunk));
@@ -279,6 +281,7 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g, ctx->mb_xn, ctx->mb_ybf, ctx->mb_g, ctx->mb_xb, ctx->mb_ss, ctx->pf_qbf}; for (void* q : pf) if (q) hipFree(q); }
     for (auto& l : ctx->layers) { if (l.bqkv_f32) hipFree(l.bqkv_f32); if (l.bo_f32) hipFree(l.bo_f32); }
     if (ctx->samp_hist) hipFree(ctx->samp_hist);
+    if (ctx->samp_ticket) hipFree(ctx->samp_ticket);
     if (ctx->samp_cut) hipFree(ctx->samp_cut);
     if (ctx->samp_chunk_cnt) hipFree(ctx->samp_chunk_cnt);
     if (ctx->samp_part_score) hipFree(ctx->samp_part_score);
@@ -915,6 +918,7 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
         SampBigP b{};
         b.s = s; b.nchunk = (s.V + 1023) / 1024;
         b.hist = ctx->samp_hist + (size_t)m0 * SAMP_HIST_STRIDE; b.cut = ctx->samp_cut + m0;
+        b.ticket = ctx->samp_ticket + m0;
         b.chunk_cnt = ctx->samp_chunk_cnt + (size_t)m0 * b.nchunk;
         b.part_score = ctx->samp_part_score + (size_t)m0 * b.nchunk;
         b.part_idx = ctx->samp_part_idx + (size_t)m0 * b.nchunk;
@@ -926,12 +930,20 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
                                     (int)SAMP_TH_LDS);
                 hipFuncSetAttribute((const void*)samp_cut_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)SAMP_TH_LDS);
+                hipFuncSetAttribute((const void*)samp_cut_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)SAMP_TH_LDS);
             });
         }
         // histogram + cut search of a row in one block (LDS counters); FT_SAMPLER_GLOBAL_HIST selects the first
         // implementation (global-atomic histogram, then the cut search on its read-back)
         const bool global_hist = getenv("FT_SAMPLER_GLOBAL_HIST") != nullptr;   // read per enqueue: tests toggle it
-        if (!global_hist) {
+        // FT_SAMPLER_FUSED: the histogram part spread over ceil(V / 4096) blocks, the cut search in the block that arrives
+        // last (same image, same search).  Measured SLOWER than the one-block kernel (75 vs 40 us per draw: global atomics
+        // and the ticket round trip cost more than 38 more CUs save), so it is not the default; kept with its test.
+        const bool fused = !global_hist && getenv("FT_SAMPLER_FUSED") != nullptr;
+        if (fused) {
+            samp_cut_fused_kernel<<<dim3((s.V + 4095) / 4096, L.M), SAMP_TH_THREADS, SAMP_TH_LDS, L.s>>>(b);
+        } else if (!global_hist) {
             samp_cut_kernel<<<L.M, SAMP_TH_THREADS, SAMP_TH_LDS, L.s>>>(b);
         } else {
             samp_hist_kernel<<<gridc, 256, 0, L.s>>>(b);

@@ -523,11 +523,15 @@ def test_large_vocabulary_sampler_vs_oracle(monkeypatch):
             want = O.sample(logits.clone()[None, None], torch.tensor(temp), torch.tensor(tp), torch.tensor(rep),
                             window[:, 0], noise=lambda p: q.to(p.dtype))[0].item()
             cases.append((logits, window, q, tp, temp, rep, want))
-    for mode in ("lds", "global"):
+    # "lds" (the default): everything in one block; "fused": histogram spread over ceil(V / 4096) blocks, cut search in the
+    # last-arriving one (measured slower, opt-in); "global": the two-launch form
+    for mode in ("lds", "fused", "global"):
+        monkeypatch.delenv("FT_SAMPLER_GLOBAL_HIST", raising=False)
+        monkeypatch.delenv("FT_SAMPLER_FUSED", raising=False)
         if mode == "global":
             monkeypatch.setenv("FT_SAMPLER_GLOBAL_HIST", "1")
-        else:
-            monkeypatch.delenv("FT_SAMPLER_GLOBAL_HIST", raising=False)
+        elif mode == "fused":
+            monkeypatch.setenv("FT_SAMPLER_FUSED", "1")
         eng, _ = make_pair(shape, "bf16")
         bad = []
         for ci, (logits, window, q, tp, temp, rep, want) in enumerate(cases):
