@@ -317,9 +317,15 @@ def _rms(x, w, eps):
 
 
 class CodecOracle:
-    def __init__(self, shape: CodecShape, weights: Dict[str, torch.Tensor]):
+    def __init__(self, shape: CodecShape, weights: Dict[str, torch.Tensor], dtype: torch.dtype = torch.float32):
+        """dtype=torch.bfloat16 restates the precision the reference ENCODES in (synthesizer.py:289-291, 345-353: the
+        codec is moved to bfloat16 on the accelerator, the audio is cast to the model's dtype): every parameter and every
+        activation is bf16, each torch op rounds its result once - the like-for-like partner of the HIP encode path
+        (bf16 operands, f32 accumulation, bf16 activations).  The decode oracle stays f32 (vocoder.py:906-912 as used by
+        the synthesizer's f32 decode)."""
         self.c = shape
-        self.w = {k: v.float() for k, v in weights.items()}
+        self.dtype = dtype
+        self.w = {k: v.float().to(dtype) for k, v in weights.items()}
         self.tab = rope_table(shape.tf_block_size, shape.tf_head_dim, shape.tf_rope_base)
         self.taps: Dict[str, torch.Tensor] = {}
 
@@ -428,7 +434,7 @@ class CodecOracle:
         audio = F.pad(audio, (0, right))
         if audio_lengths is None:
             audio_lengths = torch.tensor([length + right])
-        z = self.encoder(audio.float())
+        z = self.encoder(audio.float().to(self.dtype))
         self.taps["enc_out"] = z
         return self.quantizer_encode(z), torch.ceil(audio_lengths / fl).long()
 

@@ -60,3 +60,35 @@ def test_codec_oracle_encode_matches_reference():
         assert np.array_equal(lens.numpy(), gold[f"{name}.indices_lens"]), name
         back, _ = orc.decode(idx, lens)
         assert np.allclose(back.numpy(), gold[f"{name}.roundtrip"], atol=1e-5), name
+
+
+def test_codec_oracle_bf16_encode_mode_stays_close_to_f32():
+    """oracle/codec.py's bf16 mode (the precision the reference encodes in, synthesizer.py:289-291): same algorithm, every
+    tensor bf16.  Against the f32 oracle on the same audio most indices agree and the rebuilt latents stay close; shapes,
+    lengths and index ranges are those of the f32 path.  (Parity of this mode with the reference's bf16 encode is
+    unpinned: the reference's fixtures hold no bf16 encode output; the f32 path is pinned by
+    test_codec_oracle_encode_matches_reference.)"""
+    import numpy as np
+    import torch
+    from oracle import codec as C
+    shape = C.CodecShape(n_codebooks=3, codebook_size=64, semantic_codebook_size=128, codebook_dim=8, latent_dim=512,
+                         n_tf_layer=2, tf_n_head=8, tf_head_dim=64, tf_ffn=768, tf_window=8, tf_block_size=256,
+                         upsample=[2, 2], decoder_dim=128, rates=[4, 4], encoder_dim=32, encoder_rates=[2, 2, 2, 2],
+                         encoder_tf_layers=[0, 0, 1, 1], enc_tf_window=16, enc_tf_block_size=1024)
+    w = C.random_weights(shape, seed=0)
+    w.update(C.random_encoder_weights(shape, seed=1))
+    g = torch.Generator().manual_seed(5)
+    n = 37 * shape.enc_frame_len - 11
+    t = torch.arange(n).float()
+    audio = (0.4 * torch.sin(2 * np.pi * t / 37.0) + 0.2 * torch.randn(n, generator=g))[None, None]
+    o32, o16 = C.CodecOracle(shape, w), C.CodecOracle(shape, w, dtype=torch.bfloat16)
+    a, la = o32.encode(audio, torch.tensor([n]))
+    b, lb = o16.encode(audio, torch.tensor([n]))
+    assert a.shape == b.shape and torch.equal(la, lb) and b.dtype == torch.int64
+    assert int(b[:, 0].max()) < shape.semantic_codebook_size and int(b[:, 1:].max()) < shape.codebook_size and int(b.min()) >= 0
+    assert float((a[0, 0] == b[0, 0]).float().mean()) >= 0.8
+    o32.quantizer_decode(a)
+    za = o32.taps["rvq"].clone()
+    o32.quantizer_decode(b)
+    zb = o32.taps["rvq"]
+    assert float((za - zb).pow(2).mean().sqrt() / za.pow(2).mean().sqrt()) <= 0.5
