@@ -524,6 +524,16 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
     int halo = 0;
     for (int i = 0; i < w.ntap; ++i) halo = std::max(halo, -w.offs[i]);
     static const bool legacy = getenv("FT_CODEC_GEMM_V0") != nullptr;
+    // few rows (the 215-frame transformers, the first up-sampling stage): a 64x64 tile grid leaves most CUs idle and every
+    // block walks all of K alone (20-75 us per GEMM); the skinny kernel cuts N into 16-row blocks and splits K over the
+    // waves of a block (weights streamed once per 64 rows)
+    static const long skinny_m = getenv("FT_CODEC_SKINNY_M") ? atol(getenv("FT_CODEC_SKINNY_M")) : 512;
+    if (!legacy && w.ntap == 1 && w.offs[0] == 0 && io.M <= skinny_m && io.T_in >= io.M && w.K % 128 == 0 && w.N % 2 == 0 &&
+        (io.act == ACT_NONE || io.act == ACT_SWIGLU || io.act == ACT_GELU) && !io.out_act) {
+        p.ldw = 0;
+        skinny_gemm_launch<4>(p, (io.M + 63) / 64, st);
+        return;
+    }
     if (w.K % 32 == 0 && halo <= 56 && !legacy) {  // pipelined kernel: A stripe shared by the taps, B double-buffered
 #define FT_TG(BM_, BN_, BK_)                                                                                   \
     tapgemm64_kernel<BM_, BN_, BK_><<<dim3((io.M + BM_ - 1) / BM_, (w.N + BN_ - 1) / BN_, 1), 256,              \

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashP p) {
 // fragments go straight from global memory into the MFMA operand registers (each lane's 16 bytes are one operand),
 // the four partial tiles meet in LDS and are summed in wave order (deterministic).  Epilogue = the nn.Linear
 // rounding points of the prefill (bias, rounded; residual add, rounded; SwiGLU on interleaved (gate, up) rows).
-// Requires K % 128 == 0; act in {ACT_NONE, ACT_SWIGLU}; ntap == 1.
+// Requires K % 128 == 0; act in {ACT_NONE, ACT_GELU, ACT_SWIGLU}; ntap == 1; one batch item (b = 0).
 // XLDS: the X rows reach the MFMA operand registers through a per-wave LDS patch - loaded in full 256-byte row pieces
 // (4 rows per load instruction) and re-read fragment-shaped with ds_read_b128 - instead of 16 rows x 64 bytes per load
 // instruction straight from L2 (the per-CU address path was the limit of that form: tools/mb_skinny.hip).
@@ -712,7 +712,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(TapGemmP p) {
                 for (int w = 1; w < NW; ++w) v += Cs[w][row][c];
                 if (p.bias) v += p.bias[n % p.n_mod];
                 if (p.round_lin) v = round_bf16(v);
+                if (p.act == ACT_GELU) v = gelu_f(v);                       // (codec: ConvNeXt pwconv1)
+                if (p.gamma) v *= p.gamma[n % p.n_mod];                     // (codec: LayerScale / ConvNeXt gamma)
                 if (p.resid_f32) v += p.resid_f32[(size_t)t * p.ldr + n];
+                if (p.resid_bf) v += bf16_bits_to_f32(p.resid_bf[(size_t)t * p.ldr + n]);
                 const size_t oi = (size_t)t * p.ldo + n;
                 stored = p.round_f32_out ? round_bf16(v) : v;
                 if (p.out_f32) p.out_f32[oi] = stored;
