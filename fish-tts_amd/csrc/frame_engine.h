@@ -133,6 +133,67 @@ __device__ __forceinline__ void eng_ld3_sc1(const void* p0, const void* p1, cons
 __device__ __forceinline__ void eng_ld1_sc1(const void* p0, U4& a) {
     asm volatile("global_load_dwordx4 %0, %1, off " ENG_POLL_BITS "\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(p0) : "memory");
 }
+// One 16-byte piece per lane polled with TWO loads in flight, the second issued half a round trip after the first, so
+// memory is sampled every RTT/2 instead of every RTT (the delay between the data landing and a poll returning it is
+// RTT/2 + (sampling period)/2 on average).  The whole loop is one asm statement: the compiler never sees a register
+// whose load is still in flight.  Returns true when every lane's four granules carry `tag` (data in a); false after
+// `iters` rounds (the caller checks its clock and comes back).  Loads issued earlier by this wave return first
+// (vmcnt is in order), so the counted waits hold whatever else is outstanding.
+#ifndef ENG_STAGGER
+#define ENG_STAGGER 1
+#endif
+#ifndef ENG_STAGGER_SLEEP
+#define ENG_STAGGER_SLEEP 6       // x 64 cycles: ~half a memory-side poll round trip
+#endif
+#define ENG_STR2(x) #x
+#define ENG_STR(x) ENG_STR2(x)
+__device__ __forceinline__ bool eng_poll1_stagger(const void* p, unsigned tag, U4& a, int iters) {
+    // fixed registers v240-v249 inside the statement (inline asm cannot name the dwords of a 128-bit operand)
+    unsigned a0, a1, a2, a3;
+    int ok;
+    const unsigned tagw = tag << 16;
+#define ENG_CHK(r0, r1, r2, r3)                                                                                     \
+        "v_xor_b32 v248, " r0 ", %7\n\tv_xor_b32 v249, " r1 ", %7\n\tv_or_b32 v248, v248, v249\n\t"              \
+        "v_xor_b32 v249, " r2 ", %7\n\tv_or_b32 v248, v248, v249\n\tv_xor_b32 v249, " r3 ", %7\n\t"              \
+        "v_or_b32 v248, v248, v249\n\tv_cmp_lt_u32 vcc, 0xffff, v248\n\t"
+    asm volatile(
+        "global_load_dwordx4 v[240:243], %6, off " ENG_POLL_BITS "\n\t"
+        "s_sleep " ENG_STR(ENG_STAGGER_SLEEP) "\n\t"
+        "global_load_dwordx4 v[244:247], %6, off " ENG_POLL_BITS "\n\t"
+        "1:\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        ENG_CHK("v240", "v241", "v242", "v243")
+        "s_cbranch_vccz 2f\n\t"
+        "global_load_dwordx4 v[240:243], %6, off " ENG_POLL_BITS "\n\t"
+        "s_waitcnt vmcnt(1)\n\t"
+        ENG_CHK("v244", "v245", "v246", "v247")
+        "s_cbranch_vccz 3f\n\t"
+        "global_load_dwordx4 v[244:247], %6, off " ENG_POLL_BITS "\n\t"
+        "s_sub_u32 %5, %5, 1\n\t"
+        "s_cmp_lg_u32 %5, 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b32 %4, 0\n\t"
+        "s_branch 4f\n\t"
+        "3:\n\t"                       // b holds the data; the re-issued a is still in flight
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_mov_b32 %0, v244\n\tv_mov_b32 %1, v245\n\tv_mov_b32 %2, v246\n\tv_mov_b32 %3, v247\n\t"
+        "s_mov_b32 %4, 1\n\t"
+        "s_branch 5f\n\t"
+        "2:\n\t"                       // a holds the data; b is still in flight
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b32 %4, 1\n\t"
+        "4:\n\t"
+        "v_mov_b32 %0, v240\n\tv_mov_b32 %1, v241\n\tv_mov_b32 %2, v242\n\tv_mov_b32 %3, v243\n\t"
+        "5:\n\t"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&s"(ok), "+s"(iters)
+        : "v"(p), "v"(tagw)
+        : "memory", "vcc", "scc", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249");
+#undef ENG_CHK
+    a.x = a0; a.y = a1; a.z = a2; a.w = a3;
+    return ok != 0;
+}
+
 __device__ __forceinline__ bool eng_tags_ok(const U4& v, unsigned tag) {
     return (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
 }
@@ -270,11 +331,19 @@ __device__ __forceinline__ void eng_gather_x(const EngRelay& rl, const unsigned*
         const int o = lay.off(u0 + i);
         EngSpin sp{ctl, dead, 0, 0, where};
         U4 a;
+#if ENG_STAGGER
+        for (;;) {
+            if (eng_poll1_stagger(g + o, tag, a, 128)) break;
+            sp.spins |= 255u;                           // (a round of 128 double polls: look at the clock now)
+            if (sp.give_up(lane)) return;
+        }
+#else
         for (;;) {
             eng_ld1_sc1(g + o, a);
             if (__all(eng_tags_ok(a, tag))) break;
             if (sp.give_up(lane)) return;
         }
+#endif
         if (p * 256 + lane * 4 < n) *reinterpret_cast<U4*>(rep + o) = a;      // plain store: stays in this XCD's L2
     }
     eng_gather(rep, lay, u0, n, tag, dst, gw, ngw, lane, ctl, dead, where, dmap, dbg);

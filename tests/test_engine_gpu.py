@@ -16,10 +16,15 @@ from tests.test_ar_gpu import medium_shape
 pytestmark = pytest.mark.gpu
 
 
-def _run(monkeypatch, shape, engine_on, prompt, n_new, kw, tape=None, precision="bf16"):
-    """engine_on: False = launch path, True = both engines, "slow" = the slow-stack engine only."""
+def _run(monkeypatch, shape, engine_on, prompt, n_new, kw, tape=None, precision="bf16", env=()):
+    """engine_on: False = launch path, True = both engines, "slow" = the slow-stack engine only; env: switches that turn
+    single engine features off (FT_NO_PAIR, FT_NO_QKV0, FT_NO_RELAY)."""
     monkeypatch.delenv("FT_NO_ENGINE", raising=False)
     monkeypatch.delenv("FT_NO_FAST_ENGINE", raising=False)
+    for k in ("FT_NO_PAIR", "FT_NO_QKV0", "FT_NO_RELAY"):
+        monkeypatch.delenv(k, raising=False)
+    for k in env:
+        monkeypatch.setenv(k, "1")
     if not engine_on:
         monkeypatch.setenv("FT_NO_ENGINE", "1")
     elif engine_on == "slow":
@@ -63,6 +68,22 @@ def test_engine_frames_equal_launch_frames_sampled(monkeypatch):
         assert fb == want
         assert np.array_equal(a, b), mode
         assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), mode
+
+
+@pytest.mark.parametrize("env", [("FT_NO_PAIR",), ("FT_NO_QKV0",), ("FT_NO_PAIR", "FT_NO_QKV0"), ("FT_NO_RELAY",)])
+def test_engine_feature_switches_keep_the_bits(monkeypatch, env):
+    """The fast loop's paired first pass (positions 0 and 1 as two rows), its layer-0 q k v table and the per-XCD relay are
+    each optional (LDS budget, two-codebook models, FT_NO_*): with any of them off the frames are still the launch path's."""
+    shape = dataclasses.replace(medium_shape(), max_seq_len=1024)
+    prompt = make_prompt(shape, 33, seed=9, n_vq=2).numpy()
+    kw = dict(temperature=0.7, top_p=0.8, repetition_penalty=1.1)
+    tape = NoiseTape(shape, 32, seed=5)
+    _, a, la, ha = _run(monkeypatch, shape, False, prompt, 20, kw, tape)
+    fb, b, lb, hb = _run(monkeypatch, shape, True, prompt, 20, kw, tape, env=env)
+    assert fb == 3
+    assert np.array_equal(a, b), env
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), env
+    assert np.array_equal(ha.view(np.uint32), hb.view(np.uint32)), env
 
 
 def test_engine_full_depth_equals_launch_path(monkeypatch):

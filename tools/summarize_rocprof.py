@@ -76,8 +76,31 @@ def traffic(fetch_dir, write_dir, dst_md, frame_kernel="slow_engine_kernel"):
     print("wrote", dst_md)
 
 
+def trace(src, dst, first="rvq_gather"):
+    """Per-call list of the LAST pass that starts with kernel `first` (one codec decode) from a --kernel-trace run:
+    kernel, grid in workgroups, duration."""
+    f = glob.glob(src + "/**/*_kernel_trace.csv", recursive=True)[0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
+    rows = rows[idx[-1]:] if idx else rows
+    tot = 0.0
+    with open(dst, "w") as o:
+        o.write("| # | kernel | grid (workgroups) | us |\n|---|---|---|---|\n")
+        for i, r in enumerate(rows):
+            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            tot += d
+            g = (int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["Grid_Size_Y"]) // max(1, int(r["Workgroup_Size_Y"])),
+                 int(r["Grid_Size_Z"]) // max(1, int(r["Workgroup_Size_Z"])))
+            o.write(f"| {i} | `{r['Kernel_Name'].replace('void ft::', '').replace('ft::', '')[:60]}` | {g[0]} x {g[1]} x {g[2]} | {d:.1f} |\n")
+        span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e3
+        o.write(f"\nkernel time {tot:.0f} us, first start to last end {span:.0f} us\n")
+    print("wrote", dst)
+
+
 if __name__ == "__main__" and sys.argv[1] != "mfma":
-    if sys.argv[1] == "traffic":
+    if sys.argv[1] == "trace":
+        trace(sys.argv[2], sys.argv[3], *(sys.argv[4:5]))
+    elif sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4])
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
