@@ -140,8 +140,8 @@ __device__ __forceinline__ void eng_ld1_sc1(const void* p0, U4& a) {
 // `iters` rounds (the caller checks its clock and comes back).  Loads issued earlier by this wave return first
 // (vmcnt is in order), so the counted waits hold whatever else is outstanding.
 #ifndef ENG_STAGGER
-#define ENG_STAGGER 1
-#endif
+#define ENG_STAGGER 0     // measured (tools/mb_engine, same box): 597 -> 618 us (slow stack), 721 -> 746 us (fast loop) with it ON:
+#endif                    // more polls in flight slow the hand-off down, like every other "poll more" variant tried
 #ifndef ENG_STAGGER_SLEEP
 #define ENG_STAGGER_SLEEP 6       // x 64 cycles: ~half a memory-side poll round trip
 #endif
