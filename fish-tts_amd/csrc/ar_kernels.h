@@ -1881,12 +1881,24 @@ static __global__ __launch_bounds__(1024) void samp_cut_kernel(SampBigP b) {
     // 16 logits per thread and step, all four 16-byte loads issued before the first counter update (one block walks
     // the whole row: a load-use chain per element would cost a memory round trip 152 times)
     const int V16 = ((reinterpret_cast<uintptr_t>(L) & 15) == 0) ? (V / 16384) * 16384 : 0;
-    for (int base = 0; base < V16; base += 16384) {
-        float4 f[4];
+    // two steps in flight: the loads of step i + 1 are issued before step i's counters are updated (the row was written by
+    // the head GEMV's blocks on all XCDs a moment ago, so every load is a trip to the memory side: 9 exposed round trips
+    // were ~25 of this kernel's 40 us)
+    float4 fa[4], fb[4];
+    auto ld16 = [&](float4 (&f)[4], int base) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) f[u] = *reinterpret_cast<const float4*>(L + base + u * 4096 + tid * 4);
+    };
+    auto cnt16 = [&](const float4 (&f)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) { count1(f[u].x); count1(f[u].y); count1(f[u].z); count1(f[u].w); }
+    };
+    if (V16 > 0) ld16(fa, 0);
+    for (int base = 0; base < V16; base += 32768) {
+        if (base + 16384 < V16) ld16(fb, base + 16384);
+        cnt16(fa);
+        if (base + 32768 < V16) ld16(fa, base + 32768);
+        if (base + 16384 < V16) cnt16(fb);
     }
     for (int base = V16; base < V; base += 4096) {   // tail (and unaligned rows): 4 scalar loads in flight
         float f[4];
