@@ -545,6 +545,25 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
         const bool vec_ok = io.act != ACT_SWIGLU && w.N % 8 == 0 && w.n_mod % 8 == 0 && io.ldo % 8 == 0 && io.ldr % 8 == 0;
         const bool small_m = io.M <= big_thr || !vec_ok;   // the 128x128 tile has the vector epilogue only
         const bool k64 = w.K % 64 == 0;
+        // many rows (the decoder's convolutions after the first up-sampling): 128-row tiles on 8 waves - the 64 x 64 tile is
+        // bound by the L2 bandwidth its weight-tile re-reads need (codec_kernels.h)
+#define FT_TG8(BM_, BN_, BK_, NWM_, NWN_)                                                                       \
+    do {                                                                                                          \
+        constexpr size_t lds8_ = std::max((size_t)((BM_ + 56) + 2 * BN_) * (BK_ + 8) * 2,                         \
+                                          (size_t)(BM_ / NWM_) * (BN_ + 4) * 4);                                  \
+        static DevOnce once8_;                                                                                    \
+        once8_.run([] { hipFuncSetAttribute((const void*)tapgemm64_kernel<BM_, BN_, BK_, NWM_, NWN_>,             \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8_); });          \
+        tapgemm64_kernel<BM_, BN_, BK_, NWM_, NWN_><<<dim3((io.M + BM_ - 1) / BM_, (w.N + BN_ - 1) / BN_, 1),     \
+                                                      64 * NWM_ * NWN_, lds8_, st>>>(p);                          \
+    } while (0)
+        static const long tile8_m = getenv("FT_CODEC_TILE8_M") ? atol(getenv("FT_CODEC_TILE8_M")) : 4096;
+        if (vec_ok && io.M >= tile8_m && (w.N % 128 == 0 || w.N % 96 == 0)) {
+            if (w.N % 128 == 0) { if (k64) FT_TG8(128, 128, 64, 2, 4); else FT_TG8(128, 128, 32, 2, 4); }
+            else { if (k64) FT_TG8(128, 96, 64, 4, 2); else FT_TG8(128, 96, 32, 4, 2); }
+            return;
+        }
+#undef FT_TG8
         if (w.N % 128 == 0 || (w.N % 96 != 0 && w.N > 96)) {
             if (small_m) { if (k64) FT_TG(64, 64, 64); else FT_TG(64, 64, 32); }
             else { if (k64) FT_TG(128, 128, 64); else FT_TG(128, 128, 32); }

@@ -173,16 +173,17 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmP p) {
 
 // Epilogue through LDS: the accumulators (column-per-lane) are transposed so that each lane finishes 8 consecutive
 // columns of one row: 16-byte loads of the residual, 16-byte stores of every output (the late decoder stages are
-// bandwidth-bound: 2-byte scattered stores were the bottleneck).  Two passes of BM/2 rows.
-template <int BM, int BN, int TM, int TN>
+// bandwidth-bound: 2-byte scattered stores were the bottleneck).  NWM passes of BM/NWM rows.
+template <int BM, int BN, int TM, int TN, int NWM = 2, int NWN = 2>
 __device__ __forceinline__ void tapgemm_epilogue_lds(const TapGemmP& p, f32x4 (&acc)[TM][TN], float* Cs, const int m0,
                                                      const int n0, const int b, const int wm, const int wn,
                                                      const int fr, const int fq) {
     constexpr int LDC = BN + 4;
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int WM = BM / NWM, WN = BN / NWN;
+    constexpr int NTHR = 64 * NWM * NWN;
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < NWM; ++pass) {
         __syncthreads();
         if (wm == pass) {
 #pragma unroll
@@ -194,7 +195,7 @@ __device__ __forceinline__ void tapgemm_epilogue_lds(const TapGemmP& p, f32x4 (&
                         Cs[(i * 16 + fq * 4 + r) * LDC + wn * WN + j * 16 + fr] = acc[i][j][r];
         }
         __syncthreads();
-        for (int v = tid; v < WM * (BN / 8); v += 256) {
+        for (int v = tid; v < WM * (BN / 8); v += NTHR) {
             const int row = v / (BN / 8), c8 = (v % (BN / 8)) * 8;
             const int t = m0 + pass * WM + row, n = n0 + c8;
             if (t >= p.M || n >= p.N) continue;
@@ -265,11 +266,17 @@ __device__ __forceinline__ void tapgemm_epilogue_lds(const TapGemmP& p, f32x4 (&
 // block *and its tap halo* (BM + max|off| rows) are staged once and shared by all taps; the B (weight) tile of
 // the next tap is fetched into registers while the current one feeds the MFMAs and is written to the other LDS
 // buffer afterwards: one barrier per (tap, chunk) step, 32 (BN=128) MFMAs per wave between barriers.
-template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
+// NWM x NWN waves (default 2 x 2 = 256 threads).  The 8-wave 128-row tiles exist because the small tile is bound by the L2:
+// a BM x BN tile reads (BM + BN) K bf16 per BM BN K MACs = BM BN / (BM + BN) flop per byte - 32 at 64 x 64, and 1024
+// co-resident blocks re-reading their weight tiles at ~10-13 TB/s of L2 bandwidth is the 320-420 TFLOP/s the k = 7
+// convolutions of the decoder ran at (12.8 % MFMA); 128 x 128 doubles it with the same waves per CU.
+template <int BM, int BN, int BK, int NWM = 2, int NWN = 2>
+__global__ __launch_bounds__(64 * NWM * NWN) void tapgemm64_kernel(TapGemmP p) {
+    constexpr int NTHR = 64 * NWM * NWN;
     constexpr int LD = BK + 8;                      // LDS row stride (bf16): keeps 16-byte alignment, spreads banks
-    constexpr int WM = BM / 2, WN = BN / 2;         // 2 x 2 waves
+    constexpr int WM = BM / NWM, WN = BN / NWN;
     constexpr int TM = WM / 16, TN = WN / 16;
+    static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile = whole 16 x 16 MFMA tiles");
     constexpr int MAXH = 56;                        // largest tap halo (k=7, dilation 9 -> 54)
     constexpr int QPR = BK / 8;                     // 16-byte chunks per tile row
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
     bf16_t* Bs0 = As + (BM + MAXH) * LD;            // [BN][LD] x 2
     bf16_t* Bs1 = Bs0 + BN * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
     const bf16_t* X = p.X + (size_t)b * p.x_bstride;
     int offmin = 0;
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
-    constexpr int BCH = (BN * QPR + 255) / 256;     // 16-byte chunks of a B tile per thread
+    constexpr int BCH = (BN * QPR + NTHR - 1) / NTHR;     // 16-byte chunks of a B tile per thread
     // weight tiles are fetched TWO steps ahead into two named register sets (the MFMA work of one step is far
     // shorter than an L2 round trip)
     U4 bregA[BCH], bregB[BCH];
@@ -299,14 +306,14 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
         const bf16_t* Wt = p.W + (size_t)tap * p.N * p.K;
 #pragma unroll
         for (int u = 0; u < BCH; ++u) {
-            const int c = tid + 256 * u, r = c / QPR, q = c % QPR;
+            const int c = tid + NTHR * u, r = c / QPR, q = c % QPR;
             breg[u] = (r < BN && n0 + r < p.N) ? *reinterpret_cast<const U4*>(Wt + (size_t)(n0 + r) * p.K + k0 + q * 8) : U4{0u, 0u, 0u, 0u};
         }
     };
     auto store_b = [&](const U4 (&breg)[BCH], bf16_t* Bs) {
 #pragma unroll
         for (int u = 0; u < BCH; ++u) {
-            const int c = tid + 256 * u, r = c / QPR, q = c % QPR;
+            const int c = tid + NTHR * u, r = c / QPR, q = c % QPR;
             if (r < BN) *reinterpret_cast<U4*>(&Bs[r * LD + q * 8]) = breg[u];
         }
     };
@@ -314,12 +321,12 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
     const int nchunks = p.K / BK;
     // the A stripe of the NEXT K chunk also travels in registers while this chunk's taps run (with one tap - linears,
     // 1x1 convs, the prompt GEMMs - its load latency would otherwise be exposed once per step)
-    constexpr int ACH = ((BM + MAXH) * QPR + 255) / 256;
+    constexpr int ACH = ((BM + MAXH) * QPR + NTHR - 1) / NTHR;
     U4 areg[ACH];
     auto load_a = [&](int kc) {
 #pragma unroll
         for (int u = 0; u < ACH; ++u) {
-            const int c = tid + 256 * u, r = c / QPR, q = c % QPR;
+            const int c = tid + NTHR * u, r = c / QPR, q = c % QPR;
             const int t = m0 + offmin + r;
             areg[u] = (c < srows * QPR && t >= 0 && t < p.T_in)
                           ? *reinterpret_cast<const U4*>(X + (size_t)t * p.ldx + kc * BK + q * 8) : U4{0u, 0u, 0u, 0u};
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
             // previous chunk's MFMAs are done (barrier at the end of its last step): restage the A stripe
 #pragma unroll
             for (int u = 0; u < ACH; ++u) {
-                const int c = tid + 256 * u, r = c / QPR, q = c % QPR;
+                const int c = tid + NTHR * u, r = c / QPR, q = c % QPR;
                 if (c < srows * QPR) *reinterpret_cast<U4*>(&As[r * LD + q * 8]) = areg[u];
             }
             if (kc + 1 < nchunks) load_a(kc + 1);
@@ -368,12 +375,12 @@ __global__ __launch_bounds__(256) void tapgemm64_kernel(TapGemmP p) {
     }
     // vector epilogue whenever rows are 16-byte addressable (every real layer); SwiGLU pairs keep the lane epilogue
     const bool vec_ok = p.act != ACT_SWIGLU && (p.N % 8) == 0 && (p.n_mod % 8) == 0 && (p.ldo % 8) == 0 && (p.ldr % 8) == 0;
-    if constexpr (TM * TN >= 16) {
+    if constexpr (TM * TN >= 16 || NWM * NWN != 4) {
         // 128x128: instantiating the lane epilogue here makes the compiler keep all 16 accumulator tiles in scratch for
         // the whole kernel (272 B/lane); the host selects this tile only for layers the vector epilogue covers
-        tapgemm_epilogue_lds<BM, BN, TM, TN>(p, acc, reinterpret_cast<float*>(lds), m0, n0, b, wm, wn, fr, fq);
+        tapgemm_epilogue_lds<BM, BN, TM, TN, NWM, NWN>(p, acc, reinterpret_cast<float*>(lds), m0, n0, b, wm, wn, fr, fq);
     } else {
-        if (vec_ok) tapgemm_epilogue_lds<BM, BN, TM, TN>(p, acc, reinterpret_cast<float*>(lds), m0, n0, b, wm, wn, fr, fq);
+        if (vec_ok) tapgemm_epilogue_lds<BM, BN, TM, TN, NWM, NWN>(p, acc, reinterpret_cast<float*>(lds), m0, n0, b, wm, wn, fr, fq);
         else tapgemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, b, fr, fq);
     }
 }
