@@ -527,8 +527,11 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
     // few rows (the 215-frame transformers, the first up-sampling stage): a 64x64 tile grid leaves most CUs idle and every
     // block walks all of K alone (20-75 us per GEMM); the skinny kernel cuts N into 16-row blocks and splits K over the
     // waves of a block (weights streamed once per 64 rows)
-    static const long skinny_m = getenv("FT_CODEC_SKINNY_M") ? atol(getenv("FT_CODEC_SKINNY_M")) : 512;
-    if (!legacy && w.ntap == 1 && w.offs[0] == 0 && io.M <= skinny_m && io.T_in >= io.M && w.K % 128 == 0 && w.N % 2 == 0 &&
+    // (measured per GEMM at 215 / 430 / 860 rows: N = 1024 skinny 8-13 us against 21-75 us; N = 3072 equal; N >= 4096
+    // the tile kernel wins, 23 against 35 us: its grid is already >= 256 blocks there)
+    static const long skinny_m = getenv("FT_CODEC_SKINNY_M") ? atol(getenv("FT_CODEC_SKINNY_M")) : 1024;
+    static const long skinny_n = getenv("FT_CODEC_SKINNY_N") ? atol(getenv("FT_CODEC_SKINNY_N")) : 2048;
+    if (!legacy && w.ntap == 1 && w.offs[0] == 0 && io.M <= skinny_m && w.N <= skinny_n && io.T_in >= io.M && w.K % 128 == 0 && w.N % 2 == 0 &&
         (io.act == ACT_NONE || io.act == ACT_SWIGLU || io.act == ACT_GELU) && !io.out_act) {
         p.ldw = 0;
         skinny_gemm_launch<4>(p, (io.M + 63) / 64, st);

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void tapgemm64_kernel(TapGemmP p) {
     }
     // vector epilogue whenever rows are 16-byte addressable (every real layer); SwiGLU pairs keep the lane epilogue
     const bool vec_ok = p.act != ACT_SWIGLU && (p.N % 8) == 0 && (p.n_mod % 8) == 0 && (p.ldo % 8) == 0 && (p.ldr % 8) == 0;
-    if constexpr (TM * TN >= 16 || NWM * NWN != 4) {
+    if constexpr (TM * TN >= 16) {
         // 128x128: instantiating the lane epilogue here makes the compiler keep all 16 accumulator tiles in scratch for
         // the whole kernel (272 B/lane); the host selects this tile only for layers the vector epilogue covers
         tapgemm_epilogue_lds<BM, BN, TM, TN, NWM, NWN>(p, acc, reinterpret_cast<float*>(lds), m0, n0, b, wm, wn, fr, fq);

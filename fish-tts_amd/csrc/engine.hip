@@ -1182,7 +1182,15 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
         // 64x64x64 tiles at every prompt length: measured 12.8 vs 25.8 ms at Lp = 1500 and 22.3 vs 38.4 ms at 3000 against
         // the 128x128 tile (which spills registers); the else branch stays for FT_PF_BIG_S experiments
         static const int big_s = getenv("FT_PF_BIG_S") ? atoi(getenv("FT_PF_BIG_S")) : (1 << 30);
-        if (S <= big_s || act == ACT_SWIGLU || ldo % 8 != 0) {   // (the 128x128 tile has the vector epilogue only)
+        // long prompts: 128 x 128 on 8 waves (the 64 x 64 tile is bound by the L2 bandwidth of its weight re-reads)
+        static const int tile8_s = getenv("FT_PF_TILE8_S") ? atoi(getenv("FT_PF_TILE8_S")) : 512;
+        if (S >= tile8_s) {
+            constexpr size_t lds8 = std::max((size_t)((128 + 56) + 2 * 128) * (64 + 8) * 2, (size_t)(128 / 2) * (128 + 4) * 4);
+            static DevOnce once8;
+            once8.run([] { hipFuncSetAttribute((const void*)tapgemm64_kernel<128, 128, 64, 2, 4>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); });
+            tapgemm64_kernel<128, 128, 64, 2, 4><<<dim3((S + 127) / 128, N / 128, 1), 512, lds8, L.s>>>(p);
+        } else if (S <= big_s || act == ACT_SWIGLU || ldo % 8 != 0) {   // (the 4-wave 128x128 tile has the vector epilogue only)
             const size_t lds = std::max((size_t)((64 + 56) + 2 * 64) * (64 + 8) * 2, (size_t)(64 / 2) * (64 + 4) * 4);
             tapgemm64_kernel<64, 64, 64><<<dim3((S + 63) / 64, N / 64, 1), 256, lds, L.s>>>(p);
         } else {
