@@ -561,8 +561,10 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
                                                       64 * NWM_ * NWN_, lds8_, st>>>(p);                          \
     } while (0)
         static const long tile8_m = getenv("FT_CODEC_TILE8_M") ? atol(getenv("FT_CODEC_TILE8_M")) : 4096;
+        static const long tile256_m = getenv("FT_CODEC_TILE256_M") ? atol(getenv("FT_CODEC_TILE256_M")) : (1L << 60);
         if (vec_ok && io.M >= tile8_m && (w.N % 128 == 0 || w.N % 96 == 0)) {
-            if (w.N % 128 == 0) { if (k64) FT_TG8(128, 128, 64, 2, 4); else FT_TG8(128, 128, 32, 2, 4); }
+            if (w.N % 128 == 0 && io.M >= tile256_m) FT_TG8(256, 128, 32, 4, 2);
+            else if (w.N % 128 == 0) { if (k64) FT_TG8(128, 128, 64, 2, 4); else FT_TG8(128, 128, 32, 2, 4); }
             else { if (k64) FT_TG8(128, 96, 64, 4, 2); else FT_TG8(128, 96, 32, 4, 2); }
             return;
         }
