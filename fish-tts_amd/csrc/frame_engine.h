@@ -1653,6 +1653,7 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre
 #pragma unroll
     for (int e = 0; e < 4; ++e) { ex[e] = (i0 + e) < V ? expf(l[e] - Lmax) : 0.f; z += ex[e]; }
     const float Z = red_sum(z);
+    if (stp && tid == 0) stp[-16 + 10] = eng_rt();
     const float tp = round_bf16(ctl.top_p);
     auto removed = [&](float cum) { return round_bf16(cum) > tp; };
     constexpr uint32_t cmask = 0xffff0000u;
@@ -1675,6 +1676,7 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre
 #pragma unroll
             for (int e = 0; e < 4; ++e) etp[e] = expf(round_bf16(l[e] / Tc) - Mt);
         }
+        if (stp && tid == 0) stp[-16 + 11] = eng_rt();
         if (wave == 0) {
             float pr[16];
             uint32_t ky[16];
@@ -1684,18 +1686,36 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre
 #pragma unroll
             for (int e = 0; e < 16; ++e) tot += pr[e];
             tot = wave_sum(tot);
+            if (stp && tid == 0) stp[-16 + 12] = eng_rt();
             uint32_t kstar = 0;
             int nk = 0, all_kept = 0;
             if (!removed(tot)) {
                 all_kept = 1;
             } else {
+                // the highest key present: a candidate above it selects nothing, its mass is an exact 0 and removed(0) is
+                // false whatever top_p is - those steps of the search (about half of the 16) are decided without the sum
+                uint32_t kmx = 0u;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) kmx = ky[e] > kmx ? ky[e] : kmx;
+                {
+                    int km = (int)(kmx >> 16);      // keys carry 16 significant bits: compare as small non-negative ints
+                    km = max(km, dpp_i<DPP_XOR1>(km));
+                    km = max(km, dpp_i<DPP_XOR2>(km));
+                    km = max(km, dpp_i<DPP_HALF_MIRROR>(km));
+                    km = max(km, dpp_i<DPP_MIRROR>(km));
+                    km = max(max(__builtin_amdgcn_readlane(km, 0), __builtin_amdgcn_readlane(km, 16)),
+                             max(__builtin_amdgcn_readlane(km, 32), __builtin_amdgcn_readlane(km, 48)));
+                    kmx = (uint32_t)km << 16;
+                }
                 for (int bit = 31; bit >= 16; --bit) {
                     const uint32_t cand = kstar | (1u << bit);
+                    if (cand > kmx) continue;
                     float ms = 0.f;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) ms += ky[e] >= cand ? pr[e] : 0.f;
                     if (removed(wave_sum(ms))) kstar = cand;
                 }
+                if (stp && tid == 0) stp[-16 + 13] = eng_rt();
                 float above = 0.f, cnt = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -1713,6 +1733,7 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre
                 }
                 nk = lo_n;
             }
+            if (stp && tid == 0) stp[-16 + 14] = eng_rt();
             if (lane == 0) { S.cut[0] = kstar; S.cut[1] = (uint32_t)nk; S.cut[2] = (uint32_t)all_kept; }
         }
         sub.sync(lane);

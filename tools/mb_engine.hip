@@ -298,6 +298,21 @@ static int run_fast(int nb, hipStream_t s) {
             ++dc;
         }
         for (int k = 0; k < 5; ++k) printf("   %-26s %7.2f %7.2f   (median / latest workgroup)\n", dn[k], md[k] / dc / 100.0, hi2[k] / dc / 100.0);
+        {   // finer stamps of the cut search (kept in the previous layer's stamp row)
+            const char* fn[5] = {"  normaliser Z known", "  probabilities in LDS", "  wave 0: total mass", "  wave 0: bit search done", "  wave 0: cut found"};
+            double fm[5] = {0}; int fc = 0;
+            for (int cb = 2; cb < ncb; ++cb) {
+                unsigned long long t0 = 0;
+                for (int b = 0; b < nb; ++b) t0 = std::max(t0, st[(((size_t)b * ncb + cb) * nL + nL - 1) * 16 + 8]);
+                for (int k = 0; k < 5; ++k) {
+                    for (int b = 0; b < nb; ++b) v[b] = st[(((size_t)b * ncb + cb) * nL + nL - 2) * 16 + 10 + k];
+                    std::sort(v.begin(), v.end());
+                    fm[k] += (double)v[nb / 2] - (double)t0;
+                }
+                ++fc;
+            }
+            for (int k = 0; k < 5; ++k) printf("   %-26s %7.2f\n", fn[k], fm[k] / fc / 100.0);
+        }
     }
     return 0;
 }
