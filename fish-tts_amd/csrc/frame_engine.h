@@ -139,6 +139,9 @@ __device__ __forceinline__ void eng_ld1_sc1(const void* p0, U4& a) {
 // whose load is still in flight.  Returns true when every lane's four granules carry `tag` (data in a); false after
 // `iters` rounds (the caller checks its clock and comes back).  Loads issued earlier by this wave return first
 // (vmcnt is in order), so the counted waits hold whatever else is outstanding.
+#ifndef ENG_PAIR_FUSE_W13
+#define ENG_PAIR_FUSE_W13 1
+#endif
 #ifndef ENG_STAGGER
 #define ENG_STAGGER 0     // measured (tools/mb_engine, same box): 597 -> 618 us (slow stack), 721 -> 746 us (fast loop) with it ON:
 #endif                    // more polls in flight slow the hand-off down, like every other "poll more" variant tried
@@ -626,7 +629,7 @@ template <int NT, int RPU, int MAXS, int PRO, int EPI>
 __device__ __forceinline__ void eng_gemv2(const EngW<NT, RPU, MAXS>& r, const float* xs0, const float* xs1, int K, float eps,
                                           const bf16_t* bias, const float* resid0, const float* resid1, unsigned* gout0, unsigned* gout1,
                                           unsigned tag0, unsigned tag1, int u_lo, int u_hi, int cw, int lane, EngOut& eo) {
-    if (NT <= 2) {
+    if (NT <= 2 && (ENG_PAIR_FUSE_W13 || RPU == 1)) {
         eng_gemv_rows2<NT, RPU, MAXS, PRO, EPI>(r, xs0, xs1, K, eps, bias, resid0, resid1, eo.vals, eo.vals + 32, u_lo, u_hi, cw, lane);
     } else {
         eng_gemv_rows<NT, RPU, MAXS, PRO, EPI>(r, xs0, K, eps, bias, resid0, eo.vals, u_lo, u_hi, cw, lane);
