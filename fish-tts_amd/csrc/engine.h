@@ -74,6 +74,8 @@ struct ft_ctx {
     ft::bf16_t* mb_xb = nullptr;
     float* mb_ss = nullptr;   // [max(dim, fast_dim) / 16][max_batch]
     bool wide_fuse = false;
+    unsigned* gemm_ticket = nullptr;   // arrival counter of the skinny GEMM's tail norm (zero between launches)
+    bool tail_norm = false;            // norms after Wo / W2 inside those GEMMs' last blocks (17..128 lock-step rows)
     int wide_fuse_max = 16;   // largest lock-step batch that takes the fused-norm GEMMs
     int wide_min = 5;   // measured: the MFMA path wins from 5 rows (B=5: 2.79 vs 3.33 ms per frame), B <= 4 keeps the bit-exact multi-row GEMV
     bool wide_ok = false;

@@ -198,6 +198,13 @@ static ft_status ar_alloc(ft_ctx* ctx) {
             FT_TRY(dmalloc(ctx, &ctx->mb_g, M * (size_t)std::max(c.intermediate_size, c.fast_intermediate_size)));
             FT_TRY(dmalloc(ctx, &ctx->mb_xb, M * (size_t)std::max(c.dim, c.fast_dim)));
             FT_TRY(dmalloc(ctx, &ctx->mb_ss, M * (size_t)(std::max(c.dim, c.fast_dim) / 16 + 1)));
+            FT_TRY(dmalloc(ctx, &ctx->gemm_ticket, (size_t)4));
+            // FT_TAIL_NORM (opt-in; measured SLOWER: 4.67 against 3.54 ms per 32-row frame): the norm after a Wo / W2 GEMM
+            // inside that GEMM's last-finishing block.  Write-through stores + their acknowledgement, a returning ticket atomic
+            // and the last block's trip to the memory side for the rows add up to more than the ~5 us launch they replace.
+            ctx->tail_norm = getenv("FT_TAIL_NORM") != nullptr && c.dim == 1024 && c.fast_dim == 1024 &&
+                             (c.n_head * c.head_dim) % 128 == 0 && c.intermediate_size % 128 == 0 &&
+                             (c.fast_n_head * c.fast_head_dim) % 128 == 0 && c.fast_intermediate_size % 128 == 0 && c.max_batch <= 128;
             // the norm rides inside the consumer GEMM only where every Linear of a layer takes the skinny kernel, and only up
             // to 16 rows: measured +8 % at B=8, +5 % at B=16, -4 % at B=32 (the in-register normalisation of two row tiles
             // costs more VALU time than the removed launches)
@@ -278,7 +285,7 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     int* ibufs[] = {ctx->d_pos, ctx->d_tok, ctx->d_tokn, ctx->d_seq, ctx->d_nf, ctx->d_done, ctx->d_prompt};
     for (int* b : ibufs) if (b) hipFree(b);
     if (ctx->d_ctl) hipFree(ctx->d_ctl);
-    { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g, ctx->mb_xn, ctx->mb_ybf, ctx->mb_g, ctx->mb_xb, ctx->mb_ss, ctx->pf_qbf}; for (void* q : pf) if (q) hipFree(q); }
+    { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g, ctx->mb_xn, ctx->mb_ybf, ctx->mb_g, ctx->mb_xb, ctx->mb_ss, ctx->pf_qbf, ctx->gemm_ticket}; for (void* q : pf) if (q) hipFree(q); }
     for (auto& l : ctx->layers) { if (l.bqkv_f32) hipFree(l.bqkv_f32); if (l.bo_f32) hipFree(l.bo_f32); }
     if (ctx->samp_hist) hipFree(ctx->samp_hist);
     if (ctx->samp_ticket) hipFree(ctx->samp_ticket);
@@ -542,6 +549,7 @@ struct Launch {
     int pos_off;     // added to the device position (token-by-token prefill)
     hipError_t err = hipSuccess;
     bool gemv_only = false;  // measurement: enqueue only the weight-streaming GEMV launches of the frame
+    bool xn_final = false;   // wide path: the last W2 GEMM's tail left the final-norm rows in mb_xn (consumed by the head)
     void chk() { hipError_t e = hipGetLastError(); if (e != hipSuccess && err == hipSuccess) err = e; }
 };
 
@@ -550,6 +558,8 @@ struct PfX {   // fused RMSNorm hooks of the skinny kernel (codec_kernels.h TapG
     const float* ss_in = nullptr; // ... and the producer's partial sums of squares (nblk per row)
     int nblk = 0;
     float* ss_out = nullptr;      // leave this GEMM's own partials for the next consumer
+    const void* tail_gain = nullptr;   // RMSNorm of this GEMM's output rows by its last-finishing block (codec_kernels.h) ...
+    bf16_t* tail_out = nullptr;        // ... into this bf16 buffer
 };
 static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, const float* bias, int N, int K,
                     int act, const float* resid, float* out_f32, bf16_t* out_bf, long ldo, int round_out,
@@ -785,12 +795,23 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
                 float* ss = ctx->mb_ss + (size_t)m0 * (std::max(c.dim, c.fast_dim) / 16 + 1);
                 PfX leave; leave.ss_out = fuse ? ss : nullptr;
                 PfX nrm; nrm.ss_in = ss; nrm.nblk = D / 16;
+                // above the fused-norm limit: the norms after Wo and W2 are done by those GEMMs' last blocks (tail), so
+                // from layer 1 on xn is already there
+                const bool tail = !fuse && ctx->tail_norm && ctx->prefill_gemm_mode >= 2 && M <= 128 && !(ctx->fork_fast0 && ctx->stream2);
                 if (fuse && li > 0) {
                     nrm.gain = l.attn_norm;
                     pf_gemm(L, xb, D, M, l.wqkv, l.bqkv_f32, (int)qkvN, D, ACT_NONE, nullptr, qkv, nullptr, (long)qkvN, 0, nrm);
                 } else {
-                    rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.attn_norm, c.norm_eps, D, xn);
+                    if (!(tail && li > 0)) rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.attn_norm, c.norm_eps, D, xn);
                     pf_gemm(L, xn, D, M, l.wqkv, l.bqkv_f32, (int)qkvN, D, ACT_NONE, nullptr, qkv, nullptr, (long)qkvN, 0);
+                }
+                PfX tail_o, tail_d;
+                if (tail) {
+                    tail_o.tail_gain = l.ffn_norm; tail_o.tail_out = xn;
+                    // after W2: the next layer's first norm, or the final norm in front of the vocabulary head
+                    tail_d.tail_gain = li + 1 < c.n_layer ? ctx->layers[li + 1].attn_norm : (with_head ? ctx->norm : nullptr);
+                    tail_d.tail_out = tail_d.tail_gain ? xn : nullptr;
+                    if (li + 1 == c.n_layer && with_head) L.xn_final = true;
                 }
                 AttnP a{};
                 a.qkv = qkv; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->rope;
@@ -808,15 +829,15 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
                 a.part_ml = ctx->part_ml + (size_t)m0 * c.n_head * ctx->nsplit * 2;
                 attn_decode<WT, ROUND>(L, a);
                 if (ns > 1) { attn_combine_rows_kernel<ROUND><<<M, 256, 0, L.s>>>(a); L.chk(); }
-                pf_gemm(L, ybf, HD, M, l.wo, l.bo_f32, D, HD, ACT_NONE, x, x, fuse ? xb : nullptr, D, 1, leave);
+                pf_gemm(L, ybf, HD, M, l.wo, l.bo_f32, D, HD, ACT_NONE, x, x, fuse ? xb : nullptr, D, 1, tail ? tail_o : leave);
                 if (fuse) {
                     nrm.gain = l.ffn_norm;
                     pf_gemm(L, xb, D, M, l.w13, nullptr, 2 * F, D, ACT_SWIGLU, nullptr, nullptr, gbf, F, 0, nrm);
                 } else {
-                    rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.ffn_norm, c.norm_eps, D, xn);
+                    if (!tail) rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.ffn_norm, c.norm_eps, D, xn);
                     pf_gemm(L, xn, D, M, l.w13, nullptr, 2 * F, D, ACT_SWIGLU, nullptr, nullptr, gbf, F, 0);
                 }
-                pf_gemm(L, gbf, F, M, l.w2, nullptr, D, F, ACT_NONE, x, x, fuse ? xb : nullptr, D, 1, leave);
+                pf_gemm(L, gbf, F, M, l.w2, nullptr, D, F, ACT_NONE, x, x, fuse ? xb : nullptr, D, 1, tail ? tail_d : leave);
             }
             continue;
         }
@@ -886,7 +907,9 @@ static void enqueue_head(Launch& L) {
                         ctx->logits + (size_t)L.m0 * c.vocab_size, nullptr, c.vocab_size, 0, nrm);
                 return;
             }
-            rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(ctx->x + (size_t)L.m0 * c.dim, ctx->norm, c.norm_eps, c.dim, xn);
+            if (!L.xn_final)   // (else the last W2 GEMM's tail already normalised x with the final gain)
+                rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(ctx->x + (size_t)L.m0 * c.dim, ctx->norm, c.norm_eps, c.dim, xn);
+            L.xn_final = false;
             pf_gemm(L, xn, c.dim, L.M, ctx->head, nullptr, c.vocab_size, c.dim, ACT_NONE, nullptr,
                     ctx->logits + (size_t)L.m0 * c.vocab_size, nullptr, c.vocab_size, 0);
         }
@@ -991,13 +1014,23 @@ static void enqueue_fast_step(Launch& L, const int cb) {
                     float* ss = ctx->mb_ss + (size_t)m0 * (std::max(c.dim, c.fast_dim) / 16 + 1);
                     PfX leave; leave.ss_out = fuse ? ss : nullptr;
                     PfX nrm; nrm.ss_in = ss; nrm.nblk = Df / 16;
+                    const bool tail = !fuse && ctx->tail_norm && ctx->prefill_gemm_mode >= 2 && M <= 128 && !(ctx->fork_fast0 && ctx->stream2);
                     if (fuse && li > 0) {
                         nrm.gain = l.attn_norm;
                         pf_gemm(L, xb, Df, M, l.wqkv, nullptr, (int)qkvN, Df, ACT_NONE, nullptr, qkvf, nullptr, (long)qkvN, 0, nrm);
                     } else {
-                        rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xl, l.attn_norm, c.norm_eps, Df, xn);
+                        if (!(tail && li > 0)) rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xl, l.attn_norm, c.norm_eps, Df, xn);
                         pf_gemm(L, xn, Df, M, l.wqkv, nullptr, (int)qkvN, Df, ACT_NONE, nullptr, qkvf, nullptr, (long)qkvN, 0);
                     }
+                    PfX tail_o, tail_d;
+                    bool head_ready = false;
+                    if (tail) {
+                        tail_o.tail_gain = l.ffn_norm; tail_o.tail_out = xn;
+                        tail_d.tail_gain = li + 1 < c.n_fast_layer ? ctx->flayers[li + 1].attn_norm : (cb != 0 ? ctx->fast_norm : nullptr);
+                        tail_d.tail_out = tail_d.tail_gain ? xn : nullptr;
+                        head_ready = li + 1 == c.n_fast_layer && cb != 0;
+                    }
+                    if (head_ready) L.xn_final = true;
                     FastAttnP a{};
                     a.qkv = qkvf; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->frope;
                     a.kc = (char*)l.kc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
@@ -1009,15 +1042,15 @@ static void enqueue_fast_step(Launch& L, const int cb) {
                     // y (f32) and its bf16 copy share the row stride HDf here
                     fast_attn_kernel<WT, ROUND><<<dim3(Hf, M), 64, 0, L.s>>>(a, yf, HDf);
                     L.chk();
-                    pf_gemm(L, ybf, HDf, M, l.wo, nullptr, Df, HDf, ACT_NONE, xl, xf, fuse ? xb : nullptr, Df, 1, leave);
+                    pf_gemm(L, ybf, HDf, M, l.wo, nullptr, Df, HDf, ACT_NONE, xl, xf, fuse ? xb : nullptr, Df, 1, tail ? tail_o : leave);
                     if (fuse) {
                         nrm.gain = l.ffn_norm;
                         pf_gemm(L, xb, Df, M, l.w13, nullptr, 2 * Ff, Df, ACT_SWIGLU, nullptr, nullptr, gbf, Ff, 0, nrm);
                     } else {
-                        rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xf, l.ffn_norm, c.norm_eps, Df, xn);
+                        if (!tail) rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xf, l.ffn_norm, c.norm_eps, Df, xn);
                         pf_gemm(L, xn, Df, M, l.w13, nullptr, 2 * Ff, Df, ACT_SWIGLU, nullptr, nullptr, gbf, Ff, 0);
                     }
-                    pf_gemm(L, gbf, Ff, M, l.w2, nullptr, Df, Ff, ACT_NONE, xf, xf, fuse ? xb : nullptr, Df, 1, leave);
+                    pf_gemm(L, gbf, Ff, M, l.w2, nullptr, Df, Ff, ACT_NONE, xf, xf, fuse ? xb : nullptr, Df, 1, tail ? tail_d : leave);
                 }
                 continue;
             }
@@ -1060,7 +1093,8 @@ static void enqueue_fast_step(Launch& L, const int cb) {
                     pf_gemm(L, ctx->mb_xb + (size_t)m0 * Df, Df, L.M, ctx->fast_out, nullptr, ctx->fastV, Df, ACT_NONE, nullptr,
                             ctx->flog + (size_t)m0 * ctx->fastV, nullptr, ctx->fastV, 0, nrm);
                 } else {
-                    rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(xf, ctx->fast_norm, c.norm_eps, Df, xn);
+                    if (!L.xn_final) rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(xf, ctx->fast_norm, c.norm_eps, Df, xn);
+                    L.xn_final = false;
                     pf_gemm(L, xn, Df, L.M, ctx->fast_out, nullptr, ctx->fastV, Df, ACT_NONE, nullptr,
                             ctx->flog + (size_t)m0 * ctx->fastV, nullptr, ctx->fastV, 0);
                 }
@@ -1168,12 +1202,13 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
                     int act, const float* resid, float* out_f32, bf16_t* out_bf, long ldo, int round_out, const PfX& fx) {
     TapGemmP p{};
     p.gain = (const bf16_t*)fx.gain; p.ss_in = fx.ss_in; p.ss_out = fx.ss_out; p.ss_nblk = fx.nblk;
+    p.tail_gain = (const bf16_t*)fx.tail_gain; p.tail_out = fx.tail_out; p.ticket = L.ctx->gemm_ticket;
     p.ss_ld = std::max(L.ctx->c.dim, L.ctx->c.fast_dim) / 16 + 1; p.eps = L.ctx->c.norm_eps;
     p.X = X; p.ldx = ldx; p.T_in = S; p.W = (const bf16_t*)W; p.ntap = 1; p.offs[0] = 0; p.M = S; p.N = N; p.K = K;
     p.bias = bias; p.n_mod = N; p.act = act; p.resid_f32 = resid; p.ldr = ldo; p.out_f32 = out_f32; p.out_bf = out_bf;
     p.ldo = ldo; p.round_lin = 1; p.round_f32_out = round_out;
     const int mode = L.ctx->prefill_gemm_mode;  // FT_PREFILL_GEMM: 0 = first tile kernel only, 1 = no skinny kernel
-    const bool fused = fx.gain || fx.ss_out;
+    const bool fused = fx.gain || fx.ss_out || fx.tail_out;
     if ((mode >= 2 || fused) && S <= 128 && K % 128 == 0 && N % 2 == 0) {
         // short prompts are weight-bandwidth bound: 16 weight rows per block, K split over the waves
         if (S <= 16) skinny_gemm_launch<1>(p, 1, L.s);
