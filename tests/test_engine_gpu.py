@@ -86,6 +86,36 @@ def test_engine_feature_switches_keep_the_bits(monkeypatch, env):
     assert np.array_equal(ha.view(np.uint32), hb.view(np.uint32)), env
 
 
+def test_engine_long_run_crosses_the_tag_wrap(monkeypatch):
+    """Hand-off tags are 15 bits of an epoch that advances by 64 per launch (two launches per frame): they repeat every
+    256 frames.  700 sampled frames (three wraps) on the engine must still equal the launch path's, frame for frame - a
+    granule left over from 256 frames earlier would carry a valid-looking tag."""
+    shape = dataclasses.replace(medium_shape(), max_seq_len=1024)
+    prompt = make_prompt(shape, 20, seed=11, n_vq=2).numpy()
+    kw = dict(temperature=0.7, top_p=0.8, repetition_penalty=1.1)
+    n = 700
+
+    def run(engine_on):
+        monkeypatch.delenv("FT_NO_ENGINE", raising=False)
+        if not engine_on:
+            monkeypatch.setenv("FT_NO_ENGINE", "1")
+        eng, _ = make_pair(shape, "bf16", max_new_tokens=n + 8)
+        flags = eng.engine_state()[0]
+        sp = eng._sampling(0.7, 0.8, 1.1, seed=7, ban_eos=True)       # <|im_end|> masked: the run has its full length
+        first = eng.prefill(prompt, sp, slot=0)
+        frames, cnt = eng.decode(n, [sp], poll=64)
+        _, aborted, where = eng.engine_state()
+        eng.close()
+        assert aborted == 0, where
+        return flags, first, frames[0, : cnt[0]]
+    fa, a0, a = run(False)
+    fb, b0, b = run(True)
+    assert fa == 0 and fb == 3
+    assert len(a) == n and len(b) == n
+    assert np.array_equal(a0, b0)
+    assert np.array_equal(a, b), int(np.argmax((a != b).any(axis=1)))
+
+
 def test_engine_full_depth_equals_launch_path(monkeypatch):
     """28 + 4 layers, vocabulary 155 776 (BASELINE configs[1] shapes), sampled: 16 frames."""
     shape = s1mini_shape(max_seq_len=1024)
