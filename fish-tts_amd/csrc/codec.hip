@@ -563,6 +563,10 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
         static const long tile8_m = getenv("FT_CODEC_TILE8_M") ? atol(getenv("FT_CODEC_TILE8_M")) : 4096;
         static const long tile256_m = getenv("FT_CODEC_TILE256_M") ? atol(getenv("FT_CODEC_TILE256_M")) : (1L << 60);
         if (vec_ok && io.M >= tile8_m && (w.N % 128 == 0 || w.N % 96 == 0)) {
+            // full-width tiles where the whole N fits one block column (A read once): 128 x 192 (N = 192, 384), 256 x 96 (N = 96)
+            static const long wide_m = getenv("FT_CODEC_WIDE_M") ? atol(getenv("FT_CODEC_WIDE_M")) : 30000;
+            if (io.M >= wide_m && w.N % 192 == 0) { FT_TG8(128, 192, 32, 2, 4); return; }
+            if (io.M >= wide_m && w.N == 96) { FT_TG8(256, 96, 32, 4, 2); return; }
             if (w.N % 128 == 0 && io.M >= tile256_m) FT_TG8(256, 128, 32, 4, 2);
             else if (w.N % 128 == 0) { if (k64) FT_TG8(128, 128, 64, 2, 4); else FT_TG8(128, 128, 32, 2, 4); }
             else { if (k64) FT_TG8(128, 96, 64, 4, 2); else FT_TG8(128, 96, 32, 4, 2); }
