@@ -1017,8 +1017,37 @@ struct FinalConvP {
     float* audio;      // [T]
 };
 static __global__ __launch_bounds__(256) void final_conv_tanh_kernel(FinalConvP p) {
-    // 16 lanes per output sample, 16 samples per block step
+    // 16 lanes per output sample, 16 samples per block step.  C % 8 == 0 and C <= 128: lane `sub` owns channels
+    // 8 sub .. 8 sub + 7 - one 16-byte load per tap and sample, its 7 x 8 weights stay in registers (the first version read
+    // 2-byte elements with a 32-byte stride: 150 us for 85 MB)
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    if (p.C % 8 == 0 && p.C <= 128) {
+        const bool on = sub * 8 < p.C;
+        float wv[7][8];
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[k][j] = on ? p.w[k * p.C + sub * 8 + j] : 0.f;
+        for (long t = (long)blockIdx.x * 16 + grp; t < p.T; t += (long)gridDim.x * 16) {
+            U4 x[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const long tt = t - 6 + k;
+                x[k] = (on && tt >= 0) ? *reinterpret_cast<const U4*>(p.xs + (size_t)tt * p.C + sub * 8) : U4{0u, 0u, 0u, 0u};
+            }
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                float xv[8];
+                Vec<bf16_t>::unpack(x[k], xv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a = fmaf(wv[k][j], xv[j], a);
+            }
+            a = row16_sum(a);
+            if (sub == 0) p.audio[t] = tanhf(a + p.bias);
+        }
+        return;
+    }
     for (long t = (long)blockIdx.x * 16 + grp; t < p.T; t += (long)gridDim.x * 16) {
         float a = 0.f;
         for (int k = 0; k < 7; ++k) {
