@@ -1223,7 +1223,14 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
         static const int big_s = getenv("FT_PF_BIG_S") ? atoi(getenv("FT_PF_BIG_S")) : (1 << 30);
         // long prompts: 128 x 128 on 8 waves (the 64 x 64 tile is bound by the L2 bandwidth of its weight re-reads)
         static const int tile8_s = getenv("FT_PF_TILE8_S") ? atoi(getenv("FT_PF_TILE8_S")) : 512;
-        if (S >= tile8_s) {
+        static const int wide_s = getenv("FT_PF_WIDE_S") ? atoi(getenv("FT_PF_WIDE_S")) : (1 << 30);
+        if (S >= wide_s && N % 192 == 0) {      // (w13: N = 6144) full 192-wide tiles, BK = 32
+            constexpr size_t ldsw = std::max((size_t)((128 + 56) + 2 * 192) * (32 + 8) * 2, (size_t)(128 / 2) * (192 + 4) * 4);
+            static DevOnce oncew;
+            oncew.run([] { hipFuncSetAttribute((const void*)tapgemm64_kernel<128, 192, 32, 2, 4>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw); });
+            tapgemm64_kernel<128, 192, 32, 2, 4><<<dim3((S + 127) / 128, N / 192, 1), 512, ldsw, L.s>>>(p);
+        } else if (S >= tile8_s) {
             constexpr size_t lds8 = std::max((size_t)((128 + 56) + 2 * 128) * (64 + 8) * 2, (size_t)(128 / 2) * (128 + 4) * 4);
             static DevOnce once8;
             once8.run([] { hipFuncSetAttribute((const void*)tapgemm64_kernel<128, 128, 64, 2, 4>,
