@@ -282,6 +282,18 @@ static int run_fast(int nb, hipStream_t s) {
         for (int b = 0; b < nb; ++b) { t0 = std::max(t0, st[(((size_t)b * ncb + cb - 1) * nL + nL - 1) * 16 + 8]); t1 = std::min(t1, st[(((size_t)b * ncb + cb) * nL + 0) * 16 + 0]); }
         gap += (double)t1 - (double)t0; ++gc;
     }
+    {   // span of the stamped part of the launch: first B1 of the first pass .. last draw of the last step
+        unsigned long long first = ~0ull, last = 0;
+        const int cb0 = p.pair ? 1 : 0;
+        for (int b = 0; b < nb; ++b) {
+            first = std::min(first, st[(((size_t)b * ncb + cb0) * nL + 0) * 16 + 0]);
+            last = std::max(last, st[(((size_t)b * ncb + ncb - 1) * nL + nL - 1) * 16 + 14]);
+        }
+        double pass0 = 0;   // first pass: first B1 -> last W2 of its last layer
+        { unsigned long long e = 0; for (int b = 0; b < nb; ++b) e = std::max(e, st[(((size_t)b * ncb + cb0) * nL + nL - 1) * 16 + 8]); pass0 = (double)e - (double)first; }
+        printf("first B1 of the launch -> last draw: %.1f us (kernel: see above); first pass (layers only): %.1f us\n",
+               ((double)last - (double)first) / 100.0, pass0 / 100.0);
+    }
     printf("head + draw + code hand-off between two steps: %.2f us\n", gap / gc / 100.0);
     {   // inside that gap (gathering wave 0): chip-wide medians relative to the last workgroup's W2 of the step
         const char* dn[5] = {"head input gathered (B5)", "logits gathered", "argmax known", "top-p cut known", "code drawn"};
