@@ -355,46 +355,31 @@ __device__ __forceinline__ void eng_gather_x(const EngRelay& rl, const unsigned*
 // Two vectors of the same length n (n % 256 == 0) gathered as ONE list of 2 * npiece pieces (the two rows of the fast
 // loop's first pass): piece P < npiece belongs to vector 0, the others to vector 1.
 struct EngSrc2 { const unsigned* g[2]; float* dst[2]; unsigned tag[2]; };
-__device__ __forceinline__ void eng_ld6_sc1(const void* p0, const void* p1, const void* p2, const void* p3, const void* p4, const void* p5,
-                                            U4& a, U4& b, U4& c, U4& d, U4& e, U4& f) {
-    asm volatile("global_load_dwordx4 %0, %6, off " ENG_POLL_BITS "\n\tglobal_load_dwordx4 %1, %7, off " ENG_POLL_BITS "\n\t"
-                 "global_load_dwordx4 %2, %8, off " ENG_POLL_BITS "\n\tglobal_load_dwordx4 %3, %9, off " ENG_POLL_BITS "\n\t"
-                 "global_load_dwordx4 %4, %10, off " ENG_POLL_BITS "\n\tglobal_load_dwordx4 %5, %11, off " ENG_POLL_BITS "\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f)
-                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5) : "memory");
-}
 __device__ __forceinline__ void eng_gather2(const EngSrc2& S, long delta, int n, int gw, int ngw, int lane, unsigned* ctl, int* dead,
                                             int where) {
-    // up to SIX pieces per wave and pass (two rows of a 3072-value vector = 24 pieces on 4 waves: one round of polls)
     const int npiece = n >> 8, NP = 2 * npiece;
     EngSpin sp{ctl, dead, 0, 0, where};
-    for (int p0 = gw; p0 < NP; p0 += 6 * ngw) {
-        int c[6], sx[6], ix[6];
-        const unsigned* ad[6];
-        unsigned tg[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            c[q] = p0 + q * ngw < NP ? p0 + q * ngw : p0;            // pieces past the end repeat the first (not stored)
-            sx[q] = c[q] >= npiece;
-            ix[q] = (c[q] - sx[q] * npiece) * 256 + lane * 4;
-            ad[q] = S.g[sx[q]] + delta + ix[q];
-            tg[q] = S.tag[sx[q]];
-        }
-        U4 v[6];
+    for (int p0 = gw; p0 < NP; p0 += 3 * ngw) {
+        const int c0 = p0;
+        const int c1 = p0 + ngw < NP ? p0 + ngw : c0;
+        const int c2 = p0 + 2 * ngw < NP ? p0 + 2 * ngw : c0;
+        const int s0 = c0 >= npiece, s1 = c1 >= npiece, s2 = c2 >= npiece;
+        const int i0 = (c0 - s0 * npiece) * 256 + lane * 4, i1 = (c1 - s1 * npiece) * 256 + lane * 4, i2 = (c2 - s2 * npiece) * 256 + lane * 4;
+        const unsigned* a0 = S.g[s0] + delta + i0;
+        const unsigned* a1 = S.g[s1] + delta + i1;
+        const unsigned* a2 = S.g[s2] + delta + i2;
+        const unsigned t0 = S.tag[s0], t1 = S.tag[s1], t2 = S.tag[s2];
+        U4 a, b, c;
         for (;;) {
-            if (c[1] == c[0]) { eng_ld1_sc1(ad[0], v[0]); v[1] = v[2] = v[3] = v[4] = v[5] = v[0]; }
-            else if (c[3] == c[0]) { eng_ld3_sc1(ad[0], ad[1], ad[2], v[0], v[1], v[2]); v[3] = v[4] = v[5] = v[0]; }
-            else eng_ld6_sc1(ad[0], ad[1], ad[2], ad[3], ad[4], ad[5], v[0], v[1], v[2], v[3], v[4], v[5]);
-            bool ok = true;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) ok = ok && eng_tags_ok(v[q], tg[q]);
-            if (__all(ok)) break;
+            if (c1 == c0) { eng_ld1_sc1(a0, a); b = a; c = a; }
+            else eng_ld3_sc1(a0, a1, a2, a, b, c);
+            const bool oa = eng_tags_ok(a, t0), ob = c1 == c0 || eng_tags_ok(b, t1), oc = c2 == c0 || eng_tags_ok(c, t2);
+            if (__all(oa && ob && oc)) break;
             if (sp.give_up(lane)) return;
         }
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-            if (q == 0 || c[q] != c[0]) eng_unpack_to_lds(S.dst[sx[q]] + ix[q], v[q]);
+        eng_unpack_to_lds(S.dst[s0] + i0, a);
+        if (c1 != c0) eng_unpack_to_lds(S.dst[s1] + i1, b);
+        if (c2 != c0) eng_unpack_to_lds(S.dst[s2] + i2, c);
     }
 }
 __device__ __forceinline__ void eng_gather_x2(const EngRelay& rl, const EngSrc2& S, int n, int gw, int ngw, int lane, unsigned* ctl,
