@@ -1466,7 +1466,9 @@ struct SampBigP {
     SampP s;
     unsigned* hist;      // [M][65536 + 1024]: class counts, then counts per group of 64 classes
     SampCut* cut;        // [M]
-    unsigned* ticket;    // [M] arrival counter of samp_cut_fused_kernel (zero between launches)
+    unsigned* ticket;    // [M] arrival counter of samp_cut_fused_kernel / samp_tail_kernel (zero between launches)
+    unsigned* tail_pub;  // [M][nchunk] samp_tail_kernel: (generation << 12) | members of the cut class in the chunk
+    unsigned* tail_gen;  // [M] generation of the last completed samp_tail_kernel launch
     int* chunk_cnt;      // [M][nchunk]
     float* part_score;   // [M][nchunk]
     int* part_idx;       // [M][nchunk]
@@ -2067,6 +2069,116 @@ __global__ __launch_bounds__(256) void samp_finish_kernel(SampBigP b) {
     for (int w = 1; w < 4; ++w) t = better(t, ArgMax{red[w], redi[w]});
     __syncthreads();
     finish_draw<WT>(p, m, t.i, p.nf[m]);
+}
+
+// samp_count + samp_race + samp_finish of ONE row as one launch (batch-1 frames: three ~5 us launches and two launch
+// boundaries for ~3 us of work).  Block c counts the cut-class members of its chunk and publishes the count tagged with the
+// launch generation; it then waits for the counts of the chunks before it (chained look-back: every block of the grid is
+// resident - nchunk blocks of 256 threads - and depends only on lower block indices), runs samp_race_kernel's arithmetic
+// on its chunk, publishes its best (score, index), and the block whose ticket comes last reduces them and does the frame
+// bookkeeping (samp_finish_kernel).  Same decisions as the three kernels: counts are integers, the race and the final
+// arg-max are the same operations on the same values.
+template <typename WT>
+__global__ __launch_bounds__(256) void samp_tail_kernel(SampBigP b) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    __shared__ int wcnt[4];
+    __shared__ int last_s;
+    const SampP& p = b.s;
+    const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * 1024;
+    const float* L = p.logits + (size_t)m * p.ldl;
+    const int V = p.V;
+    const RowCtl ctl = p.ctl[m];
+    const int nfv = p.nf[m];
+    const SampCut cut = b.cut[m];
+    unsigned* pub = b.tail_pub + (size_t)m * b.nchunk;
+    const unsigned gen = (__hip_atomic_load(b.tail_gen + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u) & 0xfffffu;
+    // this thread owns 4 consecutive logits, so index order = thread order
+    float l[4];
+    bool member[4];
+    int mine = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = c0 + 4 * tid + e;
+        l[e] = i < V ? L[i] : -INFINITY;
+        member[e] = i < V && !cut.all_kept && (order_key(l[e]) >> 16) == cut.kstar;
+        mine += member[e] ? 1 : 0;
+    }
+    int incl = mine;  // inclusive prefix over lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wcnt[wave] = incl;
+    __syncthreads();
+    if (tid == 0)   // the chunk's member count, visible to the blocks after this one
+        __hip_atomic_store(pub + blockIdx.x, (gen << 12) | (unsigned)(wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // rank base: members of the cut class in earlier chunks (chained look-back)
+    float basef = 0.f;
+    for (int i = tid; i < (int)blockIdx.x; i += 256) {
+        unsigned v = 0;
+        for (long spin = 0; spin < (1l << 26); ++spin) {
+            v = __hip_atomic_load(pub + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((v >> 12) == gen) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        basef += (float)(v & 0xfffu);
+    }
+    basef = wave_sum(basef);
+    if (lane == 0) red[wave] = basef;
+    __syncthreads();
+    const int base = (int)(red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();
+    int rank = base + incl - mine;
+    for (int w = 0; w < wave; ++w) rank += wcnt[w];
+    const float* qrow = nullptr;
+    if (p.noise && nfv < p.noise_rows) qrow = p.noise + (size_t)nfv * p.noise_row_len + p.noise_off;
+    ArgMax best{-1.f, 0x7fffffff};
+    float q4[4];
+    draw_noise4(p, ctl, qrow, c0 + 4 * tid, nfv, m, V, q4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = c0 + 4 * tid + e;
+        if (i < V) {
+            bool keep = cut.all_kept || (order_key(l[e]) >> 16) > cut.kstar;
+            if (member[e]) { keep = rank < cut.nk; ++rank; }
+            const float prob = keep ? round_bf16(expf(round_bf16(l[e] / cut.Tc) - cut.Mt) / cut.Z2) : 0.f;
+            best = better(best, ArgMax{round_bf16(prob / round_bf16(q4[e])), i});
+        }
+    }
+    best = wave_argmax(best);
+    if (lane == 0) { red[wave] = best.v; redi[wave] = best.i; }
+    __syncthreads();
+    if (tid == 0) {
+        ArgMax t{red[0], redi[0]};
+        for (int w = 1; w < 4; ++w) t = better(t, ArgMax{red[w], redi[w]});
+        __hip_atomic_store(b.part_score + (size_t)m * b.nchunk + blockIdx.x, t.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(b.part_idx + (size_t)m * b.nchunk + blockIdx.x, t.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = atomicAdd(b.ticket + m, 1u);
+        last_s = tk == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    // ---- the block that arrived last: best over the chunks + frame bookkeeping
+    ArgMax fin{-2.f, 0x7fffffff};
+    for (int i = tid; i < b.nchunk; i += 256)
+        fin = better(fin, ArgMax{__hip_atomic_load(b.part_score + (size_t)m * b.nchunk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                 __hip_atomic_load(b.part_idx + (size_t)m * b.nchunk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)});
+    fin = wave_argmax(fin);
+    __syncthreads();
+    if (lane == 0) { red[wave] = fin.v; redi[wave] = fin.i; }
+    __syncthreads();
+    ArgMax t{red[0], redi[0]};
+    for (int w = 1; w < 4; ++w) t = better(t, ArgMax{red[w], redi[w]});
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(b.ticket + m, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(b.tail_gen + m, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    finish_draw<WT>(p, m, t.i, nfv);
 }
 
 }  // namespace ft

@@ -94,6 +94,8 @@ struct ft_ctx {
     // large-vocabulary sampler scratch
     unsigned* samp_hist = nullptr;
     unsigned* samp_ticket = nullptr;
+    unsigned* samp_tail_pub = nullptr;
+    unsigned* samp_tail_gen = nullptr;
     ft::SampCut* samp_cut = nullptr;
     int* samp_chunk_cnt = nullptr;
     float* samp_part_score = nullptr;

@@ -527,13 +527,17 @@ def test_large_vocabulary_sampler_vs_oracle(monkeypatch):
             cases.append((logits, window, q, tp, temp, rep, want))
     # "lds" (the default): everything in one block; "fused": histogram spread over ceil(V / 4096) blocks, cut search in the
     # last-arriving one (measured slower, opt-in); "global": the two-launch form
-    for mode in ("lds", "fused", "global"):
+    # "tail1": count + race + finish as one launch (chained look-back; opt-in, measured equal)
+    for mode in ("lds", "fused", "global", "tail1"):
         monkeypatch.delenv("FT_SAMPLER_GLOBAL_HIST", raising=False)
         monkeypatch.delenv("FT_SAMPLER_FUSED", raising=False)
+        monkeypatch.delenv("FT_SAMPLER_TAIL1", raising=False)
         if mode == "global":
             monkeypatch.setenv("FT_SAMPLER_GLOBAL_HIST", "1")
         elif mode == "fused":
             monkeypatch.setenv("FT_SAMPLER_FUSED", "1")
+        elif mode == "tail1":
+            monkeypatch.setenv("FT_SAMPLER_TAIL1", "1")
         eng, _ = make_pair(shape, "bf16")
         bad = []
         for ci, (logits, window, q, tp, temp, rep, want) in enumerate(cases):
