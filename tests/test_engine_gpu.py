@@ -86,6 +86,24 @@ def test_engine_feature_switches_keep_the_bits(monkeypatch, env):
     assert np.array_equal(ha.view(np.uint32), hb.view(np.uint32)), env
 
 
+@pytest.mark.parametrize("over", [dict(num_codebooks=2), dict(num_codebooks=3), dict(num_codebooks=7, n_fast_layer=1),
+                                  dict(n_fast_layer=3, fast_attention_qk_norm=True), dict(n_layer=1, num_codebooks=4)])
+def test_engine_other_depths_and_codebook_counts(monkeypatch, over):
+    """Edges of the fast loop's structure: two codebooks (the paired first pass is the whole loop, no table), three (one
+    table step), one / three fast layers (the row-0 tail skip sits on the last layer), q/k norms inside the fast attention,
+    a one-layer slow stack.  Each must still equal the launch path bit for bit."""
+    shape = dataclasses.replace(medium_shape(**over), max_seq_len=1024)
+    prompt = make_prompt(shape, 17, seed=21, n_vq=min(2, shape.num_codebooks)).numpy()
+    kw = dict(temperature=0.7, top_p=0.8, repetition_penalty=1.1)
+    tape = NoiseTape(shape, 24, seed=8)
+    _, a, la, ha = _run(monkeypatch, shape, False, prompt, 14, kw, tape)
+    fb, b, lb, hb = _run(monkeypatch, shape, True, prompt, 14, kw, tape)
+    assert fb == 3, fb
+    assert np.array_equal(a, b), over
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)), over
+    assert np.array_equal(ha.view(np.uint32), hb.view(np.uint32)), over
+
+
 def test_engine_long_run_crosses_the_tag_wrap(monkeypatch):
     """Hand-off tags are 15 bits of an epoch that advances by 64 per launch (two launches per frame): they repeat every
     256 frames.  700 sampled frames (three wraps) on the engine must still equal the launch path's, frame for frame - a
