@@ -37,6 +37,9 @@ struct GemvP {
     int N, K;
     int pro, epi;
     int nt;  // non-temporal weight loads
+    // vocabulary head at one row: rows are written through and counted per chunk of 4096 rows (done[(row >> 12) * 64 + wave % 64] += rows
+    // written), so samp_cut_kernel - running beside this launch on a forked stream - can walk the logits behind it
+    unsigned* done;
 };
 
 template <typename WT, int NT, int R>
@@ -137,8 +140,15 @@ __device__ __forceinline__ void gemv_finish(const GemvP& p, const int m, const i
                 if (bias) v += ld_elem(bias, row);
                 v = rb<ROUND>(v);
                 if (p.epi == EPI_RESID) v = rb<ROUND>(p.resid[(size_t)m * p.ldr + row] + v);
-                p.out[(size_t)m * p.ldo + row] = v;
+                if (p.done) __hip_atomic_store(&p.out[(size_t)m * p.ldo + row], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else p.out[(size_t)m * p.ldo + row] = v;
             }
+        }
+        if (p.done) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's rows have reached the memory side
+            // 64 counters per chunk (a chunk's ~1000 waves finish within a microsecond or two: one address would
+            // serialise their atomics - measured: the 53 us launch became ~300 us)
+            if (lane == 0) atomicAdd(p.done + (size_t)(row0 >> 12) * 64 + ((row0 / R) & 63), (unsigned)min(R, N - row0));
         }
     }
 }
@@ -1469,6 +1479,7 @@ struct SampBigP {
     unsigned* ticket;    // [M] arrival counter of samp_cut_fused_kernel / samp_tail_kernel (zero between launches)
     unsigned* tail_pub;  // [M][nchunk] samp_tail_kernel: (generation << 12) | members of the cut class in the chunk
     unsigned* tail_gen;  // [M] generation of the last completed samp_tail_kernel launch
+    unsigned* head_done; // samp_cut_kernel beside the head GEMV (one row): rows written per 4096-row chunk (GemvP::done), or nullptr
     int* chunk_cnt;      // [M][nchunk]
     float* part_score;   // [M][nchunk]
     int* part_idx;       // [M][nchunk]
@@ -1858,56 +1869,122 @@ static __global__ __launch_bounds__(1024) void samp_cut_kernel(SampBigP b) {
     const int* seq = p.seq + (size_t)m * R * p.cap;
     for (int i = tid; i < SAMP_TH_THREADS * SAMP_TH_ROW; i += 1024) cimg[i] = 0u;
     if (tid == 0) sh.ovf_n = 0;
-    if (nfv > 0) {   // repetition penalty (inference.py:38-46): gather all, then scatter (duplicates write the same value)
-        const int it = nfv - 1;
-        const int ws = it < 16 ? 0 : it - 16;
-        const int npen = p.cb == 0 ? R : 16;
-        if (tid < npen) {
-            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
-            pen_id[tid] = -1;
-            if (id >= 0 && id < V) {
-                const float sv = L[id];
-                pen_id[tid] = id;
-                pen_val[tid] = sv < 0.f ? round_bf16(sv * ctl.rep) : round_bf16(sv / ctl.rep);
-            }
-        }
-        __syncthreads();
-        if (tid < npen && pen_id[tid] >= 0) L[pen_id[tid]] = pen_val[tid];
-    }
-    if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end < V) L[p.im_end] = -INFINITY;
-    __syncthreads();
+    const bool ov = b.head_done != nullptr;   // the head GEMV is still writing L: walk behind its per-chunk counters
+    const int npen = nfv > 0 ? (p.cb == 0 ? R : 16) : 0;
     auto count1 = [&](float v) {
         const unsigned k = order_key(v) >> 16;
         atomicAdd(&cimg[(k >> 6) * SAMP_TH_ROW + ((k & 63u) >> 1)], (k & 1u) ? 0x10000u : 1u);
     };
-    // 16 logits per thread and step, all four 16-byte loads issued before the first counter update (one block walks
-    // the whole row: a load-use chain per element would cost a memory round trip 152 times)
-    const int V16 = ((reinterpret_cast<uintptr_t>(L) & 15) == 0) ? (V / 16384) * 16384 : 0;
-    // two steps in flight: the loads of step i + 1 are issued before step i's counters are updated (the row was written by
-    // the head GEMV's blocks on all XCDs a moment ago, so every load is a trip to the memory side: 9 exposed round trips
-    // were ~25 of this kernel's 40 us)
-    float4 fa[4], fb[4];
-    auto ld16 = [&](float4 (&f)[4], int base) {
+    if (!ov) {
+        if (nfv > 0) {   // repetition penalty (inference.py:38-46): gather all, then scatter (duplicates write the same value)
+            const int it = nfv - 1;
+            const int ws = it < 16 ? 0 : it - 16;
+            if (tid < npen) {
+                const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
+                pen_id[tid] = -1;
+                if (id >= 0 && id < V) {
+                    const float sv = L[id];
+                    pen_id[tid] = id;
+                    pen_val[tid] = sv < 0.f ? round_bf16(sv * ctl.rep) : round_bf16(sv / ctl.rep);
+                }
+            }
+            __syncthreads();
+            if (tid < npen && pen_id[tid] >= 0) L[pen_id[tid]] = pen_val[tid];
+        }
+        if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end < V) L[p.im_end] = -INFINITY;
+        __syncthreads();
+        // 16 logits per thread and step, all four 16-byte loads issued before the first counter update (one block walks
+        // the whole row: a load-use chain per element would cost a memory round trip 152 times)
+        const int V16 = ((reinterpret_cast<uintptr_t>(L) & 15) == 0) ? (V / 16384) * 16384 : 0;
+        // two steps in flight: the loads of step i + 1 are issued before step i's counters are updated
+        float4 fa[4], fb[4];
+        auto ld16 = [&](float4 (&f)[4], int base) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) f[u] = *reinterpret_cast<const float4*>(L + base + u * 4096 + tid * 4);
-    };
-    auto cnt16 = [&](const float4 (&f)[4]) {
+            for (int u = 0; u < 4; ++u) f[u] = *reinterpret_cast<const float4*>(L + base + u * 4096 + tid * 4);
+        };
+        auto cnt16 = [&](const float4 (&f)[4]) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { count1(f[u].x); count1(f[u].y); count1(f[u].z); count1(f[u].w); }
-    };
-    if (V16 > 0) ld16(fa, 0);
-    for (int base = 0; base < V16; base += 32768) {
-        if (base + 16384 < V16) ld16(fb, base + 16384);
-        cnt16(fa);
-        if (base + 32768 < V16) ld16(fa, base + 32768);
-        if (base + 16384 < V16) cnt16(fb);
-    }
-    for (int base = V16; base < V; base += 4096) {   // tail (and unaligned rows): 4 scalar loads in flight
-        float f[4];
+            for (int u = 0; u < 4; ++u) { count1(f[u].x); count1(f[u].y); count1(f[u].z); count1(f[u].w); }
+        };
+        if (V16 > 0) ld16(fa, 0);
+        for (int base = 0; base < V16; base += 32768) {
+            if (base + 16384 < V16) ld16(fb, base + 16384);
+            cnt16(fa);
+            if (base + 32768 < V16) ld16(fa, base + 32768);
+            if (base + 16384 < V16) cnt16(fb);
+        }
+        for (int base = V16; base < V; base += 4096) {   // tail (and unaligned rows): 4 scalar loads in flight
+            float f[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = base + u * 1024 + tid; f[u] = i < V ? L[i] : 0.f; }
+            for (int u = 0; u < 4; ++u) { const int i = base + u * 1024 + tid; f[u] = i < V ? L[i] : 0.f; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (base + u * 1024 + tid < V) count1(f[u]);
+            for (int u = 0; u < 4; ++u) if (base + u * 1024 + tid < V) count1(f[u]);
+        }
+    } else {
+        // ---- beside the head GEMV: a range of the row is read once the GEMV's counters say it is complete (the rows were
+        // written through); penalty / EOS ban are applied per range, gather first, then scatter, as above.  All accesses to
+        // L go past this CU's L1 and this XCD's stale L2 lines (agent scope).
+        if (tid < 32) pen_id[tid] = -1;
+        if (tid < npen) {
+            const int it = nfv - 1;
+            const int ws = it < 16 ? 0 : it - 16;
+            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
+            if (id >= 0 && id < V) pen_id[tid] = id;
+        }
+        __syncthreads();
+        auto ready = [&](int lo, int hi) {
+            const int cfirst = lo >> 12, nck = ((hi - 1) >> 12) - cfirst + 1;      // <= 4 chunks: <= 256 counters
+            if (tid < 64) {
+                const unsigned want = (unsigned)(hi - lo);
+                const unsigned* cw = b.head_done + (size_t)cfirst * 64 + tid * 4;
+                const bool on = tid * 4 < nck * 64;
+                for (int spin = 0; spin < (1 << 17); ++spin) {      // (bounded: ~0.1 s; a frame then fails its parity test instead of hanging)
+                    U4 q{0u, 0u, 0u, 0u};
+                    if (on) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(cw) : "memory");
+                    const float got = wave_sum((float)(q.x + q.y + q.z + q.w));     // (<= 16 384: exact)
+                    if (got >= (float)want) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (on) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(cw), "v"(U4{0u, 0u, 0u, 0u}) : "memory");   // for the next frame
+            }
+            __syncthreads();
+            const int id = tid < npen ? pen_id[tid] : -1;
+            const bool mine = id >= lo && id < hi;
+            if (mine) {
+                const float sv = __hip_atomic_load(L + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pen_val[tid] = sv < 0.f ? round_bf16(sv * ctl.rep) : round_bf16(sv / ctl.rep);
+            }
+            __syncthreads();
+            if (mine) __hip_atomic_store(L + id, pen_val[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end >= lo && p.im_end < hi)
+                __hip_atomic_store(L + p.im_end, -INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        const int V16 = ((reinterpret_cast<uintptr_t>(L) & 15) == 0) ? (V / 16384) * 16384 : 0;
+        for (int base = 0; base < V16; base += 16384) {
+            ready(base, base + 16384);
+            U4 q[4];
+            const float* src = L + base + tid * 4;
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                         "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])
+                         : "v"(src), "v"(src + 4096), "v"(src + 8192), "v"(src + 12288) : "memory");
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                count1(__uint_as_float(q[u].x)); count1(__uint_as_float(q[u].y));
+                count1(__uint_as_float(q[u].z)); count1(__uint_as_float(q[u].w));
+            }
+        }
+        if (V16 < V) ready(V16, V);
+        for (int base = V16; base < V; base += 4096) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * 1024 + tid;
+                if (i < V) count1(__hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+        }
     }
     __syncthreads();
     // my group: occupancy, highest occupied class, and the row total for the wrap check
@@ -1932,7 +2009,7 @@ static __global__ __launch_bounds__(1024) void samp_cut_kernel(SampBigP b) {
         if (tid < SAMP_TH_OVF) { exc_key[tid] = 0xffffffffu; exc_cnt[tid] = 0u; }
         __syncthreads();
         for (int i = tid; i < V; i += 1024) {
-            const unsigned k = order_key(L[i]) >> 16;
+            const unsigned k = order_key(ov ? __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : L[i]) >> 16;
             uint32_t* d = &cimg[(k >> 6) * SAMP_TH_ROW + ((k & 63u) >> 1)];
             const unsigned shft = (k & 1u) * 16u;
             for (;;) {

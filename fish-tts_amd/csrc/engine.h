@@ -94,6 +94,7 @@ struct ft_ctx {
     // large-vocabulary sampler scratch
     unsigned* samp_hist = nullptr;
     unsigned* samp_ticket = nullptr;
+    unsigned* head_done = nullptr;     // rows of the vocabulary row written so far, per 4096-row chunk (head GEMV -> samp_cut)
     unsigned* samp_tail_pub = nullptr;
     unsigned* samp_tail_gen = nullptr;
     ft::SampCut* samp_cut = nullptr;

@@ -218,6 +218,7 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     const size_t nchunk = ((size_t)c.vocab_size + 1023) / 1024;
     FT_TRY(dmalloc(ctx, &ctx->samp_hist, M * SAMP_HIST_STRIDE));
     FT_TRY(dmalloc(ctx, &ctx->samp_ticket, M));
+    FT_TRY(dmalloc(ctx, &ctx->head_done, (size_t)(c.vocab_size / 4096 + 6) * 64));
     FT_TRY(dmalloc(ctx, &ctx->samp_tail_pub, M * nchunk));
     FT_TRY(dmalloc(ctx, &ctx->samp_tail_gen, M));
     FT_HIP(ctx, hipMemset(ctx->samp_ticket, 0, M * sizeof(unsigned)));
@@ -291,6 +292,7 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     for (auto& l : ctx->layers) { if (l.bqkv_f32) hipFree(l.bqkv_f32); if (l.bo_f32) hipFree(l.bo_f32); }
     if (ctx->samp_hist) hipFree(ctx->samp_hist);
     if (ctx->samp_ticket) hipFree(ctx->samp_ticket);
+    if (ctx->head_done) hipFree(ctx->head_done);
     if (ctx->samp_tail_pub) hipFree(ctx->samp_tail_pub);
     if (ctx->samp_tail_gen) hipFree(ctx->samp_tail_gen);
     if (ctx->samp_cut) hipFree(ctx->samp_cut);
@@ -553,6 +555,8 @@ struct Launch {
     int pos_off;     // added to the device position (token-by-token prefill)
     hipError_t err = hipSuccess;
     bool gemv_only = false;  // measurement: enqueue only the weight-streaming GEMV launches of the frame
+    unsigned* head_done = nullptr;   // one row: the head GEMV counts written rows per 4096-row chunk here (samp_cut walks behind it)
+    int samp_phase = 0;              // enqueue_sample: 0 = everything, 1 = only the cut kernel (forked stream), 2 = everything after it
     bool xn_final = false;   // wide path: the last W2 GEMM's tail left the final-norm rows in mb_xn (consumed by the head)
     void chk() { hipError_t e = hipGetLastError(); if (e != hipSuccess && err == hipSuccess) err = e; }
 };
@@ -923,6 +927,7 @@ static void enqueue_head(Launch& L) {
     h.W = ctx->head; h.x = ctx->x + (size_t)L.m0 * c.dim; h.ldx = c.dim; h.gain = ctx->norm; h.eps = c.norm_eps;
     h.out = ctx->logits + (size_t)L.m0 * c.vocab_size; h.ldo = c.vocab_size; h.N = c.vocab_size; h.K = c.dim;
     h.pro = PRO_RMSNORM; h.epi = EPI_STORE; h.nt = ctx->nt_weights;
+    h.done = L.head_done;
     gemv<WT, ROUND>(L, h, rows_per_wave(h.N, L.M));
 }
 
@@ -972,7 +977,10 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
         // last (same image, same search).  Measured SLOWER than the one-block kernel (75 vs 40 us per draw: global atomics
         // and the ticket round trip cost more than 38 more CUs save), so it is not the default; kept with its test.
         const bool fused = !global_hist && getenv("FT_SAMPLER_FUSED") != nullptr;
-        if (fused) {
+        b.head_done = L.samp_phase == 1 ? L.head_done : nullptr;
+        if (L.samp_phase == 2) {
+            // (the cut kernel of this draw already ran beside the head GEMV)
+        } else if (fused) {
             samp_cut_fused_kernel<<<dim3((s.V + 4095) / 4096, L.M), SAMP_TH_THREADS, SAMP_TH_LDS, L.s>>>(b);
         } else if (!global_hist) {
             samp_cut_kernel<<<L.M, SAMP_TH_THREADS, SAMP_TH_LDS, L.s>>>(b);
@@ -984,7 +992,9 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
         // last block finishes).  Same draws, 5 launches per frame instead of 7 - and exactly the same time (0.1038 ms for head +
         // draw either way): a cross-block dependency costs a memory round trip, like a launch boundary inside a graph.
         const bool tail1 = getenv("FT_SAMPLER_TAIL1") != nullptr;   // read per enqueue: tests toggle it
-        if (tail1 && L.M == 1 && b.nchunk <= 1024) {
+        if (L.samp_phase == 1) {
+            // (count / race / finish follow on the main stream after the join)
+        } else if (tail1 && L.M == 1 && b.nchunk <= 1024) {
             b.tail_pub = ctx->samp_tail_pub + (size_t)m0 * b.nchunk; b.tail_gen = ctx->samp_tail_gen + m0;
             samp_tail_kernel<WT><<<gridc, 256, 0, L.s>>>(b);
         } else {
@@ -1157,8 +1167,34 @@ static void enqueue_frame_tail(Launch& L) {
         if (L2.err != hipSuccess) L.err = L2.err;
         hipEventRecord(ctx->ev_join, ctx->stream2);
     }
-    enqueue_head<WT, ROUND>(L);
-    enqueue_sample<WT, ROUND>(L, 0, ncb == 1);
+    // FT_CUT_BESIDE (opt-in): one row, bf16, the one-block vocabulary draw: its histogram + cut kernel (35 us, one CU) starts
+    // BESIDE the head GEMV (53 us, whole chip) on the second stream and walks the logits behind the GEMV's per-chunk
+    // counters; count / race / finish follow after the join.  Same image, same search: the draws do not change (tests).
+    // Measured: frame 1.416-1.419 ms against 1.412 ms serial - the GEMV's write-through rows + completion atomics and the
+    // walk's per-range flag polls cost what the overlap saves (with ONE counter per chunk the GEMV took ~300 us).
+    const bool cut_beside = ROUND && !fork && L.M == 1 && ctx->stream2 != nullptr && ctx->head_done != nullptr && !ctx->prof &&
+                            ctx->c.vocab_size > 1024 && !ctx->force_block_sampler && wide_batch(L) == false &&
+                            getenv("FT_SAMPLER_GLOBAL_HIST") == nullptr && getenv("FT_SAMPLER_FUSED") == nullptr &&
+                            getenv("FT_CUT_BESIDE") != nullptr;
+    if (cut_beside) {
+        hipEventRecord(ctx->ev_fork, L.s);
+        hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
+        Launch L2 = L;
+        L2.s = ctx->stream2; L2.samp_phase = 1; L2.head_done = ctx->head_done;
+        enqueue_sample<WT, ROUND>(L2, 0, ncb == 1);
+        if (L2.err != hipSuccess) L.err = L2.err;
+        hipEventRecord(ctx->ev_join, ctx->stream2);
+        L.head_done = ctx->head_done;
+        enqueue_head<WT, ROUND>(L);
+        L.head_done = nullptr;
+        hipStreamWaitEvent(L.s, ctx->ev_join, 0);
+        L.samp_phase = 2;
+        enqueue_sample<WT, ROUND>(L, 0, ncb == 1);
+        L.samp_phase = 0;
+    } else {
+        enqueue_head<WT, ROUND>(L);
+        enqueue_sample<WT, ROUND>(L, 0, ncb == 1);
+    }
     if (ROUND && !fork && eng_fast_ok(L)) { enqueue_fast_engine(L); return; }
     if (fork) hipStreamWaitEvent(L.s, ctx->ev_join, 0);
     else enqueue_fast_step<WT, ROUND>(L, 0);
