@@ -77,6 +77,8 @@ SYMBOLS = {
                                         C.POINTER(C.c_int32)]),
     "ft_sync": (C.c_int32, [_P]),
     "ft_ar_engine_state": (C.c_int32, [_P, _P, _P, _P]),
+    "ft_ar_frame_path": (C.c_char_p, [_P]),
+    "ft_test_engine_fault": (C.c_int32, [_P, C.c_int32, C.c_int32]),
     "ft_test_sample": (C.c_int32, [_P, _P, C.c_int32, C.POINTER(ft_sampling), _P, _P, _P]),
 }
 
@@ -85,18 +87,42 @@ HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-s
 SOURCES = ["engine.hip", "codec.hip"]
 
 
+def _deps(path: str, seen=None) -> set:
+    """The source plus every local header it includes (recursively)."""
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path) as f:
+        for line in f:
+            if line.startswith("#include \""):
+                _deps(os.path.join(os.path.dirname(path), line.split('"')[1]), seen)
+    return seen
+
+
 def build(force: bool = False) -> str:
-    """Compile the HIP library in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
-        [os.path.join(os.path.dirname(_HERE), "include", "fishtts_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    """Compile the HIP library in-tree with hipcc for gfx950 (cross-compiles without a GPU): one object per source,
+    stale ones rebuilt side by side, then linked."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + srcs + ["-o", LIB_PATH]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout[-4000:] + r.stderr[-8000:])
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    jobs, objs = [], []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(CSRC, s.replace(".hip", ".o"))
+        objs.append(obj)
+        newest = max(os.path.getmtime(d) for d in _deps(src))
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+            cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+            jobs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for cmd, p in jobs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out[-12000:])
+    if jobs or not os.path.exists(LIB_PATH) or any(os.path.getmtime(LIB_PATH) < os.path.getmtime(o) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + " ".join(cmd) + "\n" + r.stdout[-4000:] + r.stderr[-8000:])
     return LIB_PATH
 
 

@@ -141,6 +141,15 @@ class ARHipEngine:
     def finalize(self):
         self._check(self.lib.ft_finalize_weights(self._h), "ft_finalize_weights")
         self._loaded = True
+        logger.info("batch-1 decode frames: %s", self.frame_path())
+
+    def frame_path(self) -> str:
+        """Which path the batch-1 frames take (persistent frame engine or launches) and why."""
+        return self.lib.ft_ar_frame_path(self._h).decode()
+
+    def inject_engine_fault(self, which: int = 0, workgroup: int = 0) -> None:
+        """Test hook: the next slow-stack (0) / codebook-loop (1) engine launch loses one workgroup's rows and times out."""
+        self._check(self.lib.ft_test_engine_fault(self._h, which, workgroup), "ft_test_engine_fault")
 
     # ------------------------------------------------------------------ primitives
     @staticmethod
@@ -247,7 +256,8 @@ class ARHipEngine:
         return int(out[0])
 
     def engine_state(self):
-        """(flags, aborted, where) of the persistent frame engine: flags bit 0 = slow stack, bit 1 = fast loop."""
+        """(flags, time-outs recovered so far, phase of the last one) of the persistent frame engine: flags bit 0 = slow
+        stack, bit 1 = fast loop."""
         f, a, w = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         self._check(self.lib.ft_ar_engine_state(self._h, C.byref(f), C.byref(a), C.byref(w)), "ft_ar_engine_state")
         return f.value, a.value, w.value

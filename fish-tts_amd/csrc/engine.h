@@ -118,6 +118,14 @@ struct ft_ctx {
     bool eng_relay = true;        // per-XCD replicas of the hand-off buffers (FT_NO_RELAY: every workgroup polls the source)
     void* eng_qkv0_tab = nullptr;   // fast layer 0's q k v per codebook-embedding row (bf16 [fastV][qkvN])
     bool eng_pair = false;          // fast loop: positions 0 and 1 as two rows of the first pass
+    size_t eng_pool_bytes = 0, eng_gpart_bytes = 0, eng_fast_bytes = 0;   // hand-off allocations (zeroed again after an abort)
+    // A hand-off that timed out (ENG_CTL_ABORT) is survivable: the host clears the control words and the hand-off pools,
+    // redoes the affected frames on the launch path (eng_suspended) and turns the engine off for this context after
+    // ENG_MAX_STRIKES such events.  eng_why says, in words, which frame path this context takes and why.
+    bool eng_suspended = false;
+    int eng_strikes = 0, eng_last_where = 0;
+    bool eng_owner = false;         // this context holds its device's engine slot (one engine context per device and process)
+    std::string eng_why;
 
     std::map<int, hipGraphExec_t> graphs;
     std::map<int, int> graph_nodes;   // nodes of each captured frame graph (launches per frame)

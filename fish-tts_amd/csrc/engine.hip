@@ -8,6 +8,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -15,6 +16,7 @@
 using namespace ft;
 
 static std::string g_create_err;
+static void eng_release(ft_ctx* ctx);
 
 ft_status ft_fail(ft_ctx* ctx, ft_status code, const std::string& msg) {
     if (ctx) ctx->err = msg; else g_create_err = msg;
@@ -299,8 +301,7 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     if (ctx->samp_chunk_cnt) hipFree(ctx->samp_chunk_cnt);
     if (ctx->samp_part_score) hipFree(ctx->samp_part_score);
     if (ctx->samp_part_idx) hipFree(ctx->samp_part_idx);
-    { void* eb[] = {ctx->eng_layers, ctx->eng_flayers, ctx->eng_gx /* pool: gxb, gg, gy, gqkv live in it */,
-                    ctx->eng_gpart, ctx->eng_fast_g, ctx->eng_ctl, ctx->eng_qkv0_tab}; for (void* q : eb) if (q) hipFree(q); }
+    eng_release(ctx);
     if (ctx->h_pin) hipHostFree(ctx->h_pin);
     for (auto e : ctx->prof_ev) hipEventDestroy(e);
     codec_destroy(ctx);
@@ -433,13 +434,42 @@ static ft_status ar_finalize(ft_ctx* ctx) {
 // ------------------------------------------------------------------------------------------ frame engine (host side)
 // The engine is an instantiation for one shape class (dim = 1024, heads 16/8 x 128, ffn 3072 in bf16: openaudio-s1-mini's
 // widths at any depth); every other configuration keeps the launch path.  It needs every workgroup resident at once:
-// one per CU, sized by the device's CU count.
-static ft_status eng_setup(ft_ctx* ctx) {
+// one per CU, sized by the device's CU count - so only ONE context per device and process may run it (two would each
+// hold part of the CUs and time each other out), and nothing in here is fatal: whatever fails leaves the launch path.
+constexpr int ENG_MAX_STRIKES = 2;      // hand-off time-outs after which a context stops using the engine
+static std::mutex g_eng_mu;
+static std::map<int, ft_ctx*> g_eng_owner;      // device -> the context whose engine runs there
+
+static void eng_release(ft_ctx* ctx) {
+    void* eb[] = {ctx->eng_layers, ctx->eng_flayers, ctx->eng_gx /* pool: gxb, gg, gy, gqkv live in it */,
+                  ctx->eng_gpart, ctx->eng_fast_g, ctx->eng_ctl, ctx->eng_qkv0_tab};
+    for (void* q : eb) if (q) hipFree(q);
+    ctx->eng_layers = ctx->eng_flayers = nullptr;
+    ctx->eng_gx = ctx->eng_gqkv = ctx->eng_gy = ctx->eng_gxb = ctx->eng_gg = ctx->eng_fast_g = ctx->eng_ctl = nullptr;
+    ctx->eng_gpart = nullptr;
+    ctx->eng_qkv0_tab = nullptr;
+    ctx->eng_on = ctx->eng_fast_on = false;
+    if (ctx->eng_owner) {
+        std::lock_guard<std::mutex> lk(g_eng_mu);
+        auto it = g_eng_owner.find(ctx->device);
+        if (it != g_eng_owner.end() && it->second == ctx) g_eng_owner.erase(it);
+        ctx->eng_owner = false;
+    }
+}
+
+// false: `why` says what kept the engine off (allocations made so far are released by the caller)
+static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
     const ft_ar_config& c = ctx->c;
-    ctx->eng_on = false;
-    if (getenv("FT_NO_ENGINE") || c.dtype != FT_BF16) return FT_OK;
+    auto hip_ok = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        why = std::string(what) + ": " + hipGetErrorString(e);
+        (void)hipGetLastError();     // (not sticky for the launch path)
+        return false;
+    };
+    if (getenv("FT_NO_ENGINE")) { why = "FT_NO_ENGINE is set"; return false; }
+    if (c.dtype != FT_BF16) { why = "precision is not bf16"; return false; }
     hipDeviceProp_t prop;
-    FT_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (!hip_ok(hipGetDeviceProperties(&prop, ctx->device), "hipGetDeviceProperties")) return false;
     const int nb = prop.multiProcessorCount;
     const int HD = c.n_head * c.head_dim;
     const int qkvN = (c.n_head + 2 * c.n_local_heads) * c.head_dim;
@@ -448,9 +478,25 @@ static ft_status eng_setup(ft_ctx* ctx) {
                           c.n_head == 2 * c.n_local_heads && c.fast_dim == c.dim && c.n_layer >= 1 && c.n_layer < ENG_EPOCH_STEP &&
                           per(qkvN) <= ENG_SQ * ENG_CW && per(c.dim) <= ENG_SO * ENG_CW && per(c.intermediate_size) <= ENG_SF * ENG_CW &&
                           qkvN % (4 * nb) == 0 && c.dim % (4 * nb) == 0 && c.intermediate_size % (4 * nb) == 0 && per(qkvN) <= ENG_LINE &&
-                          c.n_local_heads * ctx->nsplit_max <= nb && c.head_dim % (4 * ctx->nsplit_max) == 0 &&
-                          (size_t)prop.sharedMemPerBlock >= 0 && nb >= 64;
-    if (!shape_ok) return FT_OK;
+                          c.n_local_heads * ctx->nsplit_max <= nb && c.head_dim % (4 * ctx->nsplit_max) == 0 && nb >= 64;
+    if (!shape_ok) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "widths outside the engine's instantiation (dim %d, heads %d/%d x %d, ffn %d, fast_dim %d on %d CUs; "
+                 "built for 1024, 16/8 x 128, 3072, 1024 on 128 or 256 CUs)", c.dim, c.n_head, c.n_local_heads, c.head_dim,
+                 c.intermediate_size, c.fast_dim, nb);
+        why = buf;
+        return false;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_eng_mu);
+        auto it = g_eng_owner.find(ctx->device);
+        if (it != g_eng_owner.end() && it->second != ctx) {
+            why = "another context of this process already runs the frame engine on this device (its workgroups need every CU)";
+            return false;
+        }
+        g_eng_owner[ctx->device] = ctx;
+        ctx->eng_owner = true;
+    }
     ctx->eng_nb = nb;
     std::vector<EngLayer> h(c.n_layer);
     for (int i = 0; i < c.n_layer; ++i) {
@@ -459,33 +505,41 @@ static ft_status eng_setup(ft_ctx* ctx) {
                         (const bf16_t*)l.kn, (const bf16_t*)l.wo, (const bf16_t*)l.bo, (const bf16_t*)l.ffn_norm,
                         (const bf16_t*)l.w13, (const bf16_t*)l.w2, (bf16_t*)l.kc, (bf16_t*)l.vc};
     }
-    FT_HIP(ctx, hipMalloc((void**)&ctx->eng_layers, h.size() * sizeof(EngLayer)));
-    FT_HIP(ctx, hipMemcpy(ctx->eng_layers, h.data(), h.size() * sizeof(EngLayer), hipMemcpyHostToDevice));
-    auto zalloc = [&](void** q, size_t bytes) -> ft_status {
-        FT_HIP(ctx, hipMalloc(q, bytes));
-        FT_HIP(ctx, hipMemset(*q, 0, bytes));
-        return FT_OK;
+    if (!hip_ok(hipMalloc((void**)&ctx->eng_layers, h.size() * sizeof(EngLayer)), "hipMalloc(engine layer table)")) return false;
+    if (!hip_ok(hipMemcpy(ctx->eng_layers, h.data(), h.size() * sizeof(EngLayer), hipMemcpyHostToDevice), "hipMemcpy(engine layer table)")) return false;
+    auto zalloc = [&](void** q, size_t bytes, const char* what) {
+        return hip_ok(hipMalloc(q, bytes), what) && hip_ok(hipMemset(*q, 0, bytes), what);
     };
     const size_t L = c.n_layer;
     const size_t VB = (size_t)nb * ENG_LINE * 4;   // bytes reserved per hand-off vector (one 128-byte line per workgroup)
     // one pool [gx | gxb | gg | gy | gqkv], followed by the eight per-XCD replicas of it (XCD relay)
     const size_t pool_words = ((L + 1) * VB + 3 * L * VB + L * HD * 4) / 4;
     ctx->eng_relay = getenv("FT_NO_RELAY") == nullptr;
-    FT_TRY(zalloc((void**)&ctx->eng_gx, pool_words * 4 * (ctx->eng_relay ? 9 : 1)));
+    ctx->eng_pool_bytes = pool_words * 4 * (ctx->eng_relay ? 9 : 1);
+    if (!zalloc((void**)&ctx->eng_gx, ctx->eng_pool_bytes, "hipMalloc(engine hand-off pool)")) return false;
     ctx->eng_pool_words = pool_words;
     ctx->eng_gxb = ctx->eng_gx + (L + 1) * (VB / 4);
     ctx->eng_gg = ctx->eng_gxb + L * (VB / 4);
     ctx->eng_gy = ctx->eng_gg + L * (VB / 4);
     ctx->eng_gqkv = ctx->eng_gy + L * HD;
-    FT_TRY(zalloc((void**)&ctx->eng_gpart, L * c.n_head * ctx->nsplit_max * (size_t)(c.head_dim + 2) * 8));
-    FT_TRY(zalloc((void**)&ctx->eng_ctl, ENG_CTL_WORDS * 4));
+    ctx->eng_gpart_bytes = L * c.n_head * ctx->nsplit_max * (size_t)(c.head_dim + 2) * 8;
+    if (!zalloc((void**)&ctx->eng_gpart, ctx->eng_gpart_bytes, "hipMalloc(engine split partials)")) return false;
+    if (!zalloc((void**)&ctx->eng_ctl, ENG_CTL_WORDS * 4, "hipMalloc(engine control words)")) return false;
     const int G = c.n_head / c.n_local_heads, hd = c.head_dim, NSLOT = 4 * (64 / (hd >> 3));
     size_t fl = (size_t)c.dim * 2 + HD + c.intermediate_size + (size_t)(G + 2) * hd + (size_t)G * hd + 2 * hd +
                 (size_t)NSLOT * G * 2 + (size_t)NSLOT * G * hd + 64 * 6 + ENG_MAX_OUT + 8;
     ctx->eng_lds_slow = std::max(fl * sizeof(float), (size_t)82 * 1024);   // > half the CU's LDS: one workgroup per CU
-    FT_HIP(ctx, hipFuncSetAttribute((const void*)slow_engine_kernel<2, 4, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)ctx->eng_lds_slow));
+    const size_t lds_cap = prop.maxSharedMemoryPerMultiProcessor;
+    if (ctx->eng_lds_slow > lds_cap) { why = "the slow stack's LDS need exceeds the CU's"; return false; }
+    if (!hip_ok(hipFuncSetAttribute((const void*)slow_engine_kernel<2, 4, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)ctx->eng_lds_slow), "hipFuncSetAttribute(slow_engine_kernel)")) return false;
+    // every workgroup must be resident at once: ask the runtime whether one fits a CU at all (registers, LDS, waves)
+    int occ = 0;
+    if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)slow_engine_kernel<2, 4, 6, 2>, ENG_THREADS,
+                                                             ctx->eng_lds_slow), "hipOccupancyMaxActiveBlocksPerMultiprocessor")) return false;
+    if (occ < 1) { why = "a slow-stack workgroup does not fit one CU (occupancy query)"; return false; }
     ctx->eng_on = true;
+    why = "slow stack on the frame engine";
 
     // ---- fast codebook loop
     const int HDf = c.fast_n_head * c.fast_head_dim;
@@ -496,7 +550,9 @@ static ft_status eng_setup(ft_ctx* ctx) {
                          per(fqkvN) <= ENG_FQ * ENG_CW && per(c.fast_dim) <= ENG_FO * ENG_CW && per(c.fast_intermediate_size) <= ENG_FF * ENG_CW &&
                          per(ctx->fastV) <= ENG_FO * ENG_CW && per(fqkvN) <= ENG_LINE && ctx->fastV <= 1024 && c.codebook_size <= 65536 &&
                          !ctx->force_block_sampler && !ctx->wave_sampler;
-    if (!fast_ok) return FT_OK;
+    if (!fast_ok) { why += "; fast loop on launches (FT_NO_FAST_ENGINE, or fast widths outside 1024 / 16 x 64 / 3072, <= 10 codebooks)"; return true; }
+    // from here on a failure keeps the slow engine and leaves the fast loop on launches
+    auto fast_off = [&](const std::string& w2) { why += "; fast loop on launches (" + w2 + ")"; return true; };
     std::vector<EngLayer> hf(c.n_fast_layer);
     for (int i = 0; i < c.n_fast_layer; ++i) {
         const FtLayer& l = ctx->flayers[i];
@@ -504,34 +560,65 @@ static ft_status eng_setup(ft_ctx* ctx) {
                          (const bf16_t*)l.kn, (const bf16_t*)l.wo, (const bf16_t*)l.bo, (const bf16_t*)l.ffn_norm,
                          (const bf16_t*)l.w13, (const bf16_t*)l.w2, nullptr, nullptr};
     }
-    FT_HIP(ctx, hipMalloc((void**)&ctx->eng_flayers, hf.size() * sizeof(EngLayer)));
-    FT_HIP(ctx, hipMemcpy(ctx->eng_flayers, hf.data(), hf.size() * sizeof(EngLayer), hipMemcpyHostToDevice));
+    std::string w2;
+    auto hip_ok2 = [&](hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        w2 = std::string(what) + ": " + hipGetErrorString(e);
+        (void)hipGetLastError();
+        return false;
+    };
+    if (!hip_ok2(hipMalloc((void**)&ctx->eng_flayers, hf.size() * sizeof(EngLayer)), "hipMalloc(fast layer table)")) return fast_off(w2);
+    if (!hip_ok2(hipMemcpy(ctx->eng_flayers, hf.data(), hf.size() * sizeof(EngLayer), hipMemcpyHostToDevice), "hipMemcpy(fast layer table)")) return fast_off(w2);
     const size_t nLf = c.n_fast_layer;
     // [2 parities]: gx (nLf + 1), gqkv, gxb, gg (nLf each), glog (1); then one line per codebook for the drawn codes
     ctx->eng_fast_words = (2 * ((nLf + 1) + 3 * nLf + 1)) * (VB / 4) + (size_t)c.num_codebooks * ENG_LINE;
-    FT_TRY(zalloc((void**)&ctx->eng_fast_g, ctx->eng_fast_words * 4 * (ctx->eng_relay ? 9 : 1)));
+    ctx->eng_fast_bytes = ctx->eng_fast_words * 4 * (ctx->eng_relay ? 9 : 1);
+    if (!hip_ok2(hipMalloc((void**)&ctx->eng_fast_g, ctx->eng_fast_bytes), "hipMalloc(fast hand-off pool)") ||
+        !hip_ok2(hipMemset(ctx->eng_fast_g, 0, ctx->eng_fast_bytes), "hipMemset(fast hand-off pool)")) return fast_off(w2);
     const int kvw = c.fast_n_local_heads * c.fast_head_dim;
     // codebook positions 0 and 1 as two rows of one pass when the second row's buffers fit the CU's LDS
     ctx->eng_pair = getenv("FT_NO_PAIR") == nullptr &&
-                    eng_fast_lds_bytes(c.fast_dim, fqkvN, HDf, c.fast_intermediate_size, ctx->fastV, (int)nLf, c.num_codebooks, kvw, true) <= 160 * 1024;
+                    eng_fast_lds_bytes(c.fast_dim, fqkvN, HDf, c.fast_intermediate_size, ctx->fastV, (int)nLf, c.num_codebooks, kvw, true) <= lds_cap;
     ctx->eng_lds_fast = eng_fast_lds_bytes(c.fast_dim, fqkvN, HDf, c.fast_intermediate_size, ctx->fastV, (int)nLf, c.num_codebooks, kvw, ctx->eng_pair);
-    if (ctx->eng_lds_fast > 160 * 1024) return FT_OK;
+    if (ctx->eng_lds_fast > lds_cap) return fast_off("the codebook loop's LDS need exceeds the CU's");
     ctx->eng_lds_fast = std::max(ctx->eng_lds_fast, (size_t)82 * 1024);
-    FT_HIP(ctx, hipFuncSetAttribute((const void*)fast_engine_kernel<2, 2, 6, 10, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)ctx->eng_lds_fast));
+    if (!hip_ok2(hipFuncSetAttribute((const void*)fast_engine_kernel<2, 2, 6, 10, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)ctx->eng_lds_fast), "hipFuncSetAttribute(fast_engine_kernel)")) return fast_off(w2);
+    occ = 0;
+    if (!hip_ok2(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)fast_engine_kernel<2, 2, 6, 10, 64>, ENG_THREADS,
+                                                              ctx->eng_lds_fast), "hipOccupancyMaxActiveBlocksPerMultiprocessor")) return fast_off(w2);
+    if (occ < 1) return fast_off("a codebook-loop workgroup does not fit one CU (occupancy query)");
     // layer 0's q k v of every codebook-embedding row a draw can select (codes < fastV): 4 MB at the s1-mini widths
     if (getenv("FT_NO_QKV0") == nullptr && c.num_codebooks > 2) {
         const size_t tb = (size_t)ctx->fastV * fqkvN * sizeof(bf16_t);
-        FT_HIP(ctx, hipMalloc((void**)&ctx->eng_qkv0_tab, tb));
+        if (!hip_ok2(hipMalloc((void**)&ctx->eng_qkv0_tab, tb), "hipMalloc(layer-0 q k v table)")) return fast_off(w2);
         const FtLayer& l0 = ctx->flayers[0];
         const size_t lds = ((size_t)c.fast_dim + ENG_MAX_OUT) * sizeof(float);
         eng_qkv0_table_kernel<2><<<dim3(fqkvN / (ENG_FQ * ENG_CW), 16), ENG_CW * 64, lds, ctx->stream>>>(
             (const bf16_t*)l0.wqkv, (const bf16_t*)l0.bqkv, (const bf16_t*)l0.attn_norm, (const bf16_t*)ctx->fast_emb,
             (bf16_t*)ctx->eng_qkv0_tab, c.fast_dim, fqkvN, ctx->fastV, c.norm_eps);
-        FT_HIP(ctx, hipGetLastError());
-        FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (!hip_ok2(hipGetLastError(), "eng_qkv0_table_kernel") || !hip_ok2(hipStreamSynchronize(ctx->stream), "eng_qkv0_table_kernel")) {
+            hipFree(ctx->eng_qkv0_tab); ctx->eng_qkv0_tab = nullptr;
+            return fast_off(w2);
+        }
     }
     ctx->eng_fast_on = true;
+    why = "slow stack and codebook loop on the frame engine";
+    return true;
+}
+
+static ft_status eng_setup(ft_ctx* ctx) {
+    ctx->eng_on = ctx->eng_fast_on = false;
+    std::string why;
+    if (!eng_setup_try(ctx, why)) {
+        eng_release(ctx);
+        ctx->eng_why = "launch path: " + why;
+    } else {
+        char buf[64];
+        snprintf(buf, sizeof buf, " (%d workgroups)", ctx->eng_nb);
+        ctx->eng_why = why + buf;
+    }
+    if (getenv("FT_LOG")) fprintf(stderr, "fish_tts_amd: batch-1 decode frames: %s\n", ctx->eng_why.c_str());
     return FT_OK;
 }
 
@@ -580,13 +667,13 @@ static bool wide_batch(const Launch& L) {
 
 static bool eng_slow_ok(const Launch& L) {
     const ft_ctx* ctx = L.ctx;
-    return ctx->eng_on && L.M == 1 && !L.gemv_only && !ctx->prof && ctx->c.n_local_heads * ctx->nsplit <= ctx->eng_nb &&
+    return ctx->eng_on && !ctx->eng_suspended && L.M == 1 && !L.gemv_only && !ctx->prof && ctx->c.n_local_heads * ctx->nsplit <= ctx->eng_nb &&
            ctx->c.head_dim % (4 * ctx->nsplit) == 0;
 }
 
 static bool eng_fast_ok(const Launch& L) {
     const ft_ctx* ctx = L.ctx;
-    return ctx->eng_fast_on && L.M == 1 && !L.gemv_only && !ctx->prof && !ctx->fork_fast0;
+    return ctx->eng_fast_on && !ctx->eng_suspended && L.M == 1 && !L.gemv_only && !ctx->prof && !ctx->fork_fast0;
 }
 
 // The whole codebook loop of one frame (steps 0 .. num_codebooks-1 with their draws) as one launch; runs after the
@@ -1211,7 +1298,8 @@ static void enqueue_slow_only(Launch& L, const int* toks, long trs, long tms, in
 }
 
 // ------------------------------------------------------------------------------------------ AR API
-static ft_status eng_check(ft_ctx* ctx);
+static ft_status eng_recover(ft_ctx* ctx, bool* aborted);
+static bool eng_in_use(const ft_ctx* ctx);
 static ft_status ar_ready(ft_ctx* ctx) {
     if (!ctx) return FT_ERR_ARG;
     if (!ctx->has_ar) return ft_fail(ctx, FT_ERR_STATE, "context was created without an AR config");
@@ -1384,6 +1472,7 @@ extern "C" ft_status ft_ar_prefill_at(ft_ctx* ctx, int32_t slot, const int32_t* 
     FT_TRY(upload_ctl(ctx, slot, 1, sp));
     FT_HIP(ctx, hipMemcpyAsync(ctx->d_prompt, prompt, (size_t)R * Lp * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     Launch L{ctx, ctx->stream, slot, 1, 0};
+    const bool on_engine = eng_in_use(ctx);
     if (!ctx->prefill_v0) {
         prefill_gemm(L, slot, Lp, pos0);
     } else {
@@ -1397,6 +1486,22 @@ extern "C" ft_status ft_ar_prefill_at(ft_ctx* ctx, int32_t slot, const int32_t* 
         enqueue_frame(L, ctx->d_prompt, Lp, 0, Lp - 1);
     }
     if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("prefill launch: ") + hipGetErrorString(L.err));
+    if (on_engine) {
+        // the first frame's codebook loop (and, position by position, its slow pass) ran on the frame engine: a hand-off
+        // time-out there must not pass for a first frame - redo that frame on the launch path (the prompt's K/V and the
+        // last position's hidden state are untouched by it)
+        FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        bool aborted = false;
+        FT_TRY(eng_recover(ctx, &aborted));
+        if (aborted) {
+            FT_TRY(ft_ar_reset(ctx, slot));
+            ctx->eng_suspended = true;
+            if (!ctx->prefill_v0) { enqueue_fproj<bf16_t, true>(L); enqueue_frame_tail<bf16_t, true>(L); }
+            else enqueue_frame(L, ctx->d_prompt, Lp, 0, Lp - 1);
+            ctx->eng_suspended = false;
+            if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("prefill launch: ") + hipGetErrorString(L.err));
+        }
+    }
     // finalize() advanced pos 0 -> 1; the next input position is pos0 + Lp
     ctx->h_pin[0] = pos0 + Lp;
     FT_HIP(ctx, hipMemcpyAsync(ctx->d_pos + slot, ctx->h_pin, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -1445,9 +1550,25 @@ extern "C" ft_status ft_ar_first_frames(ft_ctx* ctx, int32_t slot0, int32_t n, c
     const int R = c.num_codebooks + 1;
     FT_TRY(upload_ctl(ctx, slot0, n, sp));
     Launch L{ctx, ctx->stream, slot0, n, 0};
-    if (c.dtype == FT_BF16) { enqueue_fproj<bf16_t, true>(L); enqueue_frame_tail<bf16_t, true>(L); }
-    else { enqueue_fproj<float, false>(L); enqueue_frame_tail<float, false>(L); }
+    const bool on_engine = n == 1 && eng_in_use(ctx);
+    auto tail = [&]() {
+        if (c.dtype == FT_BF16) { enqueue_fproj<bf16_t, true>(L); enqueue_frame_tail<bf16_t, true>(L); }
+        else { enqueue_fproj<float, false>(L); enqueue_frame_tail<float, false>(L); }
+    };
+    tail();
     if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("first-frame launch: ") + hipGetErrorString(L.err));
+    if (on_engine) {      // as in ft_ar_prefill_at: a timed-out codebook loop is redone on the launch path
+        FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        bool aborted = false;
+        FT_TRY(eng_recover(ctx, &aborted));
+        if (aborted) {
+            FT_TRY(ft_ar_reset(ctx, slot0));
+            ctx->eng_suspended = true;
+            tail();
+            ctx->eng_suspended = false;
+            if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("first-frame launch: ") + hipGetErrorString(L.err));
+        }
+    }
     // finalize() advanced every position 0 -> 1; the next input position of a slot is the end of its prompt
     FT_HIP(ctx, hipMemcpyAsync(ctx->d_pos + slot0, next_pos, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     FT_HIP(ctx, hipMemcpyAsync(out_frames, ctx->d_tok + (size_t)slot0 * R, (size_t)n * R * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1520,9 +1641,15 @@ extern "C" void ft_ar_kv_free(ft_ctx* ctx, ft_kv_snapshot* snap) {
     delete snap;
 }
 
+// the captured grids depend on the batch width, on the KV split count and on whether the frame engine serves the frame
+static int graph_key(const ft_ctx* ctx, int M, int frames) {
+    const bool eng = (ctx->eng_on || ctx->eng_fast_on) && !ctx->eng_suspended;
+    return (M * 64 + ctx->nsplit) + (frames > 1 ? frames * (1 << 20) : 0) + (eng ? (1 << 28) : 0);
+}
+
 static ft_status get_graph(ft_ctx* ctx, int M, hipGraphExec_t* out, int frames = 1) {
     // the captured grids depend on the batch width and on the KV split count; `frames` decode frames per graph
-    const int key = (M * 64 + ctx->nsplit) + (frames > 1 ? frames * (1 << 20) : 0);
+    const int key = graph_key(ctx, M, frames);
     auto it = ctx->graphs.find(key);
     if (it != ctx->graphs.end()) { *out = it->second; return FT_OK; }
     const int R = ctx->c.num_codebooks + 1;
@@ -1581,18 +1708,17 @@ extern "C" ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames,
         const int want = pos_end <= 768 ? 8 : pos_end <= 3072 ? 16 : 32;
         ctx->nsplit = std::min(want, ctx->nsplit_max);
     }
-    hipGraphExec_t exec = nullptr, exec_k = nullptr, exec_4 = nullptr;
     const bool eager = getenv("FT_NO_GRAPH") != nullptr;
     // several frames per graph launch where a burst allows: the gap between two graph launches is ~7 us (measured: 687 ->
     // 692 tok/s at 16 frames per graph; the frames are the same launches in the same order).  FT_GRAPH_FRAMES=1 turns it off.
     static const int gk = getenv("FT_GRAPH_FRAMES") ? std::max(1, atoi(getenv("FT_GRAPH_FRAMES"))) : 16;
     const int first_burst = std::min(poll, budget);
-    if (!eager && budget > 0) FT_TRY(get_graph(ctx, nslots, &exec));
-    if (!eager && gk > 1 && first_burst >= gk) FT_TRY(get_graph(ctx, nslots, &exec_k, gk));
-    if (!eager && gk > 4 && first_burst >= 4) FT_TRY(get_graph(ctx, nslots, &exec_4, 4));
-    int done_frames = 0;
-    while (done_frames < budget) {
-        const int burst = std::min(poll, budget - done_frames);
+    // `burst` frames on the stream, then the done flags: graph replays (16 / 4 / 1 frames per launch) or eager launches
+    auto run_burst = [&](int burst) -> ft_status {
+        hipGraphExec_t exec = nullptr, exec_k = nullptr, exec_4 = nullptr;
+        if (!eager) FT_TRY(get_graph(ctx, nslots, &exec));
+        if (!eager && gk > 1 && first_burst >= gk && burst >= gk) FT_TRY(get_graph(ctx, nslots, &exec_k, gk));
+        if (!eager && gk > 4 && first_burst >= 4 && burst >= 4) FT_TRY(get_graph(ctx, nslots, &exec_4, 4));
         int i0 = 0;
         if (exec_k) for (; i0 + gk <= burst; i0 += gk) FT_HIP(ctx, hipGraphLaunch(exec_k, ctx->stream));
         if (exec_4) for (; i0 + 4 <= burst; i0 += 4) FT_HIP(ctx, hipGraphLaunch(exec_4, ctx->stream));
@@ -1605,21 +1731,48 @@ extern "C" ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames,
                 FT_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
             }
         }
-        done_frames += burst;
         FT_HIP(ctx, hipMemcpyAsync(h, ctx->d_done, nslots * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return FT_OK;
+    };
+    const int pos0 = h[nslots], done0 = h[2 * nslots];      // slot 0 at entry (the engine serves one-slot calls only)
+    std::vector<char> was_done(nslots);
+    for (int m = 0; m < nslots; ++m) was_done[m] = (char)(h[2 * nslots + m] != 0);   // frozen slots produce nothing new
+    int done_frames = 0;
+    while (done_frames < budget) {
+        const int burst = std::min(poll, budget - done_frames);
+        const bool on_engine = nslots == 1 && eng_in_use(ctx);
+        FT_TRY(run_burst(burst));
+        if (on_engine) {
+            bool aborted = false;
+            FT_TRY(eng_recover(ctx, &aborted));
+            if (aborted) {
+                // slot 0 back to where this burst began (its frames [nf0 + done_frames, ..) and cache rows are rewritten by
+                // the redo; the draws are counter-based, so the redo draws what the engine would have drawn), then the same
+                // frames on the launch path
+                int* hp = ctx->h_pin + 3 * nslots;
+                hp[0] = done0 ? pos0 : pos0 + done_frames; hp[1] = done0 ? nf0[0] : nf0[0] + done_frames; hp[2] = done0;
+                FT_HIP(ctx, hipMemcpyAsync(ctx->d_pos, hp, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+                FT_HIP(ctx, hipMemcpyAsync(ctx->d_nf, hp + 1, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+                FT_HIP(ctx, hipMemcpyAsync(ctx->d_done, hp + 2, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+                FT_HIP(ctx, hipMemcpy2DAsync(ctx->d_tok, sizeof(int), ctx->d_seq + (hp[1] - 1), (size_t)ctx->cap * sizeof(int),
+                                             sizeof(int), R, hipMemcpyDeviceToDevice, ctx->stream));
+                ctx->eng_suspended = true;
+                const ft_status st = run_burst(burst);
+                ctx->eng_suspended = false;
+                FT_TRY(st);
+            }
+        }
+        done_frames += burst;
         bool all = true;
         for (int m = 0; m < nslots; ++m) all = all && h[m];
         if (all) break;
     }
-    if (nslots == 1) FT_TRY(eng_check(ctx));
     // collect: frames [nf0, nf0+done_frames) of each slot, cut after the first <|im_end|>.  Only the columns
     // [nf0-1, nf0+done_frames) of the frame store travel (one strided copy per slot, all issued before the wait).
     const int W = done_frames + 1;
     std::vector<int> seq((size_t)nslots * R * W);
-    std::vector<char> was_done(nslots);
     for (int m = 0; m < nslots; ++m) {
-        was_done[m] = (char)(ctx->h_pin[2 * nslots + m] != 0);   // state at entry (frozen slots produce nothing new)
         if (was_done[m] || done_frames == 0) continue;
         const int c0 = std::min(nf0[m] - 1, ctx->cap - W);        // stay inside the store near its end
         FT_HIP(ctx, hipMemcpy2DAsync(seq.data() + (size_t)m * R * W, (size_t)W * sizeof(int),
@@ -1645,30 +1798,61 @@ extern "C" ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames,
     return FT_OK;
 }
 
-// hand-off time-outs of the frame engine surface as an error of the call that ran the frames
-static ft_status eng_check(ft_ctx* ctx) {
+// A hand-off time-out of the frame engine (ENG_CTL_ABORT: some workgroup gave up after ENG_TIMEOUT_TICKS, then all did)
+// is survivable.  Called after the stream has drained: *aborted tells the caller that the frames since the last check
+// are invalid; the control words and every hand-off buffer are cleared (no granule of the aborted launches can carry a
+// valid tag afterwards: tag 0 is never valid and the epoch moves on), and after ENG_MAX_STRIKES events the context stops
+// using the engine.  The caller then redoes those frames on the launch path (ctx->eng_suspended).
+static ft_status eng_recover(ft_ctx* ctx, bool* aborted) {
+    *aborted = false;
     if (!ctx->eng_ctl) return FT_OK;
-    unsigned w[4] = {0, 0, 0, 0};
+    unsigned w[ENG_CTL_WORDS];
     FT_HIP(ctx, hipMemcpyAsync(w, ctx->eng_ctl, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
     FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (w[ENG_CTL_ABORT]) {
-        char buf[160];
-        snprintf(buf, sizeof buf, "frame engine: a hand-off timed out (phase %u); results of this call are invalid", w[ENG_CTL_WHERE]);
-        return ft_fail(ctx, FT_ERR_HIP, buf);
+    if (!w[ENG_CTL_ABORT]) return FT_OK;
+    *aborted = true;
+    ctx->eng_strikes += 1;
+    ctx->eng_last_where = (int)w[ENG_CTL_WHERE];
+    const unsigned epoch = w[ENG_CTL_EPOCH] + 4u * ENG_EPOCH_STEP;
+    FT_HIP(ctx, hipMemsetAsync(ctx->eng_ctl, 0, ENG_CTL_WORDS * 4, ctx->stream));
+    FT_HIP(ctx, hipMemcpyAsync(ctx->eng_ctl + ENG_CTL_EPOCH, &epoch, sizeof epoch, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->eng_gx) FT_HIP(ctx, hipMemsetAsync(ctx->eng_gx, 0, ctx->eng_pool_bytes, ctx->stream));
+    if (ctx->eng_gpart) FT_HIP(ctx, hipMemsetAsync(ctx->eng_gpart, 0, ctx->eng_gpart_bytes, ctx->stream));
+    if (ctx->eng_fast_g) FT_HIP(ctx, hipMemsetAsync(ctx->eng_fast_g, 0, ctx->eng_fast_bytes, ctx->stream));
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // (epoch is a stack word)
+    char buf[256];
+    if (ctx->eng_strikes >= ENG_MAX_STRIKES) {
+        ctx->eng_on = ctx->eng_fast_on = false;
+        snprintf(buf, sizeof buf, "launch path: the frame engine was turned off after %d hand-off time-outs (last in phase %u)",
+                 ctx->eng_strikes, w[ENG_CTL_WHERE]);
+        ctx->eng_why = buf;
     }
+    fprintf(stderr, "fish_tts_amd: frame engine: a hand-off timed out (phase %u, strike %d of %d): the frames are redone on the "
+            "launch path%s\n", w[ENG_CTL_WHERE], ctx->eng_strikes, ENG_MAX_STRIKES,
+            ctx->eng_strikes >= ENG_MAX_STRIKES ? "; the engine stays off for this context" : "");
     return FT_OK;
 }
+static bool eng_in_use(const ft_ctx* ctx) { return (ctx->eng_on || ctx->eng_fast_on) && !ctx->eng_suspended; }
 
 extern "C" ft_status ft_ar_engine_state(ft_ctx* ctx, int32_t* flags, int32_t* aborted, int32_t* where) {
     FT_TRY(ar_ready(ctx));
-    unsigned w[4] = {0, 0, 0, 0};
-    if (ctx->eng_ctl) {
-        FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        FT_HIP(ctx, hipMemcpy(w, ctx->eng_ctl, sizeof w, hipMemcpyDeviceToHost));
-    }
     if (flags) *flags = (ctx->eng_on ? 1 : 0) | (ctx->eng_fast_on ? 2 : 0);
-    if (aborted) *aborted = (int32_t)w[ENG_CTL_ABORT];
-    if (where) *where = (int32_t)w[ENG_CTL_WHERE];
+    if (aborted) *aborted = ctx->eng_strikes;
+    if (where) *where = ctx->eng_last_where;
+    return FT_OK;
+}
+
+extern "C" const char* ft_ar_frame_path(const ft_ctx* ctx) { return ctx ? ctx->eng_why.c_str() : ""; }
+
+// Test hook: workgroup `wg` of the NEXT slow-stack (which = 0) or codebook-loop (which = 1) engine launch plays dead - it
+// publishes nothing, every workgroup that waits for its rows times out (one shot: that workgroup clears the word).
+extern "C" ft_status ft_test_engine_fault(ft_ctx* ctx, int32_t which, int32_t wg) {
+    FT_TRY(ar_ready(ctx));
+    if (!ctx->eng_ctl || !(which == 0 ? ctx->eng_on : ctx->eng_fast_on)) return ft_fail(ctx, FT_ERR_STATE, "ft_test_engine_fault: the frame engine is off");
+    if (wg < 0 || wg >= ctx->eng_nb) return ft_fail(ctx, FT_ERR_ARG, "ft_test_engine_fault: bad workgroup");
+    const unsigned v = (which == 0 ? 0u : ENG_FAULT_FAST) + 1u + (unsigned)wg;
+    FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FT_HIP(ctx, hipMemcpy(ctx->eng_ctl + ENG_CTL_FAULT, &v, sizeof v, hipMemcpyHostToDevice));
     return FT_OK;
 }
 
@@ -1822,7 +2006,7 @@ extern "C" ft_status ft_ar_profile_frame(ft_ctx* ctx, int32_t frames, const ft_s
     float t = 0.f;
     FT_HIP(ctx, hipEventElapsedTime(&t, ev[0], ev[1]));
     if (ms_graph) *ms_graph = t;
-    if (nodes_per_frame) { auto it = ctx->graph_nodes.find(1 * 64 + ctx->nsplit); *nodes_per_frame = it == ctx->graph_nodes.end() ? 0 : it->second; }
+    if (nodes_per_frame) { auto it = ctx->graph_nodes.find(graph_key(ctx, 1, 1)); *nodes_per_frame = it == ctx->graph_nodes.end() ? 0 : it->second; }
     // (2) the same frame launched eagerly, events between its three parts (bf16 only)
     double seg[3] = {0, 0, 0};
     if (seg_ms && c.dtype == FT_BF16) {
@@ -1847,7 +2031,10 @@ extern "C" ft_status ft_ar_profile_frame(ft_ctx* ctx, int32_t frames, const ft_s
         seg_ms[0] = seg_ms[1] = seg_ms[2] = 0.0;
     }
     for (auto& e : ev) hipEventDestroy(e);
-    return eng_check(ctx);
+    bool aborted = false;
+    FT_TRY(eng_recover(ctx, &aborted));
+    if (aborted) return ft_fail(ctx, FT_ERR_HIP, "ft_ar_profile_frame: a frame-engine hand-off timed out; the timing is invalid");
+    return FT_OK;
 }
 
 extern "C" ft_status ft_test_sample(ft_ctx* ctx, const float* logits, int32_t cb, const ft_sampling* sp,

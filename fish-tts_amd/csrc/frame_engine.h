@@ -49,7 +49,17 @@ typedef __attribute__((address_space(1))) unsigned long long eng_gu64;
 #define ENG_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 // control words (device memory, zeroed at creation)
-enum { ENG_CTL_EPOCH = 0, ENG_CTL_ABORT = 1, ENG_CTL_EXIT = 2, ENG_CTL_WHERE = 3, ENG_CTL_ARRIVED = 4, ENG_CTL_XCD = 16, ENG_CTL_WORDS = 32 };
+enum { ENG_CTL_EPOCH = 0, ENG_CTL_ABORT = 1, ENG_CTL_EXIT = 2, ENG_CTL_WHERE = 3, ENG_CTL_ARRIVED = 4, ENG_CTL_FAULT = 5, ENG_CTL_XCD = 16, ENG_CTL_WORDS = 32 };
+// ENG_CTL_FAULT (test hook, ft_test_engine_fault): 1 + b = workgroup b of the next slow-stack launch, ENG_FAULT_FAST + 1 + b =
+// of the next codebook-loop launch, starts with its `dead` word set and clears the fault word: it publishes nothing.
+constexpr unsigned ENG_FAULT_FAST = 0x10000u;
+// true when this workgroup is the one told to play dead (thread 0 only; the word is cleared)
+__device__ __forceinline__ bool eng_fault_here(unsigned* ctl, unsigned base, int b) {
+    const unsigned f = __hip_atomic_load((__attribute__((address_space(1))) unsigned*)(ctl + ENG_CTL_FAULT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (f != base + 1u + (unsigned)b) return false;
+    __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(ctl + ENG_CTL_FAULT), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
 
 struct EngLayer {   // device-resident table, one entry per transformer block
     const bf16_t *wqkv, *bqkv, *attn_norm, *qn, *kn, *wo, *bo, *ffn_norm, *w13, *w2;
@@ -733,7 +743,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     int* dead = reinterpret_cast<int*>(outS + ENG_MAX_OUT);
     int* out_count = dead + 1;
     int* reg_s = dead + 4;                // [3] XCD, rank in it, workgroups in it
-    if (tid == 0) { *dead = 0; *out_count = 0; }
+    if (tid == 0) { *dead = eng_fault_here(p.ctl, 0u, b) ? 1 : 0; *out_count = 0; }
     if (tid == ENG_CW * 64) {             // one thread owns the registration words
         reg_s[0] = 0; reg_s[1] = 0; reg_s[2] = 1;
         if (ENG_RELAY && p.rep_stride) eng_register(p.ctl, nb, reg_s, dead);
@@ -1862,7 +1872,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     float* gS1 = xB1 + D;
     float* qkvS1 = gS1;
     float* yS1 = gS1 + p.qkvN;
-    if (tid == 0) { *dead = 0; *out_count = 0; *sub_count = 0; }
+    if (tid == 0) { *dead = eng_fault_here(p.ctl, ENG_FAULT_FAST, b) ? 1 : 0; *out_count = 0; *sub_count = 0; }
     if (tid == ENG_CW * 64) {                  // one thread owns the registration words
         reg_s[0] = 0; reg_s[1] = 0; reg_s[2] = 1;
         if (ENG_RELAY && p.rep_stride) eng_register(p.ctl, nb, reg_s, dead);

@@ -384,9 +384,17 @@ class FishTTS:
             try:
                 audio = audio_queue.get(timeout=0.05)
             except queue.Empty:
-                if not worker.is_alive():
-                    break
-                continue
+                if worker.is_alive():
+                    continue
+                # the worker may have put its last chunk and the end mark between the time-out and this check
+                while True:
+                    try:
+                        audio = audio_queue.get_nowait()
+                    except queue.Empty:
+                        break
+                    if audio is not None:
+                        yield audio
+                break
             if audio is None:
                 break
             yield audio

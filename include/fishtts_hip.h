@@ -168,10 +168,18 @@ ft_status ft_ar_profile_frame(ft_ctx* ctx, int32_t frames, const ft_sampling* sp
 ft_status ft_sync(ft_ctx* ctx);
 /* State of the persistent frame engine (csrc/frame_engine.h), the batch-1 form of the decode step
  * (fish_tts/models/inference.py:83-155 as two launches of one workgroup per CU instead of ~325 launches).
- * flags bit 0: the slow stack runs on it, bit 1: the fast codebook loop runs on it (0 = this configuration keeps the
- * launch path: other widths, f32 precision, FT_NO_ENGINE set).  aborted != 0: a hand-off inside it timed out (ft_ar_decode
- * then returns FT_ERR_HIP); where = the phase that gave up first.  Any pointer may be NULL. */
+ * flags bit 0: the slow stack runs on it, bit 1: the fast codebook loop runs on it (0 = this context takes the launch
+ * path: other widths, f32 precision, FT_NO_ENGINE set, another context of the process owns the device's engine, or the
+ * engine was turned off after repeated time-outs).  aborted = hand-off time-outs so far: each one was recovered inside
+ * the call that hit it (control words and hand-off buffers cleared, the affected frames redone on the launch path, so
+ * the call still returns the frames the launch path yields); after two the context stops using the engine.
+ * where = the phase that gave up first in the last such event.  Any pointer may be NULL. */
 ft_status ft_ar_engine_state(ft_ctx* ctx, int32_t* flags, int32_t* aborted, int32_t* where);
+/* One line of text: which path the batch-1 decode frames of this context take and why (for the host's log). */
+const char* ft_ar_frame_path(const ft_ctx* ctx);
+/* Test hook: workgroup `wg` of the next slow-stack (which = 0) or codebook-loop (which = 1) engine launch publishes
+ * nothing, so the launch times out (one shot).  Exercises the recovery described above. */
+ft_status ft_test_engine_fault(ft_ctx* ctx, int32_t which, int32_t wg);
 /* Test hook: one draw of the sampling kernel (inference.py:30-80) on caller-supplied logits.
  * cb = 0 draws from `vocab_size` logits, cb >= 1 from min(1024, codebook_size); window is the
  * (num_codebooks+1) x 16 penalty window of inference.py:187-191 or NULL (no penalty); q the Exp(1)

@@ -609,19 +609,44 @@ def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
     ltol = (2e-3 if precision == "fp32" else 0.05) * absmax
     sp = eng._sampling(0.7, 1e-6, 1.0)
     flips, judged = [], 0
+    dflips, djudged, dframes = [], 0, 0
+    if precision == "bf16":
+        assert eng.engine_state()[0] == 3, eng.frame_path()      # the decode-loop frames below come from the frame engine
+
+    def judge(frame, k, flips_):
+        n_ok = 0
+        want = seq[:, T + k]
+        for row in range(seq.shape[0]):
+            if frame[row] != want[row]:
+                cb = 0 if row <= 1 else row - 1
+                assert float(margins[k, cb]) <= tol, f"frame {k} row {row}: {frame[row]} != {want[row]}, margin {margins[k, cb]}"
+                flips_.append((k, row, round(float(margins[k, cb]), 4)))
+                break                     # the later codebooks of this frame were drawn after a different code
+            n_ok += 1
+        return n_ok
+
     for k in range(n_new):
         first = eng.prefill(np.ascontiguousarray(seq[:, : T + k]), sp)
         logits, _ = eng.debug_state()
         assert np.max(np.abs(logits[top_idx[k]] - top_val[k])) <= ltol, (k, logits[top_idx[k]], top_val[k])
-        want = seq[:, T + k]
-        for row in range(seq.shape[0]):
-            if first[row] != want[row]:
-                cb = 0 if row <= 1 else row - 1
-                assert float(margins[k, cb]) <= tol, f"frame {k} row {row}: {first[row]} != {want[row]}, margin {margins[k, cb]}"
-                flips.append((k, row, round(float(margins[k, cb]), 4)))
-                break                     # the later codebooks of this frame were drawn after a different code
-            judged += 1
+        judged += judge(first, k, flips)
+        # The DECODE-LOOP frame (bf16: the persistent frame engine) judged directly against the reference: with
+        # repetition penalty 1.0 frame k + 1 is the same function of prompt + golden[:k + 1] whether the prompt pass or the
+        # loop yields it, so whenever frame k came out as the reference's, one decode step must yield the reference's
+        # frame k + 1 - each decision within the margin the reference recorded for it, the slow logits within ltol.
+        if k + 1 < n_new and np.array_equal(first, seq[:, T + k]):
+            frames, cnt = eng.decode(1, [sp], poll=1)
+            assert cnt[0] == 1
+            logits, _ = eng.debug_state()
+            assert np.max(np.abs(logits[top_idx[k + 1]] - top_val[k + 1])) <= ltol, (k + 1, logits[top_idx[k + 1]], top_val[k + 1])
+            djudged += judge(frames[0, 0], k + 1, dflips)
+            dframes += 1
     print(f"{tag}: {judged} decisions equal, legitimate flips (frame, row, reference margin) at {flips}")
+    print(f"{tag}: decode loop: {dframes} frames judged, {djudged} decisions equal, legitimate flips at {dflips}")
+    assert dframes >= 3, dframes
+    assert djudged >= 0.6 * dframes * seq.shape[0]
+    if precision == "bf16":
+        assert eng.engine_state()[1] == 0
     # (random weights at this width give many near-ties in bf16: 2-7 of a frame's 10 decisions have a margin inside the
     # tolerance; a flip ends the judging of its frame only, the next frame is forced back onto the golden tokens)
     assert judged >= 0.6 * n_new * seq.shape[0]
