@@ -118,6 +118,8 @@ struct ft_ctx {
     bool eng_relay = true;        // per-XCD replicas of the hand-off buffers (FT_NO_RELAY: every workgroup polls the source)
     void* eng_qkv0_tab = nullptr;   // fast layer 0's q k v per codebook-embedding row (bf16 [fastV][qkvN])
     bool eng_pair = false;          // fast loop: positions 0 and 1 as two rows of the first pass
+    bool xl_shape = false;          // 8 kv heads x (2 x 128) on 8 XCDs x 32 CUs: 32 KV splits always (engine.hip: ar_alloc)
+    bool eng_xl = false;            // the slow stack's engine runs its XCD-local form (one kv head per XCD)
     size_t eng_pool_bytes = 0, eng_gpart_bytes = 0, eng_fast_bytes = 0;   // hand-off allocations (zeroed again after an abort)
     // A hand-off that timed out (ENG_CTL_ABORT) is survivable: the host clears the control words and the hand-off pools,
     // redoes the affected frames on the launch path (eng_suspended) and turns the engine off for this context after

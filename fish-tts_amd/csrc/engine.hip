@@ -133,6 +133,15 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     ctx->nsplit = ns ? atoi(ns) : (ctx->n_slots > 512 ? 8 : 1);
     ctx->nsplit_fixed = ns != nullptr;
     ctx->nsplit_max = ctx->nsplit_fixed ? ctx->nsplit : (ctx->n_slots > 3072 ? 32 : ctx->n_slots > 768 ? 16 : ctx->nsplit);
+    // One kv head per XCD (frame_engine.h, XL): 8 kv heads of 2 x 128-wide query heads on a chip of 8 XCDs x 32 CUs split every
+    // head's cached positions 32 ways - one split per CU of the head's XCD - at every context length.  The split count is a
+    // property of the shapes and the chip, not of the frame path: launches and engine then sum in the same order.
+    {
+        hipDeviceProp_t prop;
+        ctx->xl_shape = !ns && !getenv("FT_NO_XL") && c.n_local_heads == 8 && c.n_head == 16 && c.head_dim == 128 &&
+                        hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount == 256;
+        if (ctx->xl_shape) { ctx->nsplit = ctx->nsplit_max = 32; ctx->nsplit_fixed = true; }
+    }
     ctx->nt_weights = getenv("FT_NO_NT") ? 0 : 1;
     { const char* br = getenv("FT_BATCH_ROWS"); ctx->batch_rows = br ? atoi(br) : 4; }
     if (ctx->nsplit < 1) ctx->nsplit = 1;
@@ -531,15 +540,17 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
     ctx->eng_lds_slow = std::max(fl * sizeof(float), (size_t)82 * 1024);   // > half the CU's LDS: one workgroup per CU
     const size_t lds_cap = prop.maxSharedMemoryPerMultiProcessor;
     if (ctx->eng_lds_slow > lds_cap) { why = "the slow stack's LDS need exceeds the CU's"; return false; }
-    if (!hip_ok(hipFuncSetAttribute((const void*)slow_engine_kernel<2, 4, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)ctx->eng_lds_slow), "hipFuncSetAttribute(slow_engine_kernel)")) return false;
+    ctx->eng_xl = ctx->xl_shape && nb == 256 && ctx->nsplit == 32 && c.n_local_heads * 32 == nb && qkvN / nb == (G + 2) * hd * c.n_local_heads / nb;
+    const void* slow_fn = ctx->eng_xl ? (const void*)slow_engine_kernel<2, 4, 6, 2, true> : (const void*)slow_engine_kernel<2, 4, 6, 2, false>;
+    if (!hip_ok(hipFuncSetAttribute(slow_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->eng_lds_slow),
+                "hipFuncSetAttribute(slow_engine_kernel)")) return false;
     // every workgroup must be resident at once: ask the runtime whether one fits a CU at all (registers, LDS, waves)
     int occ = 0;
-    if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)slow_engine_kernel<2, 4, 6, 2>, ENG_THREADS,
-                                                             ctx->eng_lds_slow), "hipOccupancyMaxActiveBlocksPerMultiprocessor")) return false;
+    if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, slow_fn, ENG_THREADS, ctx->eng_lds_slow),
+                "hipOccupancyMaxActiveBlocksPerMultiprocessor")) return false;
     if (occ < 1) { why = "a slow-stack workgroup does not fit one CU (occupancy query)"; return false; }
     ctx->eng_on = true;
-    why = "slow stack on the frame engine";
+    why = ctx->eng_xl ? "slow stack on the frame engine (one kv head per XCD)" : "slow stack on the frame engine";
 
     // ---- fast codebook loop
     const int HDf = c.fast_n_head * c.fast_head_dim;
@@ -603,7 +614,7 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
         }
     }
     ctx->eng_fast_on = true;
-    why = "slow stack and codebook loop on the frame engine";
+    why = ctx->eng_xl ? "slow stack (one kv head per XCD) and codebook loop on the frame engine" : "slow stack and codebook loop on the frame engine";
     return true;
 }
 
@@ -734,7 +745,8 @@ static void enqueue_slow_engine(Launch& L, const int* toks, long tok_row_stride,
     p.gx = ctx->eng_gx; p.gqkv = ctx->eng_gqkv; p.gpart = ctx->eng_gpart; p.gy = ctx->eng_gy; p.gxb = ctx->eng_gxb; p.gg = ctx->eng_gg;
     p.ctl = ctx->eng_ctl; p.x_out = ctx->x + (size_t)m0 * c.dim; p.nt = ctx->nt_weights;
     p.rep_delta0 = ctx->eng_relay ? (long)ctx->eng_pool_words : 0; p.rep_stride = ctx->eng_relay ? (long)ctx->eng_pool_words : 0;
-    slow_engine_kernel<2, 4, 6, 2><<<ctx->eng_nb, ENG_THREADS, ctx->eng_lds_slow, L.s>>>(p);
+    if (ctx->eng_xl) slow_engine_kernel<2, 4, 6, 2, true><<<ctx->eng_nb, ENG_THREADS, ctx->eng_lds_slow, L.s>>>(p);
+    else slow_engine_kernel<2, 4, 6, 2, false><<<ctx->eng_nb, ENG_THREADS, ctx->eng_lds_slow, L.s>>>(p);
     L.chk();
 }
 

@@ -426,9 +426,17 @@ struct EngW {
     U4 gain[NT];
 };
 
-template <bool NTL = true, int NT, int RPU, int MAXS>
+// which row of the matrix a unit is: the identity, or (slow stack, XCD-local attention) the rows of ONE kv head's q, k and v
+// that the workgroups of one XCD share out - workgroup r of the XCD takes NQ query rows, NK key rows and NK value rows
+struct EngRowIdent { __device__ __forceinline__ int operator()(int u) const { return u; } };
+struct EngRowQkvX {
+    int q0, k0, v0, nq, nk;      // first q / k / v row of this workgroup; q rows and k (= v) rows per workgroup
+    __device__ __forceinline__ int operator()(int u) const { return u < nq ? q0 + u : (u < nq + nk ? k0 + (u - nq) : v0 + (u - nq - nk)); }
+};
+
+template <bool NTL = true, int NT, int RPU, int MAXS, typename RM = EngRowIdent>
 __device__ __forceinline__ void eng_issue(EngW<NT, RPU, MAXS>& r, const bf16_t* W, const bf16_t* gain, int K, int u_lo, int u_hi,
-                                          int cw, int lane, int nt) {
+                                          int cw, int lane, int nt, RM rm = RM()) {
     // every compute wave issues the same number of loads on every path (units past the workgroup's last one re-read
     // it), so the counted vmcnt waits the compiler derives stay exact
 #pragma unroll
@@ -439,7 +447,7 @@ __device__ __forceinline__ void eng_issue(EngW<NT, RPU, MAXS>& r, const bf16_t* 
         for (int rr = 0; rr < RPU; ++rr)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                r.w[s][rr][t] = (nt & 2) ? U4{0u, 0u, 0u, 0u} : eng_ldg16<NTL>(W + (size_t)(u * RPU + rr) * K + t * 512 + lane * 8);
+                r.w[s][rr][t] = (nt & 2) ? U4{0u, 0u, 0u, 0u} : eng_ldg16<NTL>(W + (size_t)(rm(u) * RPU + rr) * K + t * 512 + lane * 8);
             }
     }
     if (gain) {
@@ -466,9 +474,9 @@ typedef __attribute__((address_space(3))) int* eng_lds_int;
 // vector (last phase of a launch).
 // Called by EVERY compute wave (also one without rows in this matrix).
 // the arithmetic of one input row: this wave's outputs go to vals[u - u_lo] (LDS)
-template <int NT, int RPU, int MAXS, int PRO, int EPI>
+template <int NT, int RPU, int MAXS, int PRO, int EPI, typename RM = EngRowIdent>
 __device__ __forceinline__ void eng_gemv_rows(const EngW<NT, RPU, MAXS>& r, const float* xs, int K, float eps, const bf16_t* bias,
-                                              const float* resid, float* vals, int u_lo, int u_hi, int cw, int lane) {
+                                              const float* resid, float* vals, int u_lo, int u_hi, int cw, int lane, RM rm = RM()) {
     static_assert(EPI == EPI_SWIGLU ? RPU == 2 : RPU == 1, "a unit is a (w1, w3) pair for SwiGLU, one row otherwise");
     if (u_lo + cw < u_hi) {
         float xv[NT][8];
@@ -520,13 +528,40 @@ __device__ __forceinline__ void eng_gemv_rows(const EngW<NT, RPU, MAXS>& r, cons
                 o = round_bf16(sg * b);
             } else {
                 float v = acc[0];
-                if (bias) v += eng_ldg_bf16(bias, u);
+                if (bias) v += eng_ldg_bf16(bias, rm(u));
                 v = round_bf16(v);
-                if (EPI == EPI_RESID) v = round_bf16(resid[u] + v);
+                if (EPI == EPI_RESID) v = round_bf16(resid[rm(u)] + v);
                 o = v;
             }
             if (lane == 0) vals[u - u_lo] = o;
         }
+    }
+}
+
+// Granules that stay inside ONE XCD (slow stack, XCD-local attention): written with PLAIN stores - they stay in the XCD's L2 -
+// and polled by workgroups of the same XCD with sc1 loads (past their L1, served by that L2): the mechanism of the relay's
+// replicas.  Who is in which XCD is read from the hardware at run time (eng_register), never assumed.
+__device__ __forceinline__ void eng_put_local(unsigned* g, int i, float v, unsigned tag16) {
+    __hip_atomic_store((eng_gu32*)(g + i), (tag16 << 16) | (__float_as_uint(v) >> 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void eng_put64_local(unsigned long long* g, size_t i, float v, unsigned tag32) {
+    __hip_atomic_store((eng_gu64*)(g + i), ((unsigned long long)tag32 << 32) | __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// QKV phase of the XCD-local form: this workgroup's units are rows rm(0 .. n-1) of the matrix; unit i's granule goes to
+// gvec[rm(i)] (the vector keeps its row order) with a plain store
+template <int NT, int MAXS, typename RM>
+__device__ __forceinline__ void eng_gemv_qkv_local(const EngW<NT, 1, MAXS>& r, const float* xs, int K, float eps, const bf16_t* bias,
+                                                   unsigned* gvec, unsigned tag, int n, int cw, int lane, EngOut& eo, RM rm) {
+    eng_gemv_rows<NT, 1, MAXS, PRO_RMSNORM, EPI_STORE>(r, xs, K, eps, bias, nullptr, eo.vals, 0, n, cw, lane, rm);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add((eng_lds_int)eo.count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    eo.seq += 1;
+    if (old + 1 == eo.seq * ENG_CW) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        if (lane < n) eng_put_local(gvec, rm(lane), eo.vals[lane], tag);
     }
 }
 
@@ -717,7 +752,13 @@ __device__ __forceinline__ int eng_att_role(int b, int nb, int li, int natt) {
 // continuously instead of in one burst per phase (a CU sustains ~24 GB/s only while requests are outstanding).
 // Waves 4..7 gather the input vectors, and run the attention of the layers in which this workgroup holds a
 // (kv head, split) role, with the cached K/V rows of their next turn prefetched into registers.
-template <int NTD, int NTA, int NTF, int G>
+// XL (XCD-local attention): kv head h lives in XCD h.  The XCD's workgroups compute the rows of that head's q, k, v, every
+// one of them takes ONE split of the head's cached positions (nsplit = workgroups per XCD), and the q k v vector and the
+// split partials travel inside the XCD (plain stores into its L2, sc1 polls) instead of through the memory side; only y
+// leaves the XCD.  Needs Hkv XCDs with nb / Hkv workgroups each (checked at run time; a failed census raises the abort
+// word and the host falls back to the launch path).  Per row the arithmetic is that of the launch path at the same split
+// count (attn_decode_kernel + merge_splits4), so the frames stay bit-identical to it.
+template <int NTD, int NTA, int NTF, int G, bool XL = false>
 __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     constexpr int SQ = ENG_SQ, SF = ENG_SF, SO = ENG_SO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -746,7 +787,14 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     if (tid == 0) { *dead = eng_fault_here(p.ctl, 0u, b) ? 1 : 0; *out_count = 0; }
     if (tid == ENG_CW * 64) {             // one thread owns the registration words
         reg_s[0] = 0; reg_s[1] = 0; reg_s[2] = 1;
-        if (ENG_RELAY && p.rep_stride) eng_register(p.ctl, nb, reg_s, dead);
+        if (XL || (ENG_RELAY && p.rep_stride)) eng_register(p.ctl, nb, reg_s, dead);
+        if (XL && (reg_s[2] * p.Hkv != nb || reg_s[0] >= p.Hkv || reg_s[1] >= reg_s[2] || p.nsplit != reg_s[2])) {
+            // census failed (the workgroups are not spread Hkv x nb / Hkv over the XCDs): nobody may rely on XCD-local data
+            if (!__hip_atomic_load((eng_gu32*)(p.ctl + ENG_CTL_ABORT), ENG_RLX)) __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_WHERE), 9998u, ENG_RLX);
+            __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_ABORT), 1u, ENG_RLX);
+            reg_s[0] = 0; reg_s[1] = 0;
+            *dead = 1;
+        }
     }
     const unsigned epoch = __hip_atomic_load((eng_gu32*)(p.ctl + ENG_CTL_EPOCH), ENG_RLX);
     const int pos = p.pos[0] + p.pos_off;
@@ -795,6 +843,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
         // =============================== compute waves: rows of the four matrices ===============================
         int q_lo, q_hi, o_lo, o_hi, f_lo, f_hi, d_lo, d_hi;
         eng_units(p.qkvN, b, nb, q_lo, q_hi);
+        if (XL) { q_lo = 0; q_hi = p.qkvN / nb; }          // local units of this workgroup (rows: rmq below)
         eng_units(D, b, nb, o_lo, o_hi);
         eng_units(F, b, nb, f_lo, f_hi);     // (w1_i, w3_i) pairs
         eng_units(D, b, nb, d_lo, d_hi);
@@ -805,13 +854,22 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
         EngOut eo{outS, out_count, 0};
         {
             const EngLayer l0 = eng_layer(p.layers, 0);
-            eng_issue(wq, l0.wqkv, l0.attn_norm, D, q_lo, q_hi, cw, lane, p.nt);
+            if (!XL) eng_issue(wq, l0.wqkv, l0.attn_norm, D, q_lo, q_hi, cw, lane, p.nt);
             eng_issue(wo, l0.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, p.nt);
             eng_issue(wf, l0.w13, l0.ffn_norm, D, f_lo, f_hi, cw, lane, p.nt);
             eng_issue(wd, l0.w2, (const bf16_t*)nullptr, F, d_lo, d_hi, cw, lane, p.nt);
             __builtin_amdgcn_sched_barrier(0);
         }
         eng_barrier();                                              // (registration results in LDS)
+        // XL: which rows of Wqkv are this workgroup's is known only now (kv head = its XCD, share = its rank there)
+        const int xnq = G * hd * p.Hkv / nb, xnk = hd * p.Hkv / nb;
+        const EngRowQkvX rmq{reg_s[0] * G * hd + reg_s[1] * xnq, (p.H + reg_s[0]) * hd + reg_s[1] * xnk,
+                             (p.H + p.Hkv + reg_s[0]) * hd + reg_s[1] * xnk, xnq, xnk};
+        if (XL) {
+            const EngLayer l0 = eng_layer(p.layers, 0);
+            eng_issue(wq, l0.wqkv, l0.attn_norm, D, q_lo, q_hi, cw, lane, p.nt, rmq);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         eng_barrier();                                              // B0
         for (int li = 0; li < p.n_layer; ++li) {
             const int par = ENG_SLOW_REUSE ? (li & 1) : li, parn = ENG_SLOW_REUSE ? ((li + 1) & 1) : li + 1;
@@ -825,15 +883,21 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             if (li > 0) { eng_issue(wd, l.w2, (const bf16_t*)nullptr, F, d_lo, d_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
 #endif
             ENG_STAMP(0);
-            eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, p.gqkv + (size_t)par * VSTR + eng_pub(b, q_lo), tag, nullptr,
-                                                         q_lo, q_hi, cw, lane, eo);
+            if (XL)
+                eng_gemv_qkv_local<NTD, SQ>(wq, xA, D, p.eps, l.bqkv, p.gqkv + (size_t)par * VSTR, tag, q_hi, cw, lane, eo, rmq);
+            else
+                eng_gemv<NTD, 1, SQ, PRO_RMSNORM, EPI_STORE>(wq, xA, D, p.eps, l.bqkv, nullptr, p.gqkv + (size_t)par * VSTR + eng_pub(b, q_lo), tag, nullptr,
+                                                             q_lo, q_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(1);
 #if !ENG_ISSUE_LATE
-            if (more) eng_issue(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, p.nt);
+            if (more) {
+                if (XL) eng_issue(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, p.nt, rmq);
+                else eng_issue(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, p.nt);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #endif
-            if (eng_att_role(b, nb, li, natt) >= 0) {
+            if (XL || eng_att_role(b, nb, li, natt) >= 0) {
                 eng_barrier(); if (*dead) break;                    // BA
                 eng_barrier();                                      // BB
                 eng_barrier();                                      // BC
@@ -892,17 +956,21 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
         int plan_layer = -1;
         const bf16_t *plan_kc = nullptr, *plan_vc = nullptr, *plan_qn = nullptr, *plan_kn = nullptr;
         const int period = (natt > 0 && nb % natt == 0) ? nb / natt : 0;
+        int x_role = 0;       // XL: this workgroup's (kv head, split) in EVERY layer = (its XCD, its rank there); set after registration
+        auto role = [&](int layer) { return XL ? x_role : eng_att_role(b, nb, layer, natt); };
         auto kv_plan = [&](int from_layer) {
             plan_layer = -1;
             if (from_layer >= p.n_layer) return;
-            if (period > 0) {
+            if (XL) {
+                plan_layer = from_layer;
+            } else if (period > 0) {
                 const int phase = b / natt;                          // this workgroup holds a role in layers == phase (mod period)
                 int d = phase - from_layer % period;
                 if (d < 0) d += period;
                 if (from_layer + d < p.n_layer) plan_layer = from_layer + d;
             } else {
                 for (int l2 = from_layer; l2 < p.n_layer; ++l2)
-                    if (eng_att_role(b, nb, l2, natt) >= 0) { plan_layer = l2; break; }
+                    if (role(l2) >= 0) { plan_layer = l2; break; }
             }
             if (plan_layer < 0) return;
             const EngLayer l2 = eng_layer(p.layers, plan_layer);
@@ -913,7 +981,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
 #pragma unroll
             for (int st = 0; st < ENG_KVST; ++st) { kpf[st] = U4{0u, 0u, 0u, 0u}; vpf[st] = U4{0u, 0u, 0u, 0u}; }
             if (att_next < 0) return;
-            const int a = eng_att_role(b, nb, att_next, natt);
+            const int a = role(att_next);
             const int kvh = a / p.nsplit, split = a % p.nsplit;
             const int lo = split * chunk, hi = min(lo + chunk, pos + 1);
             if (lane < hp) {
@@ -931,10 +999,10 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 }
             }
         };
-        kv_plan(0);
-        kv_issue();
+        if (!XL) { kv_plan(0); kv_issue(); }
         eng_barrier();                                              // (registration results in LDS)
         const EngRelay rl{ENG_RELAY && p.rep_stride != 0, reg_s[1], reg_s[2], p.rep_delta0 + (long)reg_s[0] * p.rep_stride};
+        if (XL) { x_role = reg_s[0] * p.nsplit + reg_s[1]; kv_plan(0); kv_issue(); }
         // rotation entries of this position (the same for every layer)
         float rope_c = 1.f, rope_s = 0.f;
         if (lane < hp) { rope_c = p.rope[((size_t)pos * hp + lane) * 2]; rope_s = p.rope[((size_t)pos * hp + lane) * 2 + 1]; }
@@ -948,7 +1016,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 eng_barrier(); if (*dead) break;                    // B1
             }
             // ---- attention (attn_decode_kernel's arithmetic; these four waves stand in for its 256 threads)
-            const int a = eng_att_role(b, nb, li, natt);
+            const int a = role(li);
             if (a >= 0) {     // (workgroup-uniform)
                 kv_plan(li + 1);                                    // the turn after this one (scalar fetches land during this turn)
                 const int kvh = a / p.nsplit, split = a % p.nsplit;
@@ -1123,8 +1191,13 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                                 eng_put(p.gy + (size_t)par * HD, head * hd + e, round_bf16(O / L), tag);
                             } else {
                                 unsigned long long* gp = p.gpart + (((size_t)par * p.H + head) * p.nsplit + split) * (hd + 2);
-                                eng_put64(gp, e, O, tag32);
-                                if (e == 0) { eng_put64(gp, hd, M, tag32); eng_put64(gp, hd + 1, L, tag32); }
+                                if (XL) {       // the mergers are this XCD's workgroups: the partials stay in its L2
+                                    eng_put64_local(gp, e, O, tag32);
+                                    if (e == 0) { eng_put64_local(gp, hd, M, tag32); eng_put64_local(gp, hd + 1, L, tag32); }
+                                } else {
+                                    eng_put64(gp, e, O, tag32);
+                                    if (e == 0) { eng_put64(gp, hd, M, tag32); eng_put64(gp, hd + 1, L, tag32); }
+                                }
                             }
                         }
                     }
@@ -1134,6 +1207,75 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 // one head; lane 8 * i + s polls split c0 + s of item i (O[0..3], m, l = three 16-byte loads), the
                 // values cross to the item's first lane through LDS, which merges in split order.
                 ENG_ASTAMP(0, 4);
+                if (XL && gw == 3 && p.nsplit == 32 && hd == 128 && G == 2) {
+                    // ---- XL merge, ONE poll round: this workgroup merges elements [4 split, 4 split + 4) of its kv head's two query
+                    // heads; lane 32 i + s polls split s of head i (O[0..3], m, l = three 16-byte loads).  merge_splits4's
+                    // arithmetic: splits in chunks of 8, running maximum, rescale at each chunk, sums taken split by split.
+                    // The per-split weights and products are formed by the polling lanes in parallel; five chains per head
+                    // (l, a0..a3; lanes 8 i + q) then add them in split order from LDS.
+                    const int item = lane >> 5, s = lane & 31, e = split * 4;
+                    const int head = kvh * G + item;
+                    const unsigned long long* gs = p.gpart + (((size_t)par * p.H + head) * p.nsplit + s) * (hd + 2);
+                    EngSpin sp{p.ctl, dead, 0, 0, li * 8 + 2};
+                    U4 A, B, C;
+                    bool alive = true;
+                    for (;;) {
+                        eng_ld3_sc1(gs + e, gs + e + 2, gs + hd, A, B, C);
+                        const bool ok = A.y == tag32 && A.w == tag32 && B.y == tag32 && B.w == tag32 && C.y == tag32 && C.w == tag32;
+                        if (__all(ok)) break;
+                        if (sp.give_up(lane)) { alive = false; break; }
+                    }
+                    ENG_ASTAMP(3, 5);
+                    if (alive) {
+                        const float m_ = __uint_as_float(C.x), l_ = __uint_as_float(C.z);
+                        float Mc = m_;                                  // maximum of this lane's chunk of 8 splits
+                        Mc = fmaxf(Mc, dpp_f<DPP_XOR1>(Mc));
+                        Mc = fmaxf(Mc, dpp_f<DPP_XOR2>(Mc));
+                        Mc = fmaxf(Mc, dpp_f<DPP_HALF_MIRROR>(Mc));
+                        float* mx = mscr;                               // [2 heads][4 chunks] chunk maxima, then [2][32][5] products
+                        float* pr = mscr + 8;
+                        if ((lane & 7) == 0) mx[lane >> 3] = Mc;
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        // running maximum after this lane's chunk (empty chunks - maximum -inf - leave it unchanged)
+                        float Mrun = -INFINITY;
+                        const int ch = s >> 3;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (c <= ch) Mrun = fmaxf(Mrun, mx[item * 4 + c]);
+                        const float w = m_ > -INFINITY ? expf(m_ - Mrun) : 0.f;
+                        float* q5 = pr + (size_t)(item * 32 + s) * 5;
+                        q5[0] = l_ * w;
+                        q5[1] = __uint_as_float(A.x) * w; q5[2] = __uint_as_float(A.z) * w;
+                        q5[3] = __uint_as_float(B.x) * w; q5[4] = __uint_as_float(B.z) * w;
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        // chains: lane 8 i + q (q < 5) sums quantity q of head i over the 32 splits in split order
+                        const int ci = (lane >> 3) & 1, cq = lane & 7;
+                        float acc = 0.f;
+                        if (cq < 5) {
+                            const float* src = pr + (size_t)ci * 32 * 5 + cq;
+                            float M = -INFINITY;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float mc = mx[ci * 4 + c];
+                                if (mc > -INFINITY) {                   // (an empty chunk adds nothing and rescales nothing)
+                                    const float Mn = fmaxf(M, mc);
+                                    if (c > 0 && M > -INFINITY) acc *= expf(M - Mn);
+                                    M = Mn;
+#pragma unroll
+                                    for (int k = 0; k < 8; ++k) acc += src[(c * 8 + k) * 5];
+                                }
+                            }
+                        }
+                        // the head's l sits in lane 8 i, a0..a3 in the four lanes after it
+                        const float a0 = dpp_f<0x101>(acc), a1 = dpp_f<0x102>(acc), a2 = dpp_f<0x103>(acc), a3 = dpp_f<0x104>(acc);
+                        if (lane == 0 || lane == 8) {
+                            unsigned* gy = p.gy + (size_t)par * HD + (size_t)a * (G * 4) + ci * 4;
+                            eng_put4(gy, round_bf16(a0 / acc), round_bf16(a1 / acc), round_bf16(a2 / acc), round_bf16(a3 / acc), tag);
+                        }
+                    }
+                    ENG_ASTAMP(3, 6);
+                } else
                 if (p.nsplit > 1 && gw == 3) {
                     const int epb = hd / p.nsplit;            // elements per workgroup and head (multiple of 4)
                     const int e4n = epb >> 2;

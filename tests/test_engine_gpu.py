@@ -41,10 +41,17 @@ def _run(monkeypatch, shape, engine_on, prompt, n_new, kw, tape=None, precision=
     return flags, seq, logits, hidden
 
 
+@pytest.mark.parametrize("no_xl", [False, True])
 @pytest.mark.parametrize("max_seq_len,Lp", [(512, 40), (1024, 40), (1024, 300), (4096, 900)])
-def test_engine_frames_equal_launch_frames_greedy(monkeypatch, max_seq_len, Lp):
-    """2+2 layers at the s1-mini widths.  max_seq_len 512 -> one KV split per head, 1024 -> 8 splits merged by the
-    attention workgroups, 4096 with a 900-token prompt -> 16 splits (two merge chunks)."""
+def test_engine_frames_equal_launch_frames_greedy(monkeypatch, max_seq_len, Lp, no_xl):
+    """2+2 layers at the s1-mini widths.  On a chip of 8 XCDs x 32 CUs the slow stack runs its XCD-local form (one kv head
+    per XCD, 32 KV splits at every context length, launches and engine alike); with FT_NO_XL (and on other chips) the split
+    count follows the cache size: max_seq_len 512 -> one KV split per head, 1024 -> 8 splits merged by the attention
+    workgroups, 4096 with a 900-token prompt -> 16 splits (two merge chunks)."""
+    if no_xl:
+        monkeypatch.setenv("FT_NO_XL", "1")
+    else:
+        monkeypatch.delenv("FT_NO_XL", raising=False)
     shape = dataclasses.replace(medium_shape(), max_seq_len=max_seq_len)
     prompt = make_prompt(shape, Lp, seed=4, n_vq=4).numpy()
     kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)

@@ -75,7 +75,10 @@ int main(int argc, char** argv) {
     float* xo; CK(hipMalloc(&xo, D * 4)); p.x_out = xo; p.nt = 1;
     unsigned long long* stamps = (unsigned long long*)zalloc((size_t)nb * n_layer * 16 * 8 * 2);
     const size_t lds = 82 * 1024;
-    CK(hipFuncSetAttribute((const void*)slow_engine_kernel<2, 4, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool xl = getenv("XL") != nullptr;     // the XCD-local form (needs nsplit = 32 on 8 x 32 CUs)
+    CK(hipFuncSetAttribute((const void*)slow_engine_kernel<2, 4, 6, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)slow_engine_kernel<2, 4, 6, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    printf("XCD-local attention: %d\n", (int)xl);
     CK(hipStreamSynchronize(s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int stamp_mode = argc > 4 ? atoi(argv[4]) : 1;    // which mode's stamps are analysed: 1 = with weights, 2 = without
@@ -85,7 +88,8 @@ int main(int argc, char** argv) {
         float best = 1e9f, sum = 0.f; const int reps = 20;
         for (int r = 0; r < reps + 3; ++r) {
             CK(hipEventRecord(e0, s));
-            slow_engine_kernel<2, 4, 6, 2><<<nb, ENG_THREADS, lds, s>>>(p);
+            if (xl) slow_engine_kernel<2, 4, 6, 2, true><<<nb, ENG_THREADS, lds, s>>>(p);
+            else slow_engine_kernel<2, 4, 6, 2, false><<<nb, ENG_THREADS, lds, s>>>(p);
             CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (r >= 3) { best = std::min(best, ms); sum += ms; }
