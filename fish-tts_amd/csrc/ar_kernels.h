@@ -37,9 +37,6 @@ struct GemvP {
     int N, K;
     int pro, epi;
     int nt;  // non-temporal weight loads
-    // vocabulary head at one row: rows are written through and counted per chunk of 4096 rows (done[(row >> 12) * 64 + wave % 64] += rows
-    // written), so samp_cut_kernel - running beside this launch on a forked stream - can walk the logits behind it
-    unsigned* done;
 };
 
 template <typename WT, int NT, int R>
@@ -140,15 +137,8 @@ __device__ __forceinline__ void gemv_finish(const GemvP& p, const int m, const i
                 if (bias) v += ld_elem(bias, row);
                 v = rb<ROUND>(v);
                 if (p.epi == EPI_RESID) v = rb<ROUND>(p.resid[(size_t)m * p.ldr + row] + v);
-                if (p.done) __hip_atomic_store(&p.out[(size_t)m * p.ldo + row], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else p.out[(size_t)m * p.ldo + row] = v;
+                p.out[(size_t)m * p.ldo + row] = v;
             }
-        }
-        if (p.done) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the wave's rows have reached the memory side
-            // 64 counters per chunk (a chunk's ~1000 waves finish within a microsecond or two: one address would
-            // serialise their atomics - measured: the 53 us launch became ~300 us)
-            if (lane == 0) atomicAdd(p.done + (size_t)(row0 >> 12) * 64 + ((row0 / R) & 63), (unsigned)min(R, N - row0));
         }
     }
 }
@@ -1092,165 +1082,6 @@ __device__ __forceinline__ void draw_noise4(const SampP& p, const RowCtl& ctl, c
     for (int e = 0; e < 4; ++e) q[e] = exp1_from_word(r.w[e]);
 }
 
-template <typename WT, bool ROUND>
-__global__ __launch_bounds__(64) void sample_wave_kernel(SampP p) {
-    constexpr int E = 16;
-    const int m = blockIdx.x, lane = threadIdx.x;
-    float* L = p.logits + (size_t)m * p.ldl;
-    const int V = p.V;
-    const RowCtl ctl = p.ctl[m];
-    const int nfv = p.nf[m];
-    const int R = p.ncb + 1;
-    const int* seq = p.seq + (size_t)m * R * p.cap;
-    // element e of this lane is logit IDX(e): four consecutive logits per lane and 256-block
-#define IDX(e) (256 * ((e) >> 2) + 4 * lane + ((e) & 3))
-    float l[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) { const int i = IDX(e); l[e] = i < V ? L[i] : -INFINITY; }
-    if (nfv > 0) {  // repetition penalty: gather all, then scatter (duplicates write the same value)
-        const int it = nfv - 1;
-        const int ws = it < 16 ? 0 : it - 16;
-        const int npen = p.cb == 0 ? R : 16;
-        int id = -1;
-        float nv = 0.f;
-        if (lane < npen) {
-            id = p.cb == 0 ? seq[(size_t)lane * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + lane];
-            if (id >= 0 && id < V) {
-                const float sv = L[id];
-                nv = sv < 0.f ? rb<ROUND>(sv * ctl.rep) : rb<ROUND>(sv / ctl.rep);
-            } else id = -1;
-        }
-        for (int k = 0; k < npen; ++k) {
-            const int idk = __shfl(id, k, 64);
-            const float nvk = __shfl(nv, k, 64);
-            if (idk >= 0 && ((idk & 255) >> 2) == lane) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) if (IDX(e) == idk) l[e] = nvk;
-            }
-        }
-    }
-    if (p.cb == 0 && ctl.ban_eos && p.im_end < V) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) if (IDX(e) == p.im_end) l[e] = -INFINITY;
-    }
-    ArgMax am{-INFINITY, 0x7fffffff};
-#pragma unroll
-    for (int e = 0; e < E; ++e) { const int i = IDX(e); if (i < V) am = better(am, ArgMax{l[e], i}); }
-    am = wave_argmax(am);
-    const float Lmax = am.v;
-    float ex[E];
-    float z = 0.f;
-#pragma unroll
-    for (int e = 0; e < E; ++e) { ex[e] = IDX(e) < V ? expf(l[e] - Lmax) : 0.f; z += ex[e]; }
-    const float Z = wave_sum(z);
-    const float tp = rb<ROUND>(ctl.top_p);
-    auto removed = [&](float cum) { return rb<ROUND>(cum) > tp; };
-    float pr[E];
-    uint32_t key[E];
-    constexpr uint32_t cmask = ROUND ? 0xffff0000u : 0xffffffffu;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        pr[e] = IDX(e) < V ? rb<ROUND>(ex[e] / Z) : 0.f;
-        key[e] = IDX(e) < V ? (order_key(l[e]) & cmask) : 0u;
-    }
-    uint32_t kstar = 0;
-    int nk = 0;
-    bool all_kept = false, only_top = false;
-    if (removed(rb<ROUND>(1.0f / Z))) {  // expf(0)/Z: the mass of rank 0
-        only_top = true;
-    } else {
-        float tot = 0.f;
-#pragma unroll
-        for (int e = 0; e < E; ++e) tot += pr[e];
-        tot = wave_sum(tot);
-        if (!removed(tot)) {
-            all_kept = true;
-        } else {
-            constexpr int lowbit = ROUND ? 16 : 0;
-            for (int bit = 31; bit >= lowbit; --bit) {
-                const uint32_t cand = kstar | (1u << bit);
-                float ms = 0.f;
-#pragma unroll
-                for (int e = 0; e < E; ++e) ms += key[e] >= cand ? pr[e] : 0.f;
-                ms = wave_sum(ms);
-                if (removed(ms)) kstar = cand;
-            }
-            float above = 0.f, cnt = 0.f, pk = 0.f;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                if (key[e] > kstar) above += pr[e];
-                else if (key[e] == kstar && IDX(e) < V) { cnt += 1.f; pk = pr[e]; }
-            }
-            above = wave_sum(above);
-            const int icnt = (int)wave_sum(cnt);
-            pk = wave_max(pk);
-            int lo_n = 0, hi_n = icnt;
-            while (lo_n < hi_n) {
-                const int mid = (lo_n + hi_n + 1) >> 1;
-                if (removed(fmaf((float)mid, pk, above))) hi_n = mid - 1; else lo_n = mid;
-            }
-            nk = lo_n;
-        }
-    }
-    int winner = am.i;
-    if (!only_top) {
-        const float Tc = fmaxf(ctl.temperature, 1e-5f);
-        const float Mt = rb<ROUND>(Lmax / Tc);
-        // members of the cut class are kept in index order: 256-blocks, then lanes, then the 4 sub-indices
-        bool keep[E];
-        int seen = 0;
-        const unsigned long long lower = (1ull << lane) - 1ull;
-#pragma unroll
-        for (int g = 0; g < E / 4; ++g) {
-            bool mem[4];
-            unsigned long long bal[4];
-            int below = 0, total = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = 4 * g + u;
-                mem[u] = IDX(e) < V && !all_kept && key[e] == kstar;
-                bal[u] = __ballot(mem[u]);
-                below += __popcll(bal[u] & lower);
-                total += __popcll(bal[u]);
-            }
-            int rank = seen + below;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = 4 * g + u;
-                const bool valid = IDX(e) < V;
-                keep[e] = valid && (all_kept || key[e] > kstar || (mem[u] && rank < nk));
-                rank += mem[u] ? 1 : 0;
-            }
-            seen += total;
-        }
-        float z2 = 0.f;
-        float et[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) { et[e] = keep[e] ? expf(rb<ROUND>(l[e] / Tc) - Mt) : 0.f; z2 += et[e]; }
-        const float Z2 = wave_sum(z2);
-        const float* qrow = nullptr;
-        if (p.noise && nfv < p.noise_rows) qrow = p.noise + (size_t)nfv * p.noise_row_len + p.noise_off;
-        ArgMax best{-1.f, 0x7fffffff};
-#pragma unroll
-        for (int g = 0; g < E / 4; ++g) {
-            float q4[4];
-            draw_noise4(p, ctl, qrow, IDX(4 * g), nfv, m, V, q4);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = 4 * g + u;
-                const int i = IDX(e);
-                if (i < V) {
-                    const float prob = keep[e] ? rb<ROUND>(et[e] / Z2) : 0.f;
-                    best = better(best, ArgMax{rb<ROUND>(prob / rb<ROUND>(q4[u])), i});
-                }
-            }
-        }
-        winner = wave_argmax(best).i;
-    }
-#undef IDX
-    finish_draw<WT>(p, m, winner, nfv);
-}
-
 // ------------------------------------------------------------------------------------------
 // V <= 1024 with one 256-thread block: 4 consecutive logits per thread in registers, wave
 // reductions on DPP, one barrier per block-wide reduction (partials alternate between two LDS
@@ -1448,17 +1279,20 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// The same draw for a large vocabulary in bf16 precision, spread over the chip in five short
-// launches (one CU cannot evaluate 155 776 exponentials several times per frame in time):
-//   1 samp_hist      penalty + ban; COUNT histogram over the 65 536 possible bf16 logit values
-//                    (every member of a class has the same probability, so counts are enough and
-//                    integer atomics keep it deterministic)
-//   2 samp_threshold one block walks the histogram from the top: max, softmax normaliser,
-//                    inclusive cumulative mass, the cut class k*, how many of its members stay (nk),
-//                    the normaliser of the kept set after temperature
-//   3 samp_count     members of class k* per 1024-logit chunk (ranks tied members by index)
-//   4 samp_race      p/q for every kept logit, best per chunk
-//   5 samp_finish    best over chunks + frame bookkeeping
+// The same draw for a large vocabulary in bf16 precision, in four short launches (one CU cannot evaluate
+// 155 776 exponentials several times per frame in time):
+//   1 samp_cut       penalty + ban; COUNT histogram over the 65 536 possible bf16 logit values in the LDS of one block
+//                    (every member of a class has the same probability, so counts are enough and integer atomics keep
+//                    it deterministic); the same block then walks the histogram from the top: max, softmax normaliser,
+//                    inclusive cumulative mass, the cut class k*, how many of its members stay (nk), the normaliser of
+//                    the kept set after temperature
+//   2 samp_count     members of class k* per 1024-logit chunk (ranks tied members by index)
+//   3 samp_race      p/q for every kept logit, best per chunk
+//   4 samp_finish    best over chunks + frame bookkeeping
+// (measured and removed: the histogram by ~V global atomics + the cut search on its read-back, 40 + 39 us per row; the
+// histogram spread over 39 blocks with the search in the last-arriving one, 75 us; count + race + finish as one launch with
+// a chained look-back, the same 0.104 ms per frame as three launches; this kernel beside the head GEMV on a forked stream,
+// walking behind per-chunk completion counters, 1.416-1.419 against 1.412 ms per frame)
 // ------------------------------------------------------------------------------------------
 struct SampCut {
     unsigned kstar;   // 16-bit class of the cut (valid unless all_kept)
@@ -1468,18 +1302,9 @@ struct SampCut {
     float Lmax, Mt, Z2, Tc;
 };
 
-constexpr int SAMP_REP = 8;                        // histogram replicas (spreads same-class atomics)
-constexpr size_t SAMP_REP_STRIDE = 65536 + 1024;   // class counts, then counts per group of 64 classes
-constexpr size_t SAMP_HIST_STRIDE = SAMP_REP * SAMP_REP_STRIDE;
-
 struct SampBigP {
     SampP s;
-    unsigned* hist;      // [M][65536 + 1024]: class counts, then counts per group of 64 classes
     SampCut* cut;        // [M]
-    unsigned* ticket;    // [M] arrival counter of samp_cut_fused_kernel / samp_tail_kernel (zero between launches)
-    unsigned* tail_pub;  // [M][nchunk] samp_tail_kernel: (generation << 12) | members of the cut class in the chunk
-    unsigned* tail_gen;  // [M] generation of the last completed samp_tail_kernel launch
-    unsigned* head_done; // samp_cut_kernel beside the head GEMV (one row): rows written per 4096-row chunk (GemvP::done), or nullptr
     int* chunk_cnt;      // [M][nchunk]
     float* part_score;   // [M][nchunk]
     int* part_idx;       // [M][nchunk]
@@ -1490,69 +1315,6 @@ __device__ __forceinline__ float key16_value(unsigned k16) {
     const uint32_t k = k16 << 16;
     const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~(k | 0xffffu);
     return __uint_as_float(u);
-}
-
-static __global__ __launch_bounds__(256) void samp_hist_kernel(SampBigP b) {
-    __shared__ int pen_id[32];
-    __shared__ float pen_val[32];
-    __shared__ unsigned grp_s[1024];
-    const SampP& p = b.s;
-    const int m = blockIdx.y, tid = threadIdx.x;
-    const int c0 = blockIdx.x * 1024;
-    float* L = p.logits + (size_t)m * p.ldl;
-    const int V = p.V;
-    const RowCtl ctl = p.ctl[m];
-    const int nfv = p.nf[m];
-    const int R = p.ncb + 1;
-    const int* seq = p.seq + (size_t)m * R * p.cap;
-    if (nfv > 0) {
-        const int it = nfv - 1;
-        const int ws = it < 16 ? 0 : it - 16;
-        const int npen = p.cb == 0 ? R : 16;
-        if (tid < npen) {
-            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
-            pen_id[tid] = -1;
-            if (id >= c0 && id < c0 + 1024 && id < V) {
-                const float sv = L[id];
-                pen_id[tid] = id;
-                pen_val[tid] = sv < 0.f ? round_bf16(sv * ctl.rep) : round_bf16(sv / ctl.rep);
-            }
-        }
-        __syncthreads();
-        if (tid < npen && pen_id[tid] >= 0) L[pen_id[tid]] = pen_val[tid];
-    }
-    if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end >= c0 && p.im_end < c0 + 1024 && p.im_end < V)
-        L[p.im_end] = -INFINITY;
-    __syncthreads();
-    unsigned* hist = b.hist + (size_t)m * SAMP_HIST_STRIDE + (size_t)(blockIdx.x % SAMP_REP) * SAMP_REP_STRIDE;
-    unsigned* grp = hist + 65536;
-    const int lane = tid & 63;
-    for (int i = tid; i < 1024; i += 256) grp_s[i] = 0u;
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = c0 + e * 256 + tid;
-        const bool valid = i < V;
-        const unsigned k = valid ? order_key(L[i]) >> 16 : 0u;
-        // one atomic per distinct class per wave (peaked or flat logits put many lanes in one class)
-        unsigned long long active = __ballot(valid);
-        while (active) {
-            const int leader = __ffsll((long long)active) - 1;
-            const unsigned kk = (unsigned)__builtin_amdgcn_readlane((int)k, leader);
-            const unsigned long long same = __ballot(valid && k == kk);
-            if (lane == leader) {
-                const unsigned n = (unsigned)__popcll(same);
-                atomicAdd(&hist[kk], n);
-                atomicAdd(&grp_s[kk >> 6], n);  // LDS: one global atomic per touched group per block below
-            }
-            active &= ~same;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < 1024; i += 256) {
-        const unsigned n = grp_s[i];
-        if (n) atomicAdd(&grp[i], n);
-    }
 }
 
 // LDS image of the histogram: thread t owns classes [64 t, 64 t + 64) as 32 dwords of two u16 counts,
@@ -1694,164 +1456,8 @@ __device__ __forceinline__ void samp_cut_from_image(const SampBigP& b, const int
     }
 }
 
-// Builds the LDS image of row m's class histogram from the replicated global counters (and clears them), then runs the
-// cut search.  COH: the counters were filled by atomics of blocks of THIS launch (samp_cut_fused_kernel), so they are
-// read with agent-scope loads (past this XCD's L2, which may hold last frame's lines); the clearing stores reach memory at
-// the end of the kernel either way.
-template <bool COH>
-__device__ __forceinline__ void samp_threshold_body(const SampBigP& b, const int m, uint32_t* cimg, SampThShared& sh) {
-    const int tid = threadIdx.x;
-    unsigned* hist0 = b.hist + (size_t)m * SAMP_HIST_STRIDE;
-    auto ld = [&](const unsigned* q) -> unsigned {
-        if (COH) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return *q;
-    };
-    if (tid == 0) sh.ovf_n = 0;
-    __syncthreads();
-    // ---- stage: thread t owns group t (classes [64 t, 64 t + 64)); replicas are summed, then cleared
-    uint32_t* row = cimg + tid * SAMP_TH_ROW;
-    int kmax_t = -1;
-    unsigned gtot = 0;
-    unsigned gr[SAMP_REP];
-#pragma unroll
-    for (int r = 0; r < SAMP_REP; ++r) { gr[r] = ld(hist0 + (size_t)r * SAMP_REP_STRIDE + 65536 + tid); gtot += gr[r]; }
-    const bool has = gtot != 0u;
-    if (has) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {  // 32 classes at a time keeps the sums in registers
-            unsigned cs[32];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) cs[j] = 0u;
-#pragma unroll
-            for (int r = 0; r < SAMP_REP; ++r) {
-                if (gr[r]) {
-                    unsigned* hr = hist0 + (size_t)r * SAMP_REP_STRIDE;
-                    if (half == 1) hr[65536 + tid] = 0u;
-                    U4* h4 = reinterpret_cast<U4*>(hr + 64 * tid + 32 * half);
-                    U4 q8[8];
-                    if (COH) {
-                        // eight 16-byte loads past the L2 in flight together (one agent-scope atomic load per counter
-                        // is a full memory round trip each: 512 of them in a row per active group cost 135 us)
-                        asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
-                                     "global_load_dwordx4 %2, %8, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
-                                     "global_load_dwordx4 %4, %8, off offset:64 sc1\n\tglobal_load_dwordx4 %5, %8, off offset:80 sc1\n\t"
-                                     "global_load_dwordx4 %6, %8, off offset:96 sc1\n\tglobal_load_dwordx4 %7, %8, off offset:112 sc1\n\t"
-                                     "s_waitcnt vmcnt(0)"
-                                     : "=&v"(q8[0]), "=&v"(q8[1]), "=&v"(q8[2]), "=&v"(q8[3]), "=&v"(q8[4]), "=&v"(q8[5]), "=&v"(q8[6]), "=&v"(q8[7])
-                                     : "v"(h4) : "memory");
-                    } else {
-#pragma unroll
-                        for (int v = 0; v < 8; ++v) q8[v] = h4[v];
-                    }
-#pragma unroll
-                    for (int v = 0; v < 8; ++v) {
-                        const U4 q = q8[v];
-                        h4[v] = U4{0u, 0u, 0u, 0u};
-                        cs[4 * v] += q.x; cs[4 * v + 1] += q.y; cs[4 * v + 2] += q.z; cs[4 * v + 3] += q.w;
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 32; j += 2) {
-                const int cj = 32 * half + j;
-                unsigned c0 = cs[j], c1 = cs[j + 1];
-                if (c0) kmax_t = 64 * tid + cj;
-                if (c1) kmax_t = 64 * tid + cj + 1;
-                if (c0 >= 65535u) { const int sl = atomicAdd(&sh.ovf_n, 1); if (sl < SAMP_TH_OVF) { sh.ovf_key[sl] = 64 * tid + cj; sh.ovf_cnt[sl] = c0; } c0 = 65535u; }
-                if (c1 >= 65535u) { const int sl = atomicAdd(&sh.ovf_n, 1); if (sl < SAMP_TH_OVF) { sh.ovf_key[sl] = 64 * tid + cj + 1; sh.ovf_cnt[sl] = c1; } c1 = 65535u; }
-                row[cj >> 1] = c0 | (c1 << 16);
-            }
-        }
-    }
-    samp_cut_from_image(b, m, cimg, sh, has, kmax_t);
-}
-
-static __global__ __launch_bounds__(1024) void samp_threshold_kernel(SampBigP b) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cimg[];
-    __shared__ SampThShared sh;
-    samp_threshold_body<false>(b, blockIdx.x, cimg, sh);
-}
-
-// samp_hist_kernel and samp_threshold_kernel as ONE launch: blocks of 1024 threads count 4096 logits each into the
-// replicated global histogram (one atomic per distinct class and wave); the block whose ticket comes last builds the
-// image and searches the cut.  The single-block samp_cut_kernel spends ~30 of its 40 us walking the 155 776 logits of
-// the vocabulary row with LDS atomics on one CU; here 39 CUs do that part.
-static __global__ __launch_bounds__(1024) void samp_cut_fused_kernel(SampBigP b) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t cimg[];
-    __shared__ SampThShared sh;
-    __shared__ int pen_id[32];
-    __shared__ float pen_val[32];
-    __shared__ int is_last;
-    unsigned* grp_s = cimg;       // [1024] group counts of this block (the image is built later, by the last block only)
-    const SampP& p = b.s;
-    const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    const int c0 = blockIdx.x * 4096;
-    float* L = p.logits + (size_t)m * p.ldl;
-    const int V = p.V;
-    const RowCtl ctl = p.ctl[m];
-    const int nfv = p.nf[m];
-    const int R = p.ncb + 1;
-    const int* seq = p.seq + (size_t)m * R * p.cap;
-    if (nfv > 0) {
-        const int it = nfv - 1;
-        const int ws = it < 16 ? 0 : it - 16;
-        const int npen = p.cb == 0 ? R : 16;
-        if (tid < npen) {
-            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
-            pen_id[tid] = -1;
-            if (id >= c0 && id < c0 + 4096 && id < V) {
-                const float sv = L[id];
-                pen_id[tid] = id;
-                pen_val[tid] = sv < 0.f ? round_bf16(sv * ctl.rep) : round_bf16(sv / ctl.rep);
-            }
-        }
-        __syncthreads();
-        if (tid < npen && pen_id[tid] >= 0) L[pen_id[tid]] = pen_val[tid];
-    }
-    if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end >= c0 && p.im_end < c0 + 4096 && p.im_end < V)
-        L[p.im_end] = -INFINITY;
-    grp_s[tid] = 0u;
-    __syncthreads();
-    unsigned* hist = b.hist + (size_t)m * SAMP_HIST_STRIDE + (size_t)(blockIdx.x % SAMP_REP) * SAMP_REP_STRIDE;
-    unsigned* grp = hist + 65536;
-    float lv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { const int i = c0 + e * 1024 + tid; lv[e] = i < V ? L[i] : 0.f; }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = c0 + e * 1024 + tid;
-        const bool valid = i < V;
-        const unsigned k = valid ? order_key(lv[e]) >> 16 : 0u;
-        unsigned long long active = __ballot(valid);
-        while (active) {
-            const int leader = __ffsll((long long)active) - 1;
-            const unsigned kk = (unsigned)__builtin_amdgcn_readlane((int)k, leader);
-            const unsigned long long same = __ballot(valid && k == kk);
-            if (lane == leader) {
-                const unsigned n = (unsigned)__popcll(same);
-                atomicAdd(&hist[kk], n);
-                atomicAdd(&grp_s[kk >> 6], n);
-            }
-            active &= ~same;
-        }
-    }
-    __syncthreads();
-    { const unsigned n = grp_s[tid]; if (n) atomicAdd(&grp[tid], n); }
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned t = atomicAdd(&b.ticket[m], 1u);
-        is_last = t == gridDim.x - 1 ? 1 : 0;
-        if (is_last) __hip_atomic_store(&b.ticket[m], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!is_last) return;
-    samp_threshold_body<true>(b, m, cimg, sh);
-}
-
 // Histogram and cut search of one row in ONE block: the 65 536 class counters live in LDS as packed u16 pairs (the
-// image samp_cut_from_image reads), filled with LDS atomics, so neither the ~V global atomics of samp_hist_kernel nor the
-// replica read-back of samp_threshold_kernel happen.  A packed counter wraps only if >= 65 536 logits of the row share
+// image samp_cut_from_image reads), filled with LDS atomics.  A packed counter wraps only if >= 65 536 logits of the row share
 // one bf16 value; the check sum(counts) == V catches that (any wrap changes the total) and the row is recounted exactly
 // with saturating updates.  Also applies the repetition penalty / EOS ban to the row.
 static __global__ __launch_bounds__(1024) void samp_cut_kernel(SampBigP b) {
@@ -1869,13 +1475,12 @@ static __global__ __launch_bounds__(1024) void samp_cut_kernel(SampBigP b) {
     const int* seq = p.seq + (size_t)m * R * p.cap;
     for (int i = tid; i < SAMP_TH_THREADS * SAMP_TH_ROW; i += 1024) cimg[i] = 0u;
     if (tid == 0) sh.ovf_n = 0;
-    const bool ov = b.head_done != nullptr;   // the head GEMV is still writing L: walk behind its per-chunk counters
     const int npen = nfv > 0 ? (p.cb == 0 ? R : 16) : 0;
     auto count1 = [&](float v) {
         const unsigned k = order_key(v) >> 16;
         atomicAdd(&cimg[(k >> 6) * SAMP_TH_ROW + ((k & 63u) >> 1)], (k & 1u) ? 0x10000u : 1u);
     };
-    if (!ov) {
+    {
         if (nfv > 0) {   // repetition penalty (inference.py:38-46): gather all, then scatter (duplicates write the same value)
             const int it = nfv - 1;
             const int ws = it < 16 ? 0 : it - 16;
@@ -1920,71 +1525,6 @@ static __global__ __launch_bounds__(1024) void samp_cut_kernel(SampBigP b) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) if (base + u * 1024 + tid < V) count1(f[u]);
         }
-    } else {
-        // ---- beside the head GEMV: a range of the row is read once the GEMV's counters say it is complete (the rows were
-        // written through); penalty / EOS ban are applied per range, gather first, then scatter, as above.  All accesses to
-        // L go past this CU's L1 and this XCD's stale L2 lines (agent scope).
-        if (tid < 32) pen_id[tid] = -1;
-        if (tid < npen) {
-            const int it = nfv - 1;
-            const int ws = it < 16 ? 0 : it - 16;
-            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
-            if (id >= 0 && id < V) pen_id[tid] = id;
-        }
-        __syncthreads();
-        auto ready = [&](int lo, int hi) {
-            const int cfirst = lo >> 12, nck = ((hi - 1) >> 12) - cfirst + 1;      // <= 4 chunks: <= 256 counters
-            if (tid < 64) {
-                const unsigned want = (unsigned)(hi - lo);
-                const unsigned* cw = b.head_done + (size_t)cfirst * 64 + tid * 4;
-                const bool on = tid * 4 < nck * 64;
-                for (int spin = 0; spin < (1 << 17); ++spin) {      // (bounded: ~0.1 s; a frame then fails its parity test instead of hanging)
-                    U4 q{0u, 0u, 0u, 0u};
-                    if (on) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(cw) : "memory");
-                    const float got = wave_sum((float)(q.x + q.y + q.z + q.w));     // (<= 16 384: exact)
-                    if (got >= (float)want) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (on) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(cw), "v"(U4{0u, 0u, 0u, 0u}) : "memory");   // for the next frame
-            }
-            __syncthreads();
-            const int id = tid < npen ? pen_id[tid] : -1;
-            const bool mine = id >= lo && id < hi;
-            if (mine) {
-                const float sv = __hip_atomic_load(L + id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pen_val[tid] = sv < 0.f ? round_bf16(sv * ctl.rep) : round_bf16(sv / ctl.rep);
-            }
-            __syncthreads();
-            if (mine) __hip_atomic_store(L + id, pen_val[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (p.cb == 0 && ctl.ban_eos && tid == 0 && p.im_end >= lo && p.im_end < hi)
-                __hip_atomic_store(L + p.im_end, -INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        };
-        const int V16 = ((reinterpret_cast<uintptr_t>(L) & 15) == 0) ? (V / 16384) * 16384 : 0;
-        for (int base = 0; base < V16; base += 16384) {
-            ready(base, base + 16384);
-            U4 q[4];
-            const float* src = L + base + tid * 4;
-            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
-                         "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\t"
-                         "s_waitcnt vmcnt(0)"
-                         : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])
-                         : "v"(src), "v"(src + 4096), "v"(src + 8192), "v"(src + 12288) : "memory");
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                count1(__uint_as_float(q[u].x)); count1(__uint_as_float(q[u].y));
-                count1(__uint_as_float(q[u].z)); count1(__uint_as_float(q[u].w));
-            }
-        }
-        if (V16 < V) ready(V16, V);
-        for (int base = V16; base < V; base += 4096) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = base + u * 1024 + tid;
-                if (i < V) count1(__hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            }
-        }
     }
     __syncthreads();
     // my group: occupancy, highest occupied class, and the row total for the wrap check
@@ -2009,7 +1549,7 @@ static __global__ __launch_bounds__(1024) void samp_cut_kernel(SampBigP b) {
         if (tid < SAMP_TH_OVF) { exc_key[tid] = 0xffffffffu; exc_cnt[tid] = 0u; }
         __syncthreads();
         for (int i = tid; i < V; i += 1024) {
-            const unsigned k = order_key(ov ? __hip_atomic_load(L + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : L[i]) >> 16;
+            const unsigned k = order_key(L[i]) >> 16;
             uint32_t* d = &cimg[(k >> 6) * SAMP_TH_ROW + ((k & 63u) >> 1)];
             const unsigned shft = (k & 1u) * 16u;
             for (;;) {
@@ -2146,116 +1686,6 @@ __global__ __launch_bounds__(256) void samp_finish_kernel(SampBigP b) {
     for (int w = 1; w < 4; ++w) t = better(t, ArgMax{red[w], redi[w]});
     __syncthreads();
     finish_draw<WT>(p, m, t.i, p.nf[m]);
-}
-
-// samp_count + samp_race + samp_finish of ONE row as one launch (batch-1 frames: three ~5 us launches and two launch
-// boundaries for ~3 us of work).  Block c counts the cut-class members of its chunk and publishes the count tagged with the
-// launch generation; it then waits for the counts of the chunks before it (chained look-back: every block of the grid is
-// resident - nchunk blocks of 256 threads - and depends only on lower block indices), runs samp_race_kernel's arithmetic
-// on its chunk, publishes its best (score, index), and the block whose ticket comes last reduces them and does the frame
-// bookkeeping (samp_finish_kernel).  Same decisions as the three kernels: counts are integers, the race and the final
-// arg-max are the same operations on the same values.
-template <typename WT>
-__global__ __launch_bounds__(256) void samp_tail_kernel(SampBigP b) {
-    __shared__ float red[4];
-    __shared__ int redi[4];
-    __shared__ int wcnt[4];
-    __shared__ int last_s;
-    const SampP& p = b.s;
-    const int m = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c0 = blockIdx.x * 1024;
-    const float* L = p.logits + (size_t)m * p.ldl;
-    const int V = p.V;
-    const RowCtl ctl = p.ctl[m];
-    const int nfv = p.nf[m];
-    const SampCut cut = b.cut[m];
-    unsigned* pub = b.tail_pub + (size_t)m * b.nchunk;
-    const unsigned gen = (__hip_atomic_load(b.tail_gen + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u) & 0xfffffu;
-    // this thread owns 4 consecutive logits, so index order = thread order
-    float l[4];
-    bool member[4];
-    int mine = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = c0 + 4 * tid + e;
-        l[e] = i < V ? L[i] : -INFINITY;
-        member[e] = i < V && !cut.all_kept && (order_key(l[e]) >> 16) == cut.kstar;
-        mine += member[e] ? 1 : 0;
-    }
-    int incl = mine;  // inclusive prefix over lanes
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) wcnt[wave] = incl;
-    __syncthreads();
-    if (tid == 0)   // the chunk's member count, visible to the blocks after this one
-        __hip_atomic_store(pub + blockIdx.x, (gen << 12) | (unsigned)(wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // rank base: members of the cut class in earlier chunks (chained look-back)
-    float basef = 0.f;
-    for (int i = tid; i < (int)blockIdx.x; i += 256) {
-        unsigned v = 0;
-        for (long spin = 0; spin < (1l << 26); ++spin) {
-            v = __hip_atomic_load(pub + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((v >> 12) == gen) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        basef += (float)(v & 0xfffu);
-    }
-    basef = wave_sum(basef);
-    if (lane == 0) red[wave] = basef;
-    __syncthreads();
-    const int base = (int)(red[0] + red[1] + red[2] + red[3]);
-    __syncthreads();
-    int rank = base + incl - mine;
-    for (int w = 0; w < wave; ++w) rank += wcnt[w];
-    const float* qrow = nullptr;
-    if (p.noise && nfv < p.noise_rows) qrow = p.noise + (size_t)nfv * p.noise_row_len + p.noise_off;
-    ArgMax best{-1.f, 0x7fffffff};
-    float q4[4];
-    draw_noise4(p, ctl, qrow, c0 + 4 * tid, nfv, m, V, q4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int i = c0 + 4 * tid + e;
-        if (i < V) {
-            bool keep = cut.all_kept || (order_key(l[e]) >> 16) > cut.kstar;
-            if (member[e]) { keep = rank < cut.nk; ++rank; }
-            const float prob = keep ? round_bf16(expf(round_bf16(l[e] / cut.Tc) - cut.Mt) / cut.Z2) : 0.f;
-            best = better(best, ArgMax{round_bf16(prob / round_bf16(q4[e])), i});
-        }
-    }
-    best = wave_argmax(best);
-    if (lane == 0) { red[wave] = best.v; redi[wave] = best.i; }
-    __syncthreads();
-    if (tid == 0) {
-        ArgMax t{red[0], redi[0]};
-        for (int w = 1; w < 4; ++w) t = better(t, ArgMax{red[w], redi[w]});
-        __hip_atomic_store(b.part_score + (size_t)m * b.nchunk + blockIdx.x, t.v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(b.part_idx + (size_t)m * b.nchunk + blockIdx.x, t.i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned tk = atomicAdd(b.ticket + m, 1u);
-        last_s = tk == gridDim.x - 1 ? 1 : 0;
-    }
-    __syncthreads();
-    if (!last_s) return;
-    // ---- the block that arrived last: best over the chunks + frame bookkeeping
-    ArgMax fin{-2.f, 0x7fffffff};
-    for (int i = tid; i < b.nchunk; i += 256)
-        fin = better(fin, ArgMax{__hip_atomic_load(b.part_score + (size_t)m * b.nchunk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                 __hip_atomic_load(b.part_idx + (size_t)m * b.nchunk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)});
-    fin = wave_argmax(fin);
-    __syncthreads();
-    if (lane == 0) { red[wave] = fin.v; redi[wave] = fin.i; }
-    __syncthreads();
-    ArgMax t{red[0], redi[0]};
-    for (int w = 1; w < 4; ++w) t = better(t, ArgMax{red[w], redi[w]});
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_store(b.ticket + m, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(b.tail_gen + m, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    finish_draw<WT>(p, m, t.i, nfv);
 }
 
 }  // namespace ft

@@ -523,30 +523,26 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
     p.out_act = io.out_act; p.alpha = io.alpha; p.ldo = io.ldo;
     int halo = 0;
     for (int i = 0; i < w.ntap; ++i) halo = std::max(halo, -w.offs[i]);
-    static const bool legacy = getenv("FT_CODEC_GEMM_V0") != nullptr;
     // few rows (the 215-frame transformers, the first up-sampling stage): a 64x64 tile grid leaves most CUs idle and every
     // block walks all of K alone (20-75 us per GEMM); the skinny kernel cuts N into 16-row blocks and splits K over the
     // waves of a block (weights streamed once per 64 rows)
     // (measured per GEMM at 215 / 430 / 860 rows: N = 1024 skinny 8-13 us against 21-75 us; N = 3072 equal; N >= 4096
     // the tile kernel wins, 23 against 35 us: its grid is already >= 256 blocks there)
-    static const long skinny_m = getenv("FT_CODEC_SKINNY_M") ? atol(getenv("FT_CODEC_SKINNY_M")) : 1024;
-    static const long skinny_n = getenv("FT_CODEC_SKINNY_N") ? atol(getenv("FT_CODEC_SKINNY_N")) : 2048;
-    if (!legacy && w.ntap == 1 && w.offs[0] == 0 && io.M <= skinny_m && w.N <= skinny_n && io.T_in >= io.M && w.K % 128 == 0 && w.N % 2 == 0 &&
+    constexpr long skinny_m = 1024, skinny_n = 2048;
+    if (w.ntap == 1 && w.offs[0] == 0 && io.M <= skinny_m && w.N <= skinny_n && io.T_in >= io.M && w.K % 128 == 0 && w.N % 2 == 0 &&
         (io.act == ACT_NONE || io.act == ACT_SWIGLU || io.act == ACT_GELU) && !io.out_act) {
         p.ldw = 0;
         skinny_gemm_launch<4>(p, (io.M + 63) / 64, st);
         return;
     }
-    if (w.K % 32 == 0 && halo <= 56 && !legacy) {  // pipelined kernel: A stripe shared by the taps, B double-buffered
+    if (w.K % 32 == 0 && halo <= 56) {  // pipelined kernel: A stripe shared by the taps, B double-buffered
 #define FT_TG(BM_, BN_, BK_)                                                                                   \
     tapgemm64_kernel<BM_, BN_, BK_><<<dim3((io.M + BM_ - 1) / BM_, (w.N + BN_ - 1) / BN_, 1), 256,              \
                                       std::max((size_t)((BM_ + 56) + 2 * BN_) * (BK_ + 8) * 2,                  \
                                                (size_t)(BM_ / 2) * (BN_ + 4) * 4), st>>>(p)
-        // 64-row tiles everywhere: the 128x128 instantiation spills registers and, at these sizes, leaves CUs idle
-        // (215-frame decode 9.9 -> 6.2 ms); FT_CODEC_BIG_M=<rows> restores the wide tiles above that many rows
-        static const long big_thr = getenv("FT_CODEC_BIG_M") ? atol(getenv("FT_CODEC_BIG_M")) : (1L << 60);
+        // 64-row tiles on 4 waves below 4096 rows: the 4-wave 128 x 128 instantiation spills registers and, at these sizes,
+        // leaves CUs idle (215-frame decode 9.9 -> 6.2 ms)
         const bool vec_ok = io.act != ACT_SWIGLU && w.N % 8 == 0 && w.n_mod % 8 == 0 && io.ldo % 8 == 0 && io.ldr % 8 == 0;
-        const bool small_m = io.M <= big_thr || !vec_ok;   // the 128x128 tile has the vector epilogue only
         const bool k64 = w.K % 64 == 0;
         // many rows (the decoder's convolutions after the first up-sampling): 128-row tiles on 8 waves - the 64 x 64 tile is
         // bound by the L2 bandwidth its weight-tile re-reads need (codec_kernels.h)
@@ -560,25 +556,21 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
         tapgemm64_kernel<BM_, BN_, BK_, NWM_, NWN_><<<dim3((io.M + BM_ - 1) / BM_, (w.N + BN_ - 1) / BN_, 1),     \
                                                       64 * NWM_ * NWN_, lds8_, st>>>(p);                          \
     } while (0)
-        static const long tile8_m = getenv("FT_CODEC_TILE8_M") ? atol(getenv("FT_CODEC_TILE8_M")) : 4096;
-        static const long tile256_m = getenv("FT_CODEC_TILE256_M") ? atol(getenv("FT_CODEC_TILE256_M")) : (1L << 60);
+        constexpr long tile8_m = 4096, wide_m = 30000;
         if (vec_ok && io.M >= tile8_m && (w.N % 128 == 0 || w.N % 96 == 0)) {
             // full-width tiles where the whole N fits one block column (A read once): 128 x 192 (N = 192, 384), 256 x 96 (N = 96)
-            static const long wide_m = getenv("FT_CODEC_WIDE_M") ? atol(getenv("FT_CODEC_WIDE_M")) : 30000;
+            // (256 x 128 x 32 on 8 waves was measured slower: 4.76 against 4.57 ms per 215-frame decode)
             if (io.M >= wide_m && w.N % 192 == 0) { FT_TG8(128, 192, 32, 2, 4); return; }
             if (io.M >= wide_m && w.N == 96) { FT_TG8(256, 96, 32, 4, 2); return; }
-            if (w.N % 128 == 0 && io.M >= tile256_m) FT_TG8(256, 128, 32, 4, 2);
-            else if (w.N % 128 == 0) { if (k64) FT_TG8(128, 128, 64, 2, 4); else FT_TG8(128, 128, 32, 2, 4); }
+            if (w.N % 128 == 0) { if (k64) FT_TG8(128, 128, 64, 2, 4); else FT_TG8(128, 128, 32, 2, 4); }
             else { if (k64) FT_TG8(128, 96, 64, 4, 2); else FT_TG8(128, 96, 32, 4, 2); }
             return;
         }
 #undef FT_TG8
         if (w.N % 128 == 0 || (w.N % 96 != 0 && w.N > 96)) {
-            if (small_m) { if (k64) FT_TG(64, 64, 64); else FT_TG(64, 64, 32); }
-            else { if (k64) FT_TG(128, 128, 64); else FT_TG(128, 128, 32); }
+            if (k64) FT_TG(64, 64, 64); else FT_TG(64, 64, 32);
         } else if (w.N % 96 == 0) {
-            if (small_m) { if (k64) FT_TG(64, 96, 64); else FT_TG(64, 96, 32); }
-            else { if (k64) FT_TG(128, 96, 64); else FT_TG(128, 96, 32); }
+            if (k64) FT_TG(64, 96, 64); else FT_TG(64, 96, 32);
         } else {
             if (k64) FT_TG(128, 64, 64); else FT_TG(128, 64, 32);
         }

@@ -48,13 +48,9 @@ struct TapGemmP {
     float* ss_out;
     int ss_nblk, ss_ld;
     float eps;
-    // skinny kernel, RMSNorm of the OUTPUT rows by the block that finishes last (the norm launch that would follow a
-    // Wo / W2 GEMM in a 17..128-row lock-step batch costs ~5 us for ~2 us of work): out_f32 is written through,
-    // the last block (ticket) re-reads the M x N rows past its L2 and writes tail_out = round(round(x / rms) * gain)
-    // with rmsnorm_llama_rows_kernel's arithmetic (256 threads per row, same summation order).  N == 1024.
-    const bf16_t* tail_gain;
-    bf16_t* tail_out;
-    unsigned* ticket;
+    // (measured and removed: the RMSNorm of the OUTPUT rows by the block that finishes last - write-through stores, a
+    // returning ticket atomic and the last block's trip to the memory side cost more than the ~5 us norm launch they
+    // replaced: 4.67 against 3.54 ms per 32-row frame)
 };
 
 // offs[] lives in the kernel arguments: a runtime index would force the whole struct into scratch
@@ -732,68 +728,12 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(TapGemmP p) {
                 if (p.resid_bf) v += bf16_bits_to_f32(p.resid_bf[(size_t)t * p.ldr + n]);
                 const size_t oi = (size_t)t * p.ldo + n;
                 stored = p.round_f32_out ? round_bf16(v) : v;
-                if (p.out_f32) {
-                    if (p.tail_out) __hip_atomic_store(&p.out_f32[oi], stored, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // written through
-                    else p.out_f32[oi] = stored;
-                }
+                if (p.out_f32) p.out_f32[oi] = stored;
                 if (p.out_bf) p.out_bf[oi] = f32_to_bf16_bits(v);
             }
             if (p.ss_out) {   // this block's share of the row's sum of squares, for the next GEMM's fused RMSNorm
                 const float sq = row16_sum(stored * stored);
                 if (c == 0 && t < p.M) p.ss_out[(size_t)t * p.ss_ld + blockIdx.x] = sq;
-            }
-        }
-        if (p.tail_out) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's write-through stores are acknowledged
-            __syncthreads();
-            int* last_s = reinterpret_cast<int*>(skinny_smem);       // (inv_s is dead by now)
-            if (tid == 0) {
-                const unsigned tk = atomicAdd(p.ticket, 1u);
-                const int last = tk == gridDim.x * gridDim.y - 1 ? 1 : 0;
-                if (last) __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *last_s = last;
-            }
-            __syncthreads();
-            const bool last = *last_s != 0;
-            __syncthreads();
-            if (last) {
-                // 16 rows per 256-thread group at a time: ALL their values are requested before the first is used (one
-                // trip to the memory side per batch; a row-by-row loop cost two exposed trips per row: 16 us per GEMM)
-                float* red = reinterpret_cast<float*>(skinny_smem);  // [RB][NW] partial sums
-                constexpr int NGRP = NW / 4, RB = 16;
-                const int grp = tid >> 8, gt = tid & 255, D = p.N;     // D == 1024 (host check): 4 values per thread and row
-                for (int rb0 = 0; rb0 < p.M; rb0 += RB * NGRP) {
-                    float v[RB][4];
-#pragma unroll
-                    for (int i = 0; i < RB; ++i) {
-                        const int row = min(rb0 + i * NGRP + grp, p.M - 1);
-                        const float* xr = p.out_f32 + (size_t)row * p.ldo + gt;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[i][e] = __hip_atomic_load(xr + 256 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-#pragma unroll
-                    for (int i = 0; i < RB; ++i) {
-                        float ss = 0.f;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) ss = fmaf(v[i][e], v[i][e], ss);     // d = t, t + 256, .. in that order
-                        ss = wave_sum(ss);
-                        if (lane == 0) red[i * NW + wave] = ss;
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int i = 0; i < RB; ++i) {
-                        const int row = rb0 + i * NGRP + grp;
-                        if (row < p.M) {
-                            const float* rr = red + i * NW + grp * 4;
-                            const float inv = rsqrt_exact((((rr[0] + rr[1]) + rr[2]) + rr[3]) / (float)D + p.eps);
-                            bf16_t* o = p.tail_out + (size_t)row * D + gt;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                o[256 * e] = f32_to_bf16_bits(round_bf16(v[i][e] * inv) * bf16_bits_to_f32(p.tail_gain[gt + 256 * e]));
-                        }
-                    }
-                    __syncthreads();
-                }
             }
         }
     }
@@ -810,8 +750,6 @@ static inline void skinny_gemm_launch(const TapGemmP& p, int gy, hipStream_t st)
     const dim3 grid((p.N + 15) / 16, gy);
     int nw = skinny_waves(p.N, p.K, TS);
     if (p.gain && TS == 4) nw = 4;   // the fused norm's extra registers: keep the 64-row variant off the spill edge
-    static const bool direct = getenv("FT_SKINNY_DIRECT") != nullptr;
-    const bool xlds = !direct;
 #define FT_SK(NWV, NORMV, XV)                                                                                       \
     do {                                                                                                              \
         constexpr size_t lds_ = skinny_lds_bytes<TS, NWV>(XV);                                                        \
@@ -821,7 +759,7 @@ static inline void skinny_gemm_launch(const TapGemmP& p, int gy, hipStream_t st)
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_); });            \
         skinny_gemm_kernel<TS, NWV, NORMV, XV><<<grid, NWV * 64, lds_, st>>>(p);                                      \
     } while (0)
-#define FT_SK_X(NWV, NORMV) do { if (xlds) FT_SK(NWV, NORMV, true); else FT_SK(NWV, NORMV, false); } while (0)
+#define FT_SK_X(NWV, NORMV) FT_SK(NWV, NORMV, true)      /* X rows staged through LDS (the direct fragment loads were slower) */
     if (p.gain) {
         switch (nw) {
             case 12: FT_SK_X(12, true); break;

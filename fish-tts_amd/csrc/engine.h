@@ -41,9 +41,7 @@ struct ft_ctx {
     ft_codec_config cc{};
     bool has_codec = false;
     int device = 0;
-    hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool fork_fast0 = true;
+    hipStream_t stream = nullptr;
     std::string err;
     bool finalized = false;
 
@@ -74,8 +72,6 @@ struct ft_ctx {
     ft::bf16_t* mb_xb = nullptr;
     float* mb_ss = nullptr;   // [max(dim, fast_dim) / 16][max_batch]
     bool wide_fuse = false;
-    unsigned* gemm_ticket = nullptr;   // arrival counter of the skinny GEMM's tail norm (zero between launches)
-    bool tail_norm = false;            // norms after Wo / W2 inside those GEMMs' last blocks (17..128 lock-step rows)
     int wide_fuse_max = 16;   // largest lock-step batch that takes the fused-norm GEMMs
     int wide_min = 5;   // measured: the MFMA path wins from 5 rows (B=5: 2.79 vs 3.33 ms per frame), B <= 4 keeps the bit-exact multi-row GEMV
     bool wide_ok = false;
@@ -92,18 +88,10 @@ struct ft_ctx {
     long noise_rows = 0, noise_row_len = 0;
 
     // large-vocabulary sampler scratch
-    unsigned* samp_hist = nullptr;
-    unsigned* samp_ticket = nullptr;
-    unsigned* head_done = nullptr;     // rows of the vocabulary row written so far, per 4096-row chunk (head GEMV -> samp_cut)
-    unsigned* samp_tail_pub = nullptr;
-    unsigned* samp_tail_gen = nullptr;
     ft::SampCut* samp_cut = nullptr;
     int* samp_chunk_cnt = nullptr;
     float* samp_part_score = nullptr;
     int* samp_part_idx = nullptr;
-    bool force_block_sampler = false, wave_sampler = false;
-    int nt_weights = 1;
-    int batch_rows = 4;  // utterance rows per weight pass in lock-step batches (1 disables)
 
     // persistent frame engine (frame_engine.h): batch-1 decode frames as two launches of one workgroup per CU
     bool eng_on = false;          // shapes fit the instantiated engine and FT_NO_ENGINE is unset

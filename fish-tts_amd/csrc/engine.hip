@@ -136,14 +136,15 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     // One kv head per XCD (frame_engine.h, XL): 8 kv heads of 2 x 128-wide query heads on a chip of 8 XCDs x 32 CUs split every
     // head's cached positions 32 ways - one split per CU of the head's XCD - at every context length.  The split count is a
     // property of the shapes and the chip, not of the frame path: launches and engine then sum in the same order.
+    // (Measured and not kept: short contexts walked UNSPLIT by every CU of the XCD for itself - no partials, no merge: 704 us
+    // per slow-stack launch at 150 positions and 825 at 260 against 589 for the 32-way split; a 16-position step of the walk
+    // costs ~0.45 us - two exact exponentials per head and step - and 10-17 of them sit on every layer's path.)
     {
         hipDeviceProp_t prop;
         ctx->xl_shape = !ns && !getenv("FT_NO_XL") && c.n_local_heads == 8 && c.n_head == 16 && c.head_dim == 128 &&
                         hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount == 256;
         if (ctx->xl_shape) { ctx->nsplit = ctx->nsplit_max = 32; ctx->nsplit_fixed = true; }
     }
-    ctx->nt_weights = getenv("FT_NO_NT") ? 0 : 1;
-    { const char* br = getenv("FT_BATCH_ROWS"); ctx->batch_rows = br ? atoi(br) : 4; }
     if (ctx->nsplit < 1) ctx->nsplit = 1;
     if (ctx->nsplit > 32) ctx->nsplit = 32;
     ctx->nsplit_max = std::max(1, std::min(32, std::max(ctx->nsplit_max, ctx->nsplit)));
@@ -202,47 +203,26 @@ static ft_status ar_alloc(ft_ctx* ctx) {
         // wide lock-step batches: no fast-layer f32 bias copies exist, and the fast widths must fit the MFMA tiles
         ctx->wide_ok = !getenv("FT_NO_WIDE") && !c.fast_attention_qkv_bias && !c.fast_attention_o_bias &&
                        c.fast_dim % 32 == 0 && (c.fast_n_head * c.fast_head_dim) % 32 == 0 && c.fast_intermediate_size % 32 == 0;
-        if (getenv("FT_WIDE_MIN")) ctx->wide_min = std::max(1, atoi(getenv("FT_WIDE_MIN")));
         if (ctx->wide_ok) {
             FT_TRY(dmalloc(ctx, &ctx->mb_xn, M * (size_t)std::max(c.dim, c.fast_dim)));
             FT_TRY(dmalloc(ctx, &ctx->mb_ybf, M * (size_t)std::max(c.n_head * c.head_dim, c.fast_n_head * c.fast_head_dim)));
             FT_TRY(dmalloc(ctx, &ctx->mb_g, M * (size_t)std::max(c.intermediate_size, c.fast_intermediate_size)));
             FT_TRY(dmalloc(ctx, &ctx->mb_xb, M * (size_t)std::max(c.dim, c.fast_dim)));
             FT_TRY(dmalloc(ctx, &ctx->mb_ss, M * (size_t)(std::max(c.dim, c.fast_dim) / 16 + 1)));
-            FT_TRY(dmalloc(ctx, &ctx->gemm_ticket, (size_t)4));
-            // FT_TAIL_NORM (opt-in; measured SLOWER: 4.67 against 3.54 ms per 32-row frame): the norm after a Wo / W2 GEMM
-            // inside that GEMM's last-finishing block.  Write-through stores + their acknowledgement, a returning ticket atomic
-            // and the last block's trip to the memory side for the rows add up to more than the ~5 us launch they replace.
-            ctx->tail_norm = getenv("FT_TAIL_NORM") != nullptr && c.dim == 1024 && c.fast_dim == 1024 &&
-                             (c.n_head * c.head_dim) % 128 == 0 && c.intermediate_size % 128 == 0 &&
-                             (c.fast_n_head * c.fast_head_dim) % 128 == 0 && c.fast_intermediate_size % 128 == 0 && c.max_batch <= 128;
             // the norm rides inside the consumer GEMM only where every Linear of a layer takes the skinny kernel, and only up
             // to 16 rows: measured +8 % at B=8, +5 % at B=16, -4 % at B=32 (the in-register normalisation of two row tiles
             // costs more VALU time than the removed launches)
-            if (getenv("FT_FUSE_NORM_MAX")) ctx->wide_fuse_max = atoi(getenv("FT_FUSE_NORM_MAX"));
             auto sk = [](int k) { return k % 128 == 0; };
-            ctx->wide_fuse = !getenv("FT_NO_FUSE_NORM") && sk(c.dim) && sk(c.n_head * c.head_dim) && sk(c.intermediate_size) &&
+            ctx->wide_fuse = sk(c.dim) && sk(c.n_head * c.head_dim) && sk(c.intermediate_size) &&
                              sk(c.fast_dim) && sk(c.fast_n_head * c.fast_head_dim) && sk(c.fast_intermediate_size) &&
                              c.dim % 16 == 0 && c.fast_dim % 16 == 0 && c.max_batch <= 128;
         }
     }
     const size_t nchunk = ((size_t)c.vocab_size + 1023) / 1024;
-    FT_TRY(dmalloc(ctx, &ctx->samp_hist, M * SAMP_HIST_STRIDE));
-    FT_TRY(dmalloc(ctx, &ctx->samp_ticket, M));
-    FT_TRY(dmalloc(ctx, &ctx->head_done, (size_t)(c.vocab_size / 4096 + 6) * 64));
-    FT_TRY(dmalloc(ctx, &ctx->samp_tail_pub, M * nchunk));
-    FT_TRY(dmalloc(ctx, &ctx->samp_tail_gen, M));
-    FT_HIP(ctx, hipMemset(ctx->samp_ticket, 0, M * sizeof(unsigned)));
     FT_TRY(dmalloc(ctx, &ctx->samp_cut, M));
     FT_TRY(dmalloc(ctx, &ctx->samp_chunk_cnt, M * nchunk));
     FT_TRY(dmalloc(ctx, &ctx->samp_part_score, M * nchunk));
     FT_TRY(dmalloc(ctx, &ctx->samp_part_idx, M * nchunk));
-    ctx->force_block_sampler = getenv("FT_SAMPLER_BLOCK") != nullptr;
-    ctx->wave_sampler = getenv("FT_SAMPLER_WAVE") != nullptr;
-    ctx->fork_fast0 = getenv("FT_FORK") != nullptr;  // measured slower than the single chain (447 vs 410 tok/s): off by default
-    FT_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    FT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    FT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     FT_HIP(ctx, hipHostMalloc((void**)&ctx->h_pin, (3 * M + 8) * sizeof(int), hipHostMallocDefault));
     return FT_OK;
 }
@@ -299,13 +279,8 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     int* ibufs[] = {ctx->d_pos, ctx->d_tok, ctx->d_tokn, ctx->d_seq, ctx->d_nf, ctx->d_done, ctx->d_prompt};
     for (int* b : ibufs) if (b) hipFree(b);
     if (ctx->d_ctl) hipFree(ctx->d_ctl);
-    { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g, ctx->mb_xn, ctx->mb_ybf, ctx->mb_g, ctx->mb_xb, ctx->mb_ss, ctx->pf_qbf, ctx->gemm_ticket}; for (void* q : pf) if (q) hipFree(q); }
+    { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g, ctx->mb_xn, ctx->mb_ybf, ctx->mb_g, ctx->mb_xb, ctx->mb_ss, ctx->pf_qbf}; for (void* q : pf) if (q) hipFree(q); }
     for (auto& l : ctx->layers) { if (l.bqkv_f32) hipFree(l.bqkv_f32); if (l.bo_f32) hipFree(l.bo_f32); }
-    if (ctx->samp_hist) hipFree(ctx->samp_hist);
-    if (ctx->samp_ticket) hipFree(ctx->samp_ticket);
-    if (ctx->head_done) hipFree(ctx->head_done);
-    if (ctx->samp_tail_pub) hipFree(ctx->samp_tail_pub);
-    if (ctx->samp_tail_gen) hipFree(ctx->samp_tail_gen);
     if (ctx->samp_cut) hipFree(ctx->samp_cut);
     if (ctx->samp_chunk_cnt) hipFree(ctx->samp_chunk_cnt);
     if (ctx->samp_part_score) hipFree(ctx->samp_part_score);
@@ -314,9 +289,6 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     if (ctx->h_pin) hipHostFree(ctx->h_pin);
     for (auto e : ctx->prof_ev) hipEventDestroy(e);
     codec_destroy(ctx);
-    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
-    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -540,7 +512,7 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
     ctx->eng_lds_slow = std::max(fl * sizeof(float), (size_t)82 * 1024);   // > half the CU's LDS: one workgroup per CU
     const size_t lds_cap = prop.maxSharedMemoryPerMultiProcessor;
     if (ctx->eng_lds_slow > lds_cap) { why = "the slow stack's LDS need exceeds the CU's"; return false; }
-    ctx->eng_xl = ctx->xl_shape && nb == 256 && ctx->nsplit == 32 && c.n_local_heads * 32 == nb && qkvN / nb == (G + 2) * hd * c.n_local_heads / nb;
+    ctx->eng_xl = ctx->xl_shape && nb == 256 && ctx->nsplit_max == 32 && c.n_local_heads * 32 == nb;
     const void* slow_fn = ctx->eng_xl ? (const void*)slow_engine_kernel<2, 4, 6, 2, true> : (const void*)slow_engine_kernel<2, 4, 6, 2, false>;
     if (!hip_ok(hipFuncSetAttribute(slow_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->eng_lds_slow),
                 "hipFuncSetAttribute(slow_engine_kernel)")) return false;
@@ -560,7 +532,7 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
                          c.num_codebooks >= 2 && c.num_codebooks <= 10 && fqkvN % (4 * nb) == 0 && ctx->fastV % (4 * nb) == 0 &&
                          per(fqkvN) <= ENG_FQ * ENG_CW && per(c.fast_dim) <= ENG_FO * ENG_CW && per(c.fast_intermediate_size) <= ENG_FF * ENG_CW &&
                          per(ctx->fastV) <= ENG_FO * ENG_CW && per(fqkvN) <= ENG_LINE && ctx->fastV <= 1024 && c.codebook_size <= 65536 &&
-                         !ctx->force_block_sampler && !ctx->wave_sampler;
+                         true;
     if (!fast_ok) { why += "; fast loop on launches (FT_NO_FAST_ENGINE, or fast widths outside 1024 / 16 x 64 / 3072, <= 10 codebooks)"; return true; }
     // from here on a failure keeps the slow engine and leaves the fast loop on launches
     auto fast_off = [&](const std::string& w2) { why += "; fast loop on launches (" + w2 + ")"; return true; };
@@ -653,9 +625,6 @@ struct Launch {
     int pos_off;     // added to the device position (token-by-token prefill)
     hipError_t err = hipSuccess;
     bool gemv_only = false;  // measurement: enqueue only the weight-streaming GEMV launches of the frame
-    unsigned* head_done = nullptr;   // one row: the head GEMV counts written rows per 4096-row chunk here (samp_cut walks behind it)
-    int samp_phase = 0;              // enqueue_sample: 0 = everything, 1 = only the cut kernel (forked stream), 2 = everything after it
-    bool xn_final = false;   // wide path: the last W2 GEMM's tail left the final-norm rows in mb_xn (consumed by the head)
     void chk() { hipError_t e = hipGetLastError(); if (e != hipSuccess && err == hipSuccess) err = e; }
 };
 
@@ -664,8 +633,6 @@ struct PfX {   // fused RMSNorm hooks of the skinny kernel (codec_kernels.h TapG
     const float* ss_in = nullptr; // ... and the producer's partial sums of squares (nblk per row)
     int nblk = 0;
     float* ss_out = nullptr;      // leave this GEMM's own partials for the next consumer
-    const void* tail_gain = nullptr;   // RMSNorm of this GEMM's output rows by its last-finishing block (codec_kernels.h) ...
-    bf16_t* tail_out = nullptr;        // ... into this bf16 buffer
 };
 static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, const float* bias, int N, int K,
                     int act, const float* resid, float* out_f32, bf16_t* out_bf, long ldo, int round_out,
@@ -684,7 +651,7 @@ static bool eng_slow_ok(const Launch& L) {
 
 static bool eng_fast_ok(const Launch& L) {
     const ft_ctx* ctx = L.ctx;
-    return ctx->eng_fast_on && !ctx->eng_suspended && L.M == 1 && !L.gemv_only && !ctx->prof && !ctx->fork_fast0;
+    return ctx->eng_fast_on && !ctx->eng_suspended && L.M == 1 && !L.gemv_only && !ctx->prof;
 }
 
 // The whole codebook loop of one frame (steps 0 .. num_codebooks-1 with their draws) as one launch; runs after the
@@ -743,7 +710,7 @@ static void enqueue_slow_engine(Launch& L, const int* toks, long tok_row_stride,
     p.rope = ctx->rope; p.pos = ctx->d_pos + m0; p.pos_off = L.pos_off; p.n_slots = ctx->n_slots; p.nsplit = ctx->nsplit;
     p.cache_off = (size_t)m0 * ctx->cache_m_stride;
     p.gx = ctx->eng_gx; p.gqkv = ctx->eng_gqkv; p.gpart = ctx->eng_gpart; p.gy = ctx->eng_gy; p.gxb = ctx->eng_gxb; p.gg = ctx->eng_gg;
-    p.ctl = ctx->eng_ctl; p.x_out = ctx->x + (size_t)m0 * c.dim; p.nt = ctx->nt_weights;
+    p.ctl = ctx->eng_ctl; p.x_out = ctx->x + (size_t)m0 * c.dim; p.nt = 1;
     p.rep_delta0 = ctx->eng_relay ? (long)ctx->eng_pool_words : 0; p.rep_stride = ctx->eng_relay ? (long)ctx->eng_pool_words : 0;
     if (ctx->eng_xl) slow_engine_kernel<2, 4, 6, 2, true><<<ctx->eng_nb, ENG_THREADS, ctx->eng_lds_slow, L.s>>>(p);
     else slow_engine_kernel<2, 4, 6, 2, false><<<ctx->eng_nb, ENG_THREADS, ctx->eng_lds_slow, L.s>>>(p);
@@ -786,10 +753,10 @@ static void gemv(Launch& L, GemvP p, int R) {
     }
     if (p.epi == EPI_SWIGLU && R < 2) R = 2;
     // lock-step batches (bf16): several utterance rows per pass over the weights
-    const bool mb_ok = sizeof(WT) == 2 && L.M >= 2 && ctx->batch_rows > 1 && (nt == 1 || nt == 2 || nt == 4 || nt == 6);
+    const bool mb_ok = sizeof(WT) == 2 && L.M >= 2 && (nt == 1 || nt == 2 || nt == 4 || nt == 6);
     if (mb_ok) {
         if constexpr (sizeof(WT) == 2) {
-            const bool four = L.M >= 3 && nt <= 2 && R <= 2 && ctx->batch_rows >= 4;  // register budget: 4 x NT x 8 activations
+            const bool four = L.M >= 3 && nt <= 2 && R <= 2;  // register budget: 4 x NT x 8 activations
             if (R >= 4) { if (nt <= 2) gemv_mb_nt<WT, ROUND, 4, 2>(L, p, nt); else gemv_nt<WT, ROUND, 4>(L, p, nt); }
             else if (R == 2) { if (four) gemv_mb_nt<WT, ROUND, 2, 4>(L, p, nt); else gemv_mb_nt<WT, ROUND, 2, 2>(L, p, nt); }
             else { if (four) gemv_mb_nt<WT, ROUND, 1, 4>(L, p, nt); else gemv_mb_nt<WT, ROUND, 1, 2>(L, p, nt); }
@@ -812,9 +779,7 @@ static void gemv(Launch& L, GemvP p, int R) {
 static int rows_per_wave(int N, int M) {
     // enough waves to cover the chip (256 CUs x 4 SIMDs) a few times over; big matrices amortise
     const long waves1 = (long)N * M;
-    // the vocabulary head (155 776 rows at M = 1): FT_HEAD_R=8 (16 KB in flight per wave) measured 0.5 % slower than 4
-    static const int head_r = getenv("FT_HEAD_R") ? atoi(getenv("FT_HEAD_R")) : 4;
-    if (M == 1 && waves1 >= 131072) return head_r;
+    // (the vocabulary head, 155 776 rows at M = 1: 8 rows per wave - 16 KB in flight - measured 0.5 % slower than 4)
     if (waves1 >= 65536) return 4;
     if (waves1 >= 2048) return 2;
     return 1;
@@ -902,23 +867,12 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
                 float* ss = ctx->mb_ss + (size_t)m0 * (std::max(c.dim, c.fast_dim) / 16 + 1);
                 PfX leave; leave.ss_out = fuse ? ss : nullptr;
                 PfX nrm; nrm.ss_in = ss; nrm.nblk = D / 16;
-                // above the fused-norm limit: the norms after Wo and W2 are done by those GEMMs' last blocks (tail), so
-                // from layer 1 on xn is already there
-                const bool tail = !fuse && ctx->tail_norm && ctx->prefill_gemm_mode >= 2 && M <= 128 && !(ctx->fork_fast0 && ctx->stream2);
                 if (fuse && li > 0) {
                     nrm.gain = l.attn_norm;
                     pf_gemm(L, xb, D, M, l.wqkv, l.bqkv_f32, (int)qkvN, D, ACT_NONE, nullptr, qkv, nullptr, (long)qkvN, 0, nrm);
                 } else {
-                    if (!(tail && li > 0)) rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.attn_norm, c.norm_eps, D, xn);
+                    rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.attn_norm, c.norm_eps, D, xn);
                     pf_gemm(L, xn, D, M, l.wqkv, l.bqkv_f32, (int)qkvN, D, ACT_NONE, nullptr, qkv, nullptr, (long)qkvN, 0);
-                }
-                PfX tail_o, tail_d;
-                if (tail) {
-                    tail_o.tail_gain = l.ffn_norm; tail_o.tail_out = xn;
-                    // after W2: the next layer's first norm, or the final norm in front of the vocabulary head
-                    tail_d.tail_gain = li + 1 < c.n_layer ? ctx->layers[li + 1].attn_norm : (with_head ? ctx->norm : nullptr);
-                    tail_d.tail_out = tail_d.tail_gain ? xn : nullptr;
-                    if (li + 1 == c.n_layer && with_head) L.xn_final = true;
                 }
                 AttnP a{};
                 a.qkv = qkv; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->rope;
@@ -936,21 +890,21 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
                 a.part_ml = ctx->part_ml + (size_t)m0 * c.n_head * ctx->nsplit * 2;
                 attn_decode<WT, ROUND>(L, a);
                 if (ns > 1) { attn_combine_rows_kernel<ROUND><<<M, 256, 0, L.s>>>(a); L.chk(); }
-                pf_gemm(L, ybf, HD, M, l.wo, l.bo_f32, D, HD, ACT_NONE, x, x, fuse ? xb : nullptr, D, 1, tail ? tail_o : leave);
+                pf_gemm(L, ybf, HD, M, l.wo, l.bo_f32, D, HD, ACT_NONE, x, x, fuse ? xb : nullptr, D, 1, leave);
                 if (fuse) {
                     nrm.gain = l.ffn_norm;
                     pf_gemm(L, xb, D, M, l.w13, nullptr, 2 * F, D, ACT_SWIGLU, nullptr, nullptr, gbf, F, 0, nrm);
                 } else {
-                    if (!tail) rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.ffn_norm, c.norm_eps, D, xn);
+                    rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.ffn_norm, c.norm_eps, D, xn);
                     pf_gemm(L, xn, D, M, l.w13, nullptr, 2 * F, D, ACT_SWIGLU, nullptr, nullptr, gbf, F, 0);
                 }
-                pf_gemm(L, gbf, F, M, l.w2, nullptr, D, F, ACT_NONE, x, x, fuse ? xb : nullptr, D, 1, tail ? tail_d : leave);
+                pf_gemm(L, gbf, F, M, l.w2, nullptr, D, F, ACT_NONE, x, x, fuse ? xb : nullptr, D, 1, leave);
             }
             continue;
         }
         GemvP p{};
         p.W = l.wqkv; p.bias = l.bqkv; p.x = x; p.ldx = c.dim; p.gain = l.attn_norm; p.eps = c.norm_eps;
-        p.out = qkv; p.ldo = (int)qkvN; p.N = (int)qkvN; p.K = c.dim; p.pro = PRO_RMSNORM; p.epi = EPI_STORE; p.nt = ctx->nt_weights;
+        p.out = qkv; p.ldo = (int)qkvN; p.N = (int)qkvN; p.K = c.dim; p.pro = PRO_RMSNORM; p.epi = EPI_STORE; p.nt = 1;
         gemv<WT, ROUND>(L, p, rows_per_wave(p.N, L.M));
 
         AttnP a{};
@@ -967,7 +921,7 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
 
         GemvP o{};
         o.W = l.wo; o.bias = l.bo; o.x = y; o.ldx = ctx->y_ld; o.out = x; o.ldo = c.dim;
-        o.resid = x; o.ldr = c.dim; o.N = c.dim; o.K = c.n_head * c.head_dim; o.pro = PRO_NONE; o.epi = EPI_RESID; o.nt = ctx->nt_weights;
+        o.resid = x; o.ldr = c.dim; o.N = c.dim; o.K = c.n_head * c.head_dim; o.pro = PRO_NONE; o.epi = EPI_RESID; o.nt = 1;
         if (ctx->nsplit > 1) {  // split-KV partials are merged inside the Wo kernel
             const int nt = pick_nt(o.K, Vec<WT>::N);
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -989,12 +943,12 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
 
         GemvP f{};
         f.W = l.w13; f.x = x; f.ldx = c.dim; f.gain = l.ffn_norm; f.eps = c.norm_eps; f.out = g;
-        f.ldo = c.intermediate_size; f.N = 2 * c.intermediate_size; f.K = c.dim; f.pro = PRO_RMSNORM; f.epi = EPI_SWIGLU; f.nt = ctx->nt_weights;
+        f.ldo = c.intermediate_size; f.N = 2 * c.intermediate_size; f.K = c.dim; f.pro = PRO_RMSNORM; f.epi = EPI_SWIGLU; f.nt = 1;
         gemv<WT, ROUND>(L, f, rows_per_wave(f.N, L.M));
 
         GemvP d{};
         d.W = l.w2; d.x = g; d.ldx = c.intermediate_size; d.out = x; d.ldo = c.dim; d.resid = x; d.ldr = c.dim;
-        d.N = c.dim; d.K = c.intermediate_size; d.pro = PRO_NONE; d.epi = EPI_RESID; d.nt = ctx->nt_weights;
+        d.N = c.dim; d.K = c.intermediate_size; d.pro = PRO_NONE; d.epi = EPI_RESID; d.nt = 1;
         gemv<WT, ROUND>(L, d, rows_per_wave(d.N, L.M));
     }
     if (with_head) enqueue_fproj<WT, ROUND>(L);
@@ -1014,9 +968,7 @@ static void enqueue_head(Launch& L) {
                         ctx->logits + (size_t)L.m0 * c.vocab_size, nullptr, c.vocab_size, 0, nrm);
                 return;
             }
-            if (!L.xn_final)   // (else the last W2 GEMM's tail already normalised x with the final gain)
-                rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(ctx->x + (size_t)L.m0 * c.dim, ctx->norm, c.norm_eps, c.dim, xn);
-            L.xn_final = false;
+            rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(ctx->x + (size_t)L.m0 * c.dim, ctx->norm, c.norm_eps, c.dim, xn);
             pf_gemm(L, xn, c.dim, L.M, ctx->head, nullptr, c.vocab_size, c.dim, ACT_NONE, nullptr,
                     ctx->logits + (size_t)L.m0 * c.vocab_size, nullptr, c.vocab_size, 0);
         }
@@ -1025,8 +977,7 @@ static void enqueue_head(Launch& L) {
     GemvP h{};
     h.W = ctx->head; h.x = ctx->x + (size_t)L.m0 * c.dim; h.ldx = c.dim; h.gain = ctx->norm; h.eps = c.norm_eps;
     h.out = ctx->logits + (size_t)L.m0 * c.vocab_size; h.ldo = c.vocab_size; h.N = c.vocab_size; h.K = c.dim;
-    h.pro = PRO_RMSNORM; h.epi = EPI_STORE; h.nt = ctx->nt_weights;
-    h.done = L.head_done;
+    h.pro = PRO_RMSNORM; h.epi = EPI_STORE; h.nt = 1;
     gemv<WT, ROUND>(L, h, rows_per_wave(h.N, L.M));
 }
 
@@ -1046,14 +997,14 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
     s.noise_row_len = ctx->noise_row_len; s.noise_rows = ctx->noise_rows;
     s.noise_off = cb == 0 ? 0 : (long)c.vocab_size + (long)(cb - 1) * ctx->fastV;
     s.last = last ? 1 : 0; s.tok = ctx->d_tok + (size_t)m0 * R; s.pos = ctx->d_pos + m0; s.done = ctx->d_done + m0;
-    if (s.V <= 1024 && !ctx->force_block_sampler) {
-        if (ctx->wave_sampler) sample_wave_kernel<WT, ROUND><<<L.M, 64, 0, L.s>>>(s);
-        else sample_small_kernel<WT, ROUND><<<L.M, 256, 0, L.s>>>(s);
-    } else if (ROUND && !ctx->force_block_sampler) {
+    if (s.V <= 1024) {
+        sample_small_kernel<WT, ROUND><<<L.M, 256, 0, L.s>>>(s);
+    } else if (ROUND) {
+        // large vocabulary, bf16: the histogram of the 65 536 bf16 classes and the search of the top-p cut on it in ONE block
+        // per row (LDS counters), then index-ordered tie handling and the chip-wide race
         SampBigP b{};
         b.s = s; b.nchunk = (s.V + 1023) / 1024;
-        b.hist = ctx->samp_hist + (size_t)m0 * SAMP_HIST_STRIDE; b.cut = ctx->samp_cut + m0;
-        b.ticket = ctx->samp_ticket + m0;
+        b.cut = ctx->samp_cut + m0;
         b.chunk_cnt = ctx->samp_chunk_cnt + (size_t)m0 * b.nchunk;
         b.part_score = ctx->samp_part_score + (size_t)m0 * b.nchunk;
         b.part_idx = ctx->samp_part_idx + (size_t)m0 * b.nchunk;
@@ -1061,46 +1012,13 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
         {
             static DevOnce once;     // per device
             once.run([] {
-                hipFuncSetAttribute((const void*)samp_threshold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)SAMP_TH_LDS);
-                hipFuncSetAttribute((const void*)samp_cut_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)SAMP_TH_LDS);
-                hipFuncSetAttribute((const void*)samp_cut_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)SAMP_TH_LDS);
+                hipFuncSetAttribute((const void*)samp_cut_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SAMP_TH_LDS);
             });
         }
-        // histogram + cut search of a row in one block (LDS counters); FT_SAMPLER_GLOBAL_HIST selects the first
-        // implementation (global-atomic histogram, then the cut search on its read-back)
-        const bool global_hist = getenv("FT_SAMPLER_GLOBAL_HIST") != nullptr;   // read per enqueue: tests toggle it
-        // FT_SAMPLER_FUSED: the histogram part spread over ceil(V / 4096) blocks, the cut search in the block that arrives
-        // last (same image, same search).  Measured SLOWER than the one-block kernel (75 vs 40 us per draw: global atomics
-        // and the ticket round trip cost more than 38 more CUs save), so it is not the default; kept with its test.
-        const bool fused = !global_hist && getenv("FT_SAMPLER_FUSED") != nullptr;
-        b.head_done = L.samp_phase == 1 ? L.head_done : nullptr;
-        if (L.samp_phase == 2) {
-            // (the cut kernel of this draw already ran beside the head GEMV)
-        } else if (fused) {
-            samp_cut_fused_kernel<<<dim3((s.V + 4095) / 4096, L.M), SAMP_TH_THREADS, SAMP_TH_LDS, L.s>>>(b);
-        } else if (!global_hist) {
-            samp_cut_kernel<<<L.M, SAMP_TH_THREADS, SAMP_TH_LDS, L.s>>>(b);
-        } else {
-            samp_hist_kernel<<<gridc, 256, 0, L.s>>>(b);
-            samp_threshold_kernel<<<L.M, SAMP_TH_THREADS, SAMP_TH_LDS, L.s>>>(b);
-        }
-        // FT_SAMPLER_TAIL1 (opt-in): count + race + finish of one row as one launch (chained look-back over the chunk counts,
-        // last block finishes).  Same draws, 5 launches per frame instead of 7 - and exactly the same time (0.1038 ms for head +
-        // draw either way): a cross-block dependency costs a memory round trip, like a launch boundary inside a graph.
-        const bool tail1 = getenv("FT_SAMPLER_TAIL1") != nullptr;   // read per enqueue: tests toggle it
-        if (L.samp_phase == 1) {
-            // (count / race / finish follow on the main stream after the join)
-        } else if (tail1 && L.M == 1 && b.nchunk <= 1024) {
-            b.tail_pub = ctx->samp_tail_pub + (size_t)m0 * b.nchunk; b.tail_gen = ctx->samp_tail_gen + m0;
-            samp_tail_kernel<WT><<<gridc, 256, 0, L.s>>>(b);
-        } else {
-            samp_count_kernel<<<gridc, 256, 0, L.s>>>(b);
-            samp_race_kernel<<<gridc, 256, 0, L.s>>>(b);
-            samp_finish_kernel<WT><<<L.M, 256, 0, L.s>>>(b);
-        }
+        samp_cut_kernel<<<L.M, SAMP_TH_THREADS, SAMP_TH_LDS, L.s>>>(b);
+        samp_count_kernel<<<gridc, 256, 0, L.s>>>(b);
+        samp_race_kernel<<<gridc, 256, 0, L.s>>>(b);
+        samp_finish_kernel<WT><<<L.M, 256, 0, L.s>>>(b);
     } else {
         sample_block_kernel<WT, ROUND><<<L.M, 1024, 0, L.s>>>(s);
     }
@@ -1136,23 +1054,13 @@ static void enqueue_fast_step(Launch& L, const int cb) {
                     float* ss = ctx->mb_ss + (size_t)m0 * (std::max(c.dim, c.fast_dim) / 16 + 1);
                     PfX leave; leave.ss_out = fuse ? ss : nullptr;
                     PfX nrm; nrm.ss_in = ss; nrm.nblk = Df / 16;
-                    const bool tail = !fuse && ctx->tail_norm && ctx->prefill_gemm_mode >= 2 && M <= 128 && !(ctx->fork_fast0 && ctx->stream2);
                     if (fuse && li > 0) {
                         nrm.gain = l.attn_norm;
                         pf_gemm(L, xb, Df, M, l.wqkv, nullptr, (int)qkvN, Df, ACT_NONE, nullptr, qkvf, nullptr, (long)qkvN, 0, nrm);
                     } else {
-                        if (!(tail && li > 0)) rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xl, l.attn_norm, c.norm_eps, Df, xn);
+                        rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xl, l.attn_norm, c.norm_eps, Df, xn);
                         pf_gemm(L, xn, Df, M, l.wqkv, nullptr, (int)qkvN, Df, ACT_NONE, nullptr, qkvf, nullptr, (long)qkvN, 0);
                     }
-                    PfX tail_o, tail_d;
-                    bool head_ready = false;
-                    if (tail) {
-                        tail_o.tail_gain = l.ffn_norm; tail_o.tail_out = xn;
-                        tail_d.tail_gain = li + 1 < c.n_fast_layer ? ctx->flayers[li + 1].attn_norm : (cb != 0 ? ctx->fast_norm : nullptr);
-                        tail_d.tail_out = tail_d.tail_gain ? xn : nullptr;
-                        head_ready = li + 1 == c.n_fast_layer && cb != 0;
-                    }
-                    if (head_ready) L.xn_final = true;
                     FastAttnP a{};
                     a.qkv = qkvf; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->frope;
                     a.kc = (char*)l.kc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
@@ -1164,15 +1072,15 @@ static void enqueue_fast_step(Launch& L, const int cb) {
                     // y (f32) and its bf16 copy share the row stride HDf here
                     fast_attn_kernel<WT, ROUND><<<dim3(Hf, M), 64, 0, L.s>>>(a, yf, HDf);
                     L.chk();
-                    pf_gemm(L, ybf, HDf, M, l.wo, nullptr, Df, HDf, ACT_NONE, xl, xf, fuse ? xb : nullptr, Df, 1, tail ? tail_o : leave);
+                    pf_gemm(L, ybf, HDf, M, l.wo, nullptr, Df, HDf, ACT_NONE, xl, xf, fuse ? xb : nullptr, Df, 1, leave);
                     if (fuse) {
                         nrm.gain = l.ffn_norm;
                         pf_gemm(L, xb, Df, M, l.w13, nullptr, 2 * Ff, Df, ACT_SWIGLU, nullptr, nullptr, gbf, Ff, 0, nrm);
                     } else {
-                        if (!tail) rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xf, l.ffn_norm, c.norm_eps, Df, xn);
+                        rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xf, l.ffn_norm, c.norm_eps, Df, xn);
                         pf_gemm(L, xn, Df, M, l.w13, nullptr, 2 * Ff, Df, ACT_SWIGLU, nullptr, nullptr, gbf, Ff, 0);
                     }
-                    pf_gemm(L, gbf, Ff, M, l.w2, nullptr, Df, Ff, ACT_NONE, xf, xf, fuse ? xb : nullptr, Df, 1, tail ? tail_d : leave);
+                    pf_gemm(L, gbf, Ff, M, l.w2, nullptr, Df, Ff, ACT_NONE, xf, xf, fuse ? xb : nullptr, Df, 1, leave);
                 }
                 continue;
             }
@@ -1215,8 +1123,7 @@ static void enqueue_fast_step(Launch& L, const int cb) {
                     pf_gemm(L, ctx->mb_xb + (size_t)m0 * Df, Df, L.M, ctx->fast_out, nullptr, ctx->fastV, Df, ACT_NONE, nullptr,
                             ctx->flog + (size_t)m0 * ctx->fastV, nullptr, ctx->fastV, 0, nrm);
                 } else {
-                    if (!L.xn_final) rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(xf, ctx->fast_norm, c.norm_eps, Df, xn);
-                    L.xn_final = false;
+                    rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(xf, ctx->fast_norm, c.norm_eps, Df, xn);
                     pf_gemm(L, xn, Df, L.M, ctx->fast_out, nullptr, ctx->fastV, Df, ACT_NONE, nullptr,
                             ctx->flog + (size_t)m0 * ctx->fastV, nullptr, ctx->fastV, 0);
                 }
@@ -1253,51 +1160,10 @@ static void enqueue_frame_tail(Launch& L) {
         enqueue_head<WT, ROUND>(L);
         return;
     }
-    // The fast pass at codebook position 0 needs only the hidden state, not the sampled token
-    // (inference.py:121-122): it runs beside the vocabulary head + semantic draw on a second stream
-    // (a forked branch of the captured graph) and joins before position 1.
-    const bool fork = ctx->fork_fast0 && ctx->stream2 != nullptr;
-    if (fork) {
-        hipEventRecord(ctx->ev_fork, L.s);
-        hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
-        Launch L2 = L;
-        L2.s = ctx->stream2;
-        enqueue_fast_step<WT, ROUND>(L2, 0);
-        if (L2.err != hipSuccess) L.err = L2.err;
-        hipEventRecord(ctx->ev_join, ctx->stream2);
-    }
-    // FT_CUT_BESIDE (opt-in): one row, bf16, the one-block vocabulary draw: its histogram + cut kernel (35 us, one CU) starts
-    // BESIDE the head GEMV (53 us, whole chip) on the second stream and walks the logits behind the GEMV's per-chunk
-    // counters; count / race / finish follow after the join.  Same image, same search: the draws do not change (tests).
-    // Measured: frame 1.416-1.419 ms against 1.412 ms serial - the GEMV's write-through rows + completion atomics and the
-    // walk's per-range flag polls cost what the overlap saves (with ONE counter per chunk the GEMV took ~300 us).
-    const bool cut_beside = ROUND && !fork && L.M == 1 && ctx->stream2 != nullptr && ctx->head_done != nullptr && !ctx->prof &&
-                            ctx->c.vocab_size > 1024 && !ctx->force_block_sampler && wide_batch(L) == false &&
-                            getenv("FT_SAMPLER_GLOBAL_HIST") == nullptr && getenv("FT_SAMPLER_FUSED") == nullptr &&
-                            getenv("FT_CUT_BESIDE") != nullptr;
-    if (cut_beside) {
-        hipEventRecord(ctx->ev_fork, L.s);
-        hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0);
-        Launch L2 = L;
-        L2.s = ctx->stream2; L2.samp_phase = 1; L2.head_done = ctx->head_done;
-        enqueue_sample<WT, ROUND>(L2, 0, ncb == 1);
-        if (L2.err != hipSuccess) L.err = L2.err;
-        hipEventRecord(ctx->ev_join, ctx->stream2);
-        L.head_done = ctx->head_done;
-        enqueue_head<WT, ROUND>(L);
-        L.head_done = nullptr;
-        hipStreamWaitEvent(L.s, ctx->ev_join, 0);
-        L.samp_phase = 2;
-        enqueue_sample<WT, ROUND>(L, 0, ncb == 1);
-        L.samp_phase = 0;
-    } else {
-        enqueue_head<WT, ROUND>(L);
-        enqueue_sample<WT, ROUND>(L, 0, ncb == 1);
-    }
-    if (ROUND && !fork && eng_fast_ok(L)) { enqueue_fast_engine(L); return; }
-    if (fork) hipStreamWaitEvent(L.s, ctx->ev_join, 0);
-    else enqueue_fast_step<WT, ROUND>(L, 0);
-    for (int cb = 1; cb < ncb; ++cb) enqueue_fast_step<WT, ROUND>(L, cb);
+    enqueue_head<WT, ROUND>(L);
+    enqueue_sample<WT, ROUND>(L, 0, ncb == 1);
+    if (ROUND && eng_fast_ok(L)) { enqueue_fast_engine(L); return; }
+    for (int cb = 0; cb < ncb; ++cb) enqueue_fast_step<WT, ROUND>(L, cb);
 }
 
 static void enqueue_frame(Launch& L, const int* toks, long trs, long tms, int col) {
@@ -1332,6 +1198,14 @@ extern "C" ft_status ft_ar_reset(ft_ctx* ctx, int32_t slot) {
     return FT_OK;
 }
 
+// KV splits of the decode attention for a call whose longest context ends at pos_end (more blocks walking the cache in
+// parallel); measured at s1-mini shapes (tools/longctx_probe.py): 8 splits are fastest up to ~700 positions, 16 up to ~3000
+static void pick_nsplit(ft_ctx* ctx, int pos_end) {
+    if (ctx->nsplit_fixed || ctx->nsplit_max <= 1) return;
+    const int want = pos_end <= 768 ? 8 : pos_end <= 3072 ? 16 : 32;
+    ctx->nsplit = std::min(want, ctx->nsplit_max);
+}
+
 static ft_status upload_ctl(ft_ctx* ctx, int m0, int n, const ft_sampling* sp) {
     std::vector<RowCtl> h(n);
     for (int i = 0; i < n; ++i) {
@@ -1351,13 +1225,12 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
                     int act, const float* resid, float* out_f32, bf16_t* out_bf, long ldo, int round_out, const PfX& fx) {
     TapGemmP p{};
     p.gain = (const bf16_t*)fx.gain; p.ss_in = fx.ss_in; p.ss_out = fx.ss_out; p.ss_nblk = fx.nblk;
-    p.tail_gain = (const bf16_t*)fx.tail_gain; p.tail_out = fx.tail_out; p.ticket = L.ctx->gemm_ticket;
     p.ss_ld = std::max(L.ctx->c.dim, L.ctx->c.fast_dim) / 16 + 1; p.eps = L.ctx->c.norm_eps;
     p.X = X; p.ldx = ldx; p.T_in = S; p.W = (const bf16_t*)W; p.ntap = 1; p.offs[0] = 0; p.M = S; p.N = N; p.K = K;
     p.bias = bias; p.n_mod = N; p.act = act; p.resid_f32 = resid; p.ldr = ldo; p.out_f32 = out_f32; p.out_bf = out_bf;
     p.ldo = ldo; p.round_lin = 1; p.round_f32_out = round_out;
     const int mode = L.ctx->prefill_gemm_mode;  // FT_PREFILL_GEMM: 0 = first tile kernel only, 1 = no skinny kernel
-    const bool fused = fx.gain || fx.ss_out || fx.tail_out;
+    const bool fused = fx.gain || fx.ss_out;
     if ((mode >= 2 || fused) && S <= 128 && K % 128 == 0 && N % 2 == 0) {
         // short prompts are weight-bandwidth bound: 16 weight rows per block, K split over the waves
         if (S <= 16) skinny_gemm_launch<1>(p, 1, L.s);
@@ -1367,30 +1240,18 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
         L.err = hipErrorInvalidValue;   // the fused norm exists on the skinny kernel only (callers check the shapes)
     } else if (mode >= 1 && K % 64 == 0 && N % 128 == 0) {
         // long prompts (reference audio): the pipelined tile kernel of the codec
-        // 64x64x64 tiles at every prompt length: measured 12.8 vs 25.8 ms at Lp = 1500 and 22.3 vs 38.4 ms at 3000 against
-        // the 128x128 tile (which spills registers); the else branch stays for FT_PF_BIG_S experiments
-        static const int big_s = getenv("FT_PF_BIG_S") ? atoi(getenv("FT_PF_BIG_S")) : (1 << 30);
-        // long prompts: 128 x 128 on 8 waves (the 64 x 64 tile is bound by the L2 bandwidth of its weight re-reads)
-        static const int tile8_s = getenv("FT_PF_TILE8_S") ? atoi(getenv("FT_PF_TILE8_S")) : 512;
-        static const int wide_s = getenv("FT_PF_WIDE_S") ? atoi(getenv("FT_PF_WIDE_S")) : (1 << 30);
-        if (S >= wide_s && N % 192 == 0) {      // (w13: N = 6144) full 192-wide tiles, BK = 32
-            constexpr size_t ldsw = std::max((size_t)((128 + 56) + 2 * 192) * (32 + 8) * 2, (size_t)(128 / 2) * (192 + 4) * 4);
-            static DevOnce oncew;
-            oncew.run([] { hipFuncSetAttribute((const void*)tapgemm64_kernel<128, 192, 32, 2, 4>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw); });
-            tapgemm64_kernel<128, 192, 32, 2, 4><<<dim3((S + 127) / 128, N / 192, 1), 512, ldsw, L.s>>>(p);
-        } else if (S >= tile8_s) {
+        // 64 x 64 x 64 tiles on 4 waves up to 511 rows (the 4-wave 128 x 128 tile spills: 25.8 vs 12.8 ms at Lp = 1500);
+        // from 512 rows 128 x 128 on 8 waves (the 64 x 64 tile is bound by the L2 bandwidth of its weight re-reads)
+        constexpr int tile8_s = 512;
+        if (S >= tile8_s) {
             constexpr size_t lds8 = std::max((size_t)((128 + 56) + 2 * 128) * (64 + 8) * 2, (size_t)(128 / 2) * (128 + 4) * 4);
             static DevOnce once8;
             once8.run([] { hipFuncSetAttribute((const void*)tapgemm64_kernel<128, 128, 64, 2, 4>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); });
             tapgemm64_kernel<128, 128, 64, 2, 4><<<dim3((S + 127) / 128, N / 128, 1), 512, lds8, L.s>>>(p);
-        } else if (S <= big_s || act == ACT_SWIGLU || ldo % 8 != 0) {   // (the 4-wave 128x128 tile has the vector epilogue only)
+        } else {
             const size_t lds = std::max((size_t)((64 + 56) + 2 * 64) * (64 + 8) * 2, (size_t)(64 / 2) * (64 + 4) * 4);
             tapgemm64_kernel<64, 64, 64><<<dim3((S + 63) / 64, N / 64, 1), 256, lds, L.s>>>(p);
-        } else {
-            const size_t lds = std::max((size_t)((128 + 56) + 2 * 128) * (64 + 8) * 2, (size_t)(128 / 2) * (128 + 4) * 4);
-            tapgemm64_kernel<128, 128, 64><<<dim3((S + 127) / 128, N / 128, 1), 256, lds, L.s>>>(p);
         }
     } else if (N >= 128) tapgemm_kernel<128, 128, 2, 2><<<dim3((S + 127) / 128, (N + 127) / 128, 1), 256, 0, L.s>>>(p);
     else tapgemm_kernel<128, 64, 4, 1><<<dim3((S + 127) / 128, (N + 63) / 64, 1), 256, 0, L.s>>>(p);
@@ -1483,6 +1344,7 @@ extern "C" ft_status ft_ar_prefill_at(ft_ctx* ctx, int32_t slot, const int32_t* 
     FT_TRY(ft_ar_reset(ctx, slot));
     FT_TRY(upload_ctl(ctx, slot, 1, sp));
     FT_HIP(ctx, hipMemcpyAsync(ctx->d_prompt, prompt, (size_t)R * Lp * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    pick_nsplit(ctx, pos0 + Lp);       // (position-by-position prompt passes: the split count of this prompt's length)
     Launch L{ctx, ctx->stream, slot, 1, 0};
     const bool on_engine = eng_in_use(ctx);
     if (!ctx->prefill_v0) {
@@ -1537,6 +1399,7 @@ extern "C" ft_status ft_ar_prefill_slow(ft_ctx* ctx, int32_t slot, const int32_t
     const int R = c.num_codebooks + 1;
     FT_TRY(ft_ar_reset(ctx, slot));
     FT_HIP(ctx, hipMemcpyAsync(ctx->d_prompt, prompt, (size_t)R * Lp * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    pick_nsplit(ctx, pos0 + Lp);
     Launch L{ctx, ctx->stream, slot, 1, 0};
     if (!ctx->prefill_v0) {
         prefill_gemm(L, slot, Lp, pos0, false);
@@ -1711,19 +1574,16 @@ extern "C" ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames,
         budget = std::min(budget, ctx->n_slots - h[nslots + m]);  // cache positions left
     }
     if (budget < 0) budget = 0;
-    if (!ctx->nsplit_fixed && ctx->nsplit_max > 1) {
-        // KV splits follow the longest context this call will reach (more blocks walking the cache in parallel)
+    {   // KV splits follow the longest context this call will reach
         int pos_end = 0;
         for (int m = 0; m < nslots; ++m)
             if (!h[2 * nslots + m]) pos_end = std::max(pos_end, h[nslots + m] + budget);
-        // measured at s1-mini shapes (tools/longctx_probe.py): 8 splits are fastest up to ~700 positions, 16 up to ~3000
-        const int want = pos_end <= 768 ? 8 : pos_end <= 3072 ? 16 : 32;
-        ctx->nsplit = std::min(want, ctx->nsplit_max);
+        pick_nsplit(ctx, pos_end);
     }
     const bool eager = getenv("FT_NO_GRAPH") != nullptr;
     // several frames per graph launch where a burst allows: the gap between two graph launches is ~7 us (measured: 687 ->
-    // 692 tok/s at 16 frames per graph; the frames are the same launches in the same order).  FT_GRAPH_FRAMES=1 turns it off.
-    static const int gk = getenv("FT_GRAPH_FRAMES") ? std::max(1, atoi(getenv("FT_GRAPH_FRAMES"))) : 16;
+    // 692 tok/s at 16 frames per graph; the frames are the same launches in the same order)
+    constexpr int gk = 16;
     const int first_burst = std::min(poll, budget);
     // `burst` frames on the stream, then the done flags: graph replays (16 / 4 / 1 frames per launch) or eager launches
     auto run_burst = [&](int burst) -> ft_status {
@@ -1929,7 +1789,7 @@ extern "C" ft_status ft_ar_profile_gemv(ft_ctx* ctx, int32_t frames, const ft_sa
     // counters come from the same enqueue code as the real frame.
     double tot = 0.0;
     int64_t n_launch = 0, n_bytes = 0;
-    bool graph_ok = getenv("FT_PROFILE_EAGER") == nullptr;
+    bool graph_ok = true;
     if (graph_ok) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;

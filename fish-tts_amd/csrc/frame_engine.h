@@ -32,16 +32,7 @@ constexpr int ENG_CW = 4;                // waves 0..3 own weight rows
 constexpr int ENG_GW = 4;                // waves 4..7 gather the input vector of a phase
 // slow stack: the hand-off vectors of layer li live in the buffers of parity li & 1 (tag = epoch + li), so the lines that
 // are polled were written two layers ago and are still in the L2 / memory-side cache instead of cold in HBM
-#ifndef ENG_SLOW_REUSE
-#define ENG_SLOW_REUSE 1
-#endif
 constexpr int ENG_EPOCH_STEP = 64;       // tags used per launch (>= num_codebooks, >= slow layers)
-#ifndef ENG_ISSUE_LATE
-#define ENG_ISSUE_LATE 0                   // 1: a matrix's next rows are requested one barrier later than its last use
-#endif
-#ifndef ENG_POLL_SLEEP
-#define ENG_POLL_SLEEP 0                   // s_sleep units (64 clocks each) between two polls of a hand-off
-#endif
 constexpr unsigned long long ENG_TIMEOUT_TICKS = 20000000ull;   // 200 ms of s_memrealtime (100 MHz)
 
 typedef __attribute__((address_space(1))) unsigned eng_gu32;
@@ -103,19 +94,9 @@ __device__ __forceinline__ unsigned eng_tag16(unsigned e) { return (e & 0x7fffu)
 __device__ __forceinline__ unsigned eng_tag32(unsigned e) { return e | 0x80000000u; }
 __device__ __forceinline__ unsigned long long eng_rt() { return __builtin_amdgcn_s_memrealtime(); }
 
-// publish one bf16-representable value as a granule
-#ifndef ENG_PUT_MODE
-#define ENG_PUT_MODE 0
-#endif
+// publish one bf16-representable value as a granule (an sc1 store; atomic exchange and sc0 sc1 stores measured no faster)
 __device__ __forceinline__ void eng_put(unsigned* g, int i, float v, unsigned tag16) {
-    const unsigned w = (tag16 << 16) | (__float_as_uint(v) >> 16);
-#if ENG_PUT_MODE == 0
-    __hip_atomic_store((eng_gu32*)(g + i), w, ENG_RLX);
-#elif ENG_PUT_MODE == 1
-    (void)__hip_atomic_exchange((eng_gu32*)(g + i), w, ENG_RLX);     // executes at the memory side, not in a write buffer
-#else
-    asm volatile("global_store_dword %0, %1, off sc0 sc1" :: "v"(g + i), "v"(w) : "memory");
-#endif
+    __hip_atomic_store((eng_gu32*)(g + i), (tag16 << 16) | (__float_as_uint(v) >> 16), ENG_RLX);
 }
 __device__ __forceinline__ void eng_put_raw(unsigned* g, int i, unsigned v16, unsigned tag16) {
     __hip_atomic_store((eng_gu32*)(g + i), (tag16 << 16) | (v16 & 0xffffu), ENG_RLX);
@@ -132,80 +113,20 @@ __device__ __forceinline__ void eng_put64(unsigned long long* g, size_t i, float
     __hip_atomic_store((eng_gu64*)(g + i), ((unsigned long long)tag32 << 32) | __float_as_uint(v), ENG_RLX);
 }
 
-#ifndef ENG_POLL_BITS
-#define ENG_POLL_BITS "sc1"
-#endif
+// polls of handed-off bytes: 16-byte sc1 loads to registers, waited for at once (sc0 sc1 and nt polls measured slower
+// on buffers other XCDs write; on an XCD's replica and on XCD-local buffers nt measured the same as sc1)
+template <int FL = 0>
 __device__ __forceinline__ void eng_ld3_sc1(const void* p0, const void* p1, const void* p2, U4& a, U4& b, U4& c) {
-    asm volatile("global_load_dwordx4 %0, %3, off " ENG_POLL_BITS "\n\tglobal_load_dwordx4 %1, %4, off " ENG_POLL_BITS "\n\t"
-                 "global_load_dwordx4 %2, %5, off " ENG_POLL_BITS "\n\ts_waitcnt vmcnt(0)"
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p0), "v"(p1), "v"(p2) : "memory");
 }
+template <int FL = 0>
 __device__ __forceinline__ void eng_ld1_sc1(const void* p0, U4& a) {
-    asm volatile("global_load_dwordx4 %0, %1, off " ENG_POLL_BITS "\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(p0) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(p0) : "memory");
 }
-// One 16-byte piece per lane polled with TWO loads in flight, the second issued half a round trip after the first, so
-// memory is sampled every RTT/2 instead of every RTT (the delay between the data landing and a poll returning it is
-// RTT/2 + (sampling period)/2 on average).  The whole loop is one asm statement: the compiler never sees a register
-// whose load is still in flight.  Returns true when every lane's four granules carry `tag` (data in a); false after
-// `iters` rounds (the caller checks its clock and comes back).  Loads issued earlier by this wave return first
-// (vmcnt is in order), so the counted waits hold whatever else is outstanding.
-#ifndef ENG_PAIR_FUSE_W13
-#define ENG_PAIR_FUSE_W13 1
-#endif
-#ifndef ENG_STAGGER
-#define ENG_STAGGER 0     // measured (tools/mb_engine, same box): 597 -> 618 us (slow stack), 721 -> 746 us (fast loop) with it ON:
-#endif                    // more polls in flight slow the hand-off down, like every other "poll more" variant tried
-#ifndef ENG_STAGGER_SLEEP
-#define ENG_STAGGER_SLEEP 6       // x 64 cycles: ~half a memory-side poll round trip
-#endif
-#define ENG_STR2(x) #x
-#define ENG_STR(x) ENG_STR2(x)
-__device__ __forceinline__ bool eng_poll1_stagger(const void* p, unsigned tag, U4& a, int iters) {
-    // fixed registers v240-v249 inside the statement (inline asm cannot name the dwords of a 128-bit operand)
-    unsigned a0, a1, a2, a3;
-    int ok;
-    const unsigned tagw = tag << 16;
-#define ENG_CHK(r0, r1, r2, r3)                                                                                     \
-        "v_xor_b32 v248, " r0 ", %7\n\tv_xor_b32 v249, " r1 ", %7\n\tv_or_b32 v248, v248, v249\n\t"              \
-        "v_xor_b32 v249, " r2 ", %7\n\tv_or_b32 v248, v248, v249\n\tv_xor_b32 v249, " r3 ", %7\n\t"              \
-        "v_or_b32 v248, v248, v249\n\tv_cmp_lt_u32 vcc, 0xffff, v248\n\t"
-    asm volatile(
-        "global_load_dwordx4 v[240:243], %6, off " ENG_POLL_BITS "\n\t"
-        "s_sleep " ENG_STR(ENG_STAGGER_SLEEP) "\n\t"
-        "global_load_dwordx4 v[244:247], %6, off " ENG_POLL_BITS "\n\t"
-        "1:\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        ENG_CHK("v240", "v241", "v242", "v243")
-        "s_cbranch_vccz 2f\n\t"
-        "global_load_dwordx4 v[240:243], %6, off " ENG_POLL_BITS "\n\t"
-        "s_waitcnt vmcnt(1)\n\t"
-        ENG_CHK("v244", "v245", "v246", "v247")
-        "s_cbranch_vccz 3f\n\t"
-        "global_load_dwordx4 v[244:247], %6, off " ENG_POLL_BITS "\n\t"
-        "s_sub_u32 %5, %5, 1\n\t"
-        "s_cmp_lg_u32 %5, 0\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_mov_b32 %4, 0\n\t"
-        "s_branch 4f\n\t"
-        "3:\n\t"                       // b holds the data; the re-issued a is still in flight
-        "s_waitcnt vmcnt(0)\n\t"
-        "v_mov_b32 %0, v244\n\tv_mov_b32 %1, v245\n\tv_mov_b32 %2, v246\n\tv_mov_b32 %3, v247\n\t"
-        "s_mov_b32 %4, 1\n\t"
-        "s_branch 5f\n\t"
-        "2:\n\t"                       // a holds the data; b is still in flight
-        "s_waitcnt vmcnt(0)\n\t"
-        "s_mov_b32 %4, 1\n\t"
-        "4:\n\t"
-        "v_mov_b32 %0, v240\n\tv_mov_b32 %1, v241\n\tv_mov_b32 %2, v242\n\tv_mov_b32 %3, v243\n\t"
-        "5:\n\t"
-        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&s"(ok), "+s"(iters)
-        : "v"(p), "v"(tagw)
-        : "memory", "vcc", "scc", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249");
-#undef ENG_CHK
-    a.x = a0; a.y = a1; a.z = a2; a.w = a3;
-    return ok != 0;
-}
+// (measured and removed: two polls in flight per importer wave, the second issued half a round trip after the first -
+// 597 -> 618 us for the slow stack, 721 -> 746 us for the codebook loop: every variant that polls more is slower)
 
 __device__ __forceinline__ bool eng_tags_ok(const U4& v, unsigned tag) {
     return (v.x >> 16) == tag && (v.y >> 16) == tag && (v.z >> 16) == tag && (v.w >> 16) == tag;
@@ -245,25 +166,20 @@ struct EngSpin {
 // `per` consecutive units there with ONE store instruction, so a line is written once per phase (the memory side serves
 // the accesses to one line one after the other, and every write of a polled line also recalls its copies from the
 // XCDs' L2s: 32 four-byte writes per line cost 2.5-3 us per hand-off, 8 cost 1.6-2, one costs about 1).
-#ifndef ENG_DRAIN
-#define ENG_DRAIN 0
-#endif
-#ifndef ENG_PAD
-#define ENG_PAD 0                          // 0 (timing experiments): vectors stored linearly, 8 workgroups share a 128-byte line
-#endif
+// (measured and not kept: every producer's outputs padded to its own 128-byte line, -5 %: vectors are stored linearly)
 constexpr int ENG_LINE = 32;   // dwords
 // where workgroup b publishes its units [u_lo, ..) of a vector
-__device__ __forceinline__ size_t eng_pub(int b, int u_lo) { return ENG_PAD ? (size_t)b * ENG_LINE : (size_t)u_lo; }
+__device__ __forceinline__ size_t eng_pub(int b, int u_lo) { (void)b; return (size_t)u_lo; }
 struct EngLayout {
     int per;        // units per producing workgroup (0: the vector is stored linearly)
-    __device__ __forceinline__ int off(int u) const { return (ENG_PAD && per) ? (u / per) * ENG_LINE + (u % per) : u; }
+    __device__ __forceinline__ int off(int u) const { return u; }
 };
 struct EngIdent { __device__ __forceinline__ int operator()(int i) const { return i; } };
 
 // Gather units [u0, u0 + n) (n % 4 == 0, u0 % 4 == 0, per % 4 == 0) of the vector at g into LDS: unit u0 + i lands at
 // dst[dmap(i)] (dmap is given the first of 4 consecutive units and must keep them consecutive).  Called by ngw waves
 // (gw = 0..ngw-1); pieces of 256 units are dealt round-robin to the waves, at most three per wave and pass.
-template <typename DMap = EngIdent>
+template <typename DMap = EngIdent, int FL = 0>
 __device__ __forceinline__ void eng_gather(const unsigned* g, EngLayout lay, int u0, int n, unsigned tag, float* dst, int gw, int ngw,
                                            int lane, unsigned* ctl, int* dead, int where, DMap dmap = DMap(),
                                            unsigned long long* dbg = nullptr) {
@@ -281,14 +197,13 @@ __device__ __forceinline__ void eng_gather(const unsigned* g, EngLayout lay, int
         const int o0 = lay.off(u0 + i0), o1 = lay.off(u0 + i1), o2 = lay.off(u0 + i2);
         U4 a, b, c;
         for (;;) {
-            if (c1 == c0) { eng_ld1_sc1(g + o0, a); b = a; c = a; }
-            else eng_ld3_sc1(g + o0, g + o1, g + o2, a, b, c);
+            if (c1 == c0) { eng_ld1_sc1<FL>(g + o0, a); b = a; c = a; }
+            else eng_ld3_sc1<FL>(g + o0, g + o1, g + o2, a, b, c);
             const bool oa = eng_tags_ok(a, tag), ob = eng_tags_ok(b, tag), oc = eng_tags_ok(c, tag);
             if (dbg && n_full == 0) t_first = eng_rt();
             ++n_full;
             if (__all(oa && ob && oc)) break;
             if (sp.give_up(lane)) return;
-            if (ENG_POLL_SLEEP) __builtin_amdgcn_s_sleep(ENG_POLL_SLEEP);
         }
         if (c0 * 256 + lane * 4 < n) eng_unpack_to_lds(dst + dmap(i0), a);
         if (c1 != c0 && c1 * 256 + lane * 4 < n) eng_unpack_to_lds(dst + dmap(i1), b);
@@ -305,9 +220,6 @@ __device__ __forceinline__ void eng_gather(const unsigned* g, EngLayout lay, int
 // (sc1 loads: past their L1, served by the L2 they share with the importer).  The XCD of a workgroup is read from the
 // hardware (XCC_ID), never assumed from blockIdx; replicas carry the same self-validating {tag, value} granules.
 // ------------------------------------------------------------------------------------------
-#ifndef ENG_RELAY
-#define ENG_RELAY 1
-#endif
 struct EngRelay {
     int on;          // 0: every workgroup polls the source buffer itself
     int rank, nr;    // this workgroup's rank among the nr workgroups of its XCD
@@ -344,27 +256,20 @@ __device__ __forceinline__ void eng_gather_x(const EngRelay& rl, const unsigned*
         const int o = lay.off(u0 + i);
         EngSpin sp{ctl, dead, 0, 0, where};
         U4 a;
-#if ENG_STAGGER
-        for (;;) {
-            if (eng_poll1_stagger(g + o, tag, a, 128)) break;
-            sp.spins |= 255u;                           // (a round of 128 double polls: look at the clock now)
-            if (sp.give_up(lane)) return;
-        }
-#else
         for (;;) {
             eng_ld1_sc1(g + o, a);
             if (__all(eng_tags_ok(a, tag))) break;
             if (sp.give_up(lane)) return;
         }
-#endif
         if (p * 256 + lane * 4 < n) *reinterpret_cast<U4*>(rep + o) = a;      // plain store: stays in this XCD's L2
     }
-    eng_gather(rep, lay, u0, n, tag, dst, gw, ngw, lane, ctl, dead, where, dmap, dbg);
+    eng_gather<DMap, 1>(rep, lay, u0, n, tag, dst, gw, ngw, lane, ctl, dead, where, dmap, dbg);
 }
 
 // Two vectors of the same length n (n % 256 == 0) gathered as ONE list of 2 * npiece pieces (the two rows of the fast
 // loop's first pass): piece P < npiece belongs to vector 0, the others to vector 1.
 struct EngSrc2 { const unsigned* g[2]; float* dst[2]; unsigned tag[2]; };
+template <int FL = 0>
 __device__ __forceinline__ void eng_gather2(const EngSrc2& S, long delta, int n, int gw, int ngw, int lane, unsigned* ctl, int* dead,
                                             int where) {
     const int npiece = n >> 8, NP = 2 * npiece;
@@ -381,8 +286,8 @@ __device__ __forceinline__ void eng_gather2(const EngSrc2& S, long delta, int n,
         const unsigned t0 = S.tag[s0], t1 = S.tag[s1], t2 = S.tag[s2];
         U4 a, b, c;
         for (;;) {
-            if (c1 == c0) { eng_ld1_sc1(a0, a); b = a; c = a; }
-            else eng_ld3_sc1(a0, a1, a2, a, b, c);
+            if (c1 == c0) { eng_ld1_sc1<FL>(a0, a); b = a; c = a; }
+            else eng_ld3_sc1<FL>(a0, a1, a2, a, b, c);
             const bool oa = eng_tags_ok(a, t0), ob = c1 == c0 || eng_tags_ok(b, t1), oc = c2 == c0 || eng_tags_ok(c, t2);
             if (__all(oa && ob && oc)) break;
             if (sp.give_up(lane)) return;
@@ -411,7 +316,7 @@ __device__ __forceinline__ void eng_gather_x2(const EngRelay& rl, const EngSrc2&
         }
         *reinterpret_cast<U4*>(const_cast<unsigned*>(src) + rl.delta) = a;
     }
-    eng_gather2(S, rl.delta, n, gw, ngw, lane, ctl, dead, where);
+    eng_gather2<1>(S, rl.delta, n, gw, ngw, lane, ctl, dead, where);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -584,9 +489,6 @@ __device__ __forceinline__ void eng_gemv(const EngW<NT, RPU, MAXS>& r, const flo
             eng_put(gout, lane, o, tag);
             if (plain) plain[u_lo + lane] = o;
         }
-#if ENG_DRAIN
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     }
 }
 
@@ -674,7 +576,7 @@ template <int NT, int RPU, int MAXS, int PRO, int EPI>
 __device__ __forceinline__ void eng_gemv2(const EngW<NT, RPU, MAXS>& r, const float* xs0, const float* xs1, int K, float eps,
                                           const bf16_t* bias, const float* resid0, const float* resid1, unsigned* gout0, unsigned* gout1,
                                           unsigned tag0, unsigned tag1, int u_lo, int u_hi, int cw, int lane, EngOut& eo) {
-    if (NT <= 2 && (ENG_PAIR_FUSE_W13 || RPU == 1)) {
+    if (NT <= 2) {
         eng_gemv_rows2<NT, RPU, MAXS, PRO, EPI>(r, xs0, xs1, K, eps, bias, resid0, resid1, eo.vals, eo.vals + 32, u_lo, u_hi, cw, lane);
     } else {
         eng_gemv_rows<NT, RPU, MAXS, PRO, EPI>(r, xs0, K, eps, bias, resid0, eo.vals, u_lo, u_hi, cw, lane);
@@ -787,7 +689,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     if (tid == 0) { *dead = eng_fault_here(p.ctl, 0u, b) ? 1 : 0; *out_count = 0; }
     if (tid == ENG_CW * 64) {             // one thread owns the registration words
         reg_s[0] = 0; reg_s[1] = 0; reg_s[2] = 1;
-        if (XL || (ENG_RELAY && p.rep_stride)) eng_register(p.ctl, nb, reg_s, dead);
+        if (XL || p.rep_stride) eng_register(p.ctl, nb, reg_s, dead);
         if (XL && (reg_s[2] * p.Hkv != nb || reg_s[0] >= p.Hkv || reg_s[1] >= reg_s[2] || p.nsplit != reg_s[2])) {
             // census failed (the workgroups are not spread Hkv x nb / Hkv over the XCDs): nobody may rely on XCD-local data
             if (!__hip_atomic_load((eng_gu32*)(p.ctl + ENG_CTL_ABORT), ENG_RLX)) __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_WHERE), 9998u, ENG_RLX);
@@ -872,16 +774,13 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
         }
         eng_barrier();                                              // B0
         for (int li = 0; li < p.n_layer; ++li) {
-            const int par = ENG_SLOW_REUSE ? (li & 1) : li, parn = ENG_SLOW_REUSE ? ((li + 1) & 1) : li + 1;
-            const unsigned tag = eng_tag16(epoch + (ENG_SLOW_REUSE ? (unsigned)li : 0u));
-            const unsigned tagn = eng_tag16(epoch + (ENG_SLOW_REUSE ? (unsigned)li + 1u : 0u));    // the next layer reads W2's output
+            const int par = li & 1, parn = (li + 1) & 1;
+            const unsigned tag = eng_tag16(epoch + (unsigned)li);
+            const unsigned tagn = eng_tag16(epoch + (unsigned)li + 1u);    // the next layer reads W2's output
             const EngLayer l = eng_layer(p.layers, li);
             const bool more = li + 1 < p.n_layer;
             const EngLayer ln = eng_layer(p.layers, more ? li + 1 : li);
             if (li > 0) { eng_barrier(); if (*dead) break; }        // B1
-#if ENG_ISSUE_LATE
-            if (li > 0) { eng_issue(wd, l.w2, (const bf16_t*)nullptr, F, d_lo, d_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
-#endif
             ENG_STAMP(0);
             if (XL)
                 eng_gemv_qkv_local<NTD, SQ>(wq, xA, D, p.eps, l.bqkv, p.gqkv + (size_t)par * VSTR, tag, q_hi, cw, lane, eo, rmq);
@@ -890,13 +789,11 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                                                              q_lo, q_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(1);
-#if !ENG_ISSUE_LATE
             if (more) {
                 if (XL) eng_issue(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, p.nt, rmq);
                 else eng_issue(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, p.nt);
             }
             __builtin_amdgcn_sched_barrier(0);
-#endif
             if (XL || eng_att_role(b, nb, li, natt) >= 0) {
                 eng_barrier(); if (*dead) break;                    // BA
                 eng_barrier();                                      // BB
@@ -904,43 +801,28 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             }
             ENG_STAMP(2);
             eng_barrier(); if (*dead) break;                        // B2
-#if ENG_ISSUE_LATE
-            if (more) { eng_issue(wq, ln.wqkv, ln.attn_norm, D, q_lo, q_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
-#endif
             ENG_STAMP(3);
             eng_gemv<NTA, 1, SO, PRO_NONE, EPI_RESID>(wo, yS, HD, p.eps, l.bo, xA, p.gxb + (size_t)par * VSTR + eng_pub(b, o_lo), tag, nullptr, o_lo, o_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(4);
             if (p.stamps && (p.nt & 2)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ENG_STAMP(9); }   // write-through acknowledged
-#if !ENG_ISSUE_LATE
             if (more) eng_issue(wo, ln.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, p.nt);
             __builtin_amdgcn_sched_barrier(0);
-#endif
             eng_barrier(); if (*dead) break;                        // B3
-#if ENG_ISSUE_LATE
-            if (more) { eng_issue(wo, ln.wo, (const bf16_t*)nullptr, HD, o_lo, o_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
-#endif
             ENG_STAMP(5);
             eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, D, p.eps, nullptr, nullptr, p.gg + (size_t)par * VSTR + eng_pub(b, f_lo), tag, nullptr, f_lo, f_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(6);
-#if !ENG_ISSUE_LATE
             if (more) eng_issue(wf, ln.w13, ln.ffn_norm, D, f_lo, f_hi, cw, lane, p.nt);
             __builtin_amdgcn_sched_barrier(0);
-#endif
             eng_barrier(); if (*dead) break;                        // B4
-#if ENG_ISSUE_LATE
-            if (more) { eng_issue(wf, ln.w13, ln.ffn_norm, D, f_lo, f_hi, cw, lane, p.nt); __builtin_amdgcn_sched_barrier(0); }
-#endif
             ENG_STAMP(7);
             eng_gemv<NTF, 1, SO, PRO_NONE, EPI_RESID>(wd, gS, F, p.eps, nullptr, xB, p.gx + (size_t)parn * VSTR + eng_pub(b, d_lo), tagn,
                                                       li == p.n_layer - 1 ? p.x_out : nullptr, d_lo, d_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(8);
-#if !ENG_ISSUE_LATE
             if (more) eng_issue(wd, ln.w2, (const bf16_t*)nullptr, F, d_lo, d_hi, cw, lane, p.nt);
             __builtin_amdgcn_sched_barrier(0);
-#endif
             if (!(p.nt & 2)) ENG_STAMP(9);
         }
     } else {
@@ -1001,15 +883,15 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
         };
         if (!XL) { kv_plan(0); kv_issue(); }
         eng_barrier();                                              // (registration results in LDS)
-        const EngRelay rl{ENG_RELAY && p.rep_stride != 0, reg_s[1], reg_s[2], p.rep_delta0 + (long)reg_s[0] * p.rep_stride};
+        const EngRelay rl{p.rep_stride != 0, reg_s[1], reg_s[2], p.rep_delta0 + (long)reg_s[0] * p.rep_stride};
         if (XL) { x_role = reg_s[0] * p.nsplit + reg_s[1]; kv_plan(0); kv_issue(); }
         // rotation entries of this position (the same for every layer)
         float rope_c = 1.f, rope_s = 0.f;
         if (lane < hp) { rope_c = p.rope[((size_t)pos * hp + lane) * 2]; rope_s = p.rope[((size_t)pos * hp + lane) * 2 + 1]; }
         eng_barrier();                                              // B0
         for (int li = 0; li < p.n_layer; ++li) {
-            const int par = ENG_SLOW_REUSE ? (li & 1) : li;
-            const unsigned tag = eng_tag16(epoch + (ENG_SLOW_REUSE ? (unsigned)li : 0u)), tag32 = eng_tag32(epoch + (ENG_SLOW_REUSE ? (unsigned)li : 0u));
+            const int par = li & 1;
+            const unsigned tag = eng_tag16(epoch + (unsigned)li), tag32 = eng_tag32(epoch + (unsigned)li);
             const EngLayer l = eng_layer(p.layers, li);
             if (li > 0) {
                 eng_gather_x(rl, p.gx + (size_t)par * VSTR, layD, 0, D, tag, xA, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 0);
@@ -1028,9 +910,10 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 const unsigned* gq = p.gqkv + (size_t)par * VSTR;
                 ENG_ASTAMP(0, 0);
                 // q heads of the group (G*hd granules), new k, new v (hd each): one gathering wave per piece
-                if (gw == 0) eng_gather(gq, layQ, kvh * G * hd, G * hd, tag, qS, 0, 1, lane, p.ctl, dead, li * 8 + 1);
-                if (gw == 1) eng_gather(gq, layQ, (p.H + kvh) * hd, hd, tag, qS + G * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
-                if (gw == 2) eng_gather(gq, layQ, (p.H + p.Hkv + kvh) * hd, hd, tag, qS + (G + 1) * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
+                constexpr int QFL = XL ? 2 : 0;      // (XL: written inside this XCD)
+                if (gw == 0) eng_gather<EngIdent, QFL>(gq, layQ, kvh * G * hd, G * hd, tag, qS, 0, 1, lane, p.ctl, dead, li * 8 + 1);
+                if (gw == 1) eng_gather<EngIdent, QFL>(gq, layQ, (p.H + kvh) * hd, hd, tag, qS + G * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
+                if (gw == 2) eng_gather<EngIdent, QFL>(gq, layQ, (p.H + p.Hkv + kvh) * hd, hd, tag, qS + (G + 1) * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
                 eng_barrier(); if (*dead) break;                    // BA
                 ENG_ASTAMP(0, 1);
                 if (gw >= 0) {
@@ -1102,43 +985,39 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                             }
                         }
                     };
-                    const bool pre = att_next == li;     // the registers hold this layer's rows
+                    const bool pre = att_next == li;     // the registers hold this layer's first ENG_KVST steps
+                    // The K/V registers are a rolling window: while step st is consumed, the rows of step st + ENG_KVST start
+                    // their trip into the registers it frees, so a walk of any length keeps ENG_KVST steps in flight (long
+                    // contexts, and the unsplit walk of the XCD-local form) with the register count of a short one.
+                    for (int blk = 0; lo + gw * PPW + blk * (ENG_KVST * NSLOT) < hi; ++blk) {      // wave-uniform
 #pragma unroll
-                    for (int st = 0; st < ENG_KVST; ++st) {
-                        const int base = lo + gw * PPW + st * NSLOT;
-                        if (base < hi) {                 // wave-uniform
-                            const int j = base + grp;
-                            float kv[8], vv[8];
-                            if (j < hi && j == pos) {
+                        for (int st = 0; st < ENG_KVST; ++st) {
+                            const int base = lo + gw * PPW + (blk * ENG_KVST + st) * NSLOT;
+                            if (base < hi) {                 // wave-uniform
+                                const int j = base + grp;
+                                float kv[8], vv[8];
+                                if (j < hi && j == pos) {
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) { kv[e] = k_new[gl * 8 + e]; vv[e] = v_new[gl * 8 + e]; }
-                            } else if (pre) {
-                                Vec<bf16_t>::unpack(kpf[st], kv); Vec<bf16_t>::unpack(vpf[st], vv);
-                            } else if (j < hi) {
-                                Vec<bf16_t>::unpack(eng_ldg16<false>(kc + (size_t)j * hd + gl * 8), kv);
-                                Vec<bf16_t>::unpack(eng_ldg16<false>(vc + (size_t)j * hd + gl * 8), vv);
-                            } else {
+                                    for (int e = 0; e < 8; ++e) { kv[e] = k_new[gl * 8 + e]; vv[e] = v_new[gl * 8 + e]; }
+                                } else if (pre || blk > 0) {
+                                    Vec<bf16_t>::unpack(kpf[st], kv); Vec<bf16_t>::unpack(vpf[st], vv);
+                                } else if (j < hi) {
+                                    Vec<bf16_t>::unpack(eng_ldg16<false>(kc + (size_t)j * hd + gl * 8), kv);
+                                    Vec<bf16_t>::unpack(eng_ldg16<false>(vc + (size_t)j * hd + gl * 8), vv);
+                                } else {
 #pragma unroll
-                                for (int e = 0; e < 8; ++e) { kv[e] = 0.f; vv[e] = 0.f; }
-                            }
-                            step(j, kv, vv);
-                        }
-                    }
-                    for (int base = lo + gw * PPW + ENG_KVST * NSLOT; base < hi; base += NSLOT) {   // long contexts
-                        const int j = base + grp;
-                        float kv[8], vv[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) { kv[e] = 0.f; vv[e] = 0.f; }
-                        if (j < hi) {
-                            if (j == pos) {
-#pragma unroll
-                                for (int e = 0; e < 8; ++e) { kv[e] = k_new[gl * 8 + e]; vv[e] = v_new[gl * 8 + e]; }
-                            } else {
-                                Vec<bf16_t>::unpack(eng_ldg16<false>(kc + (size_t)j * hd + gl * 8), kv);
-                                Vec<bf16_t>::unpack(eng_ldg16<false>(vc + (size_t)j * hd + gl * 8), vv);
+                                    for (int e = 0; e < 8; ++e) { kv[e] = 0.f; vv[e] = 0.f; }
+                                }
+                                const int jn = j + ENG_KVST * NSLOT;
+                                if (jn < hi && jn != pos) {
+                                    kpf[st] = eng_ldg16<false>(kc + (size_t)jn * hd + gl * 8);
+                                    vpf[st] = eng_ldg16<false>(vc + (size_t)jn * hd + gl * 8);
+                                } else {
+                                    kpf[st] = U4{0u, 0u, 0u, 0u}; vpf[st] = U4{0u, 0u, 0u, 0u};
+                                }
+                                step(j, kv, vv);
                             }
                         }
-                        step(j, kv, vv);
                     }
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
@@ -1220,7 +1099,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                     U4 A, B, C;
                     bool alive = true;
                     for (;;) {
-                        eng_ld3_sc1(gs + e, gs + e + 2, gs + hd, A, B, C);
+                        eng_ld3_sc1<2>(gs + e, gs + e + 2, gs + hd, A, B, C);
                         const bool ok = A.y == tag32 && A.w == tag32 && B.y == tag32 && B.w == tag32 && C.y == tag32 && C.w == tag32;
                         if (__all(ok)) break;
                         if (sp.give_up(lane)) { alive = false; break; }
@@ -1249,22 +1128,32 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                         q5[3] = __uint_as_float(B.x) * w; q5[4] = __uint_as_float(B.z) * w;
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        // chains: lane 8 i + q (q < 5) sums quantity q of head i over the 32 splits in split order
+                        // chains: lane 8 i + q (q < 5) sums quantity q of head i over the 32 splits in split order.  Branch-free:
+                        // an empty chunk's products are exact zeros and its rescale factor an exact 1 (as is the factor of the
+                        // first visible chunk), so adding / multiplying them changes no bit; all 32 LDS reads and the three
+                        // exponentials are issued before the dependent chain of additions starts.
                         const int ci = (lane >> 3) & 1, cq = lane & 7;
                         float acc = 0.f;
-                        if (cq < 5) {
-                            const float* src = pr + (size_t)ci * 32 * 5 + cq;
+                        {
+                            const float* src = pr + (size_t)ci * 32 * 5 + (cq < 5 ? cq : 0);
+                            float v[32];
+#pragma unroll
+                            for (int k = 0; k < 32; ++k) v[k] = src[k * 5];
+                            float mc[4], rr[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) mc[c] = mx[ci * 4 + c];
                             float M = -INFINITY;
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
-                                const float mc = mx[ci * 4 + c];
-                                if (mc > -INFINITY) {                   // (an empty chunk adds nothing and rescales nothing)
-                                    const float Mn = fmaxf(M, mc);
-                                    if (c > 0 && M > -INFINITY) acc *= expf(M - Mn);
-                                    M = Mn;
+                                const float Mn = fmaxf(M, mc[c]);
+                                rr[c] = (c > 0 && M > -INFINITY && mc[c] > -INFINITY) ? expf(M - Mn) : 1.0f;
+                                M = Mn;
+                            }
 #pragma unroll
-                                    for (int k = 0; k < 8; ++k) acc += src[(c * 8 + k) * 5];
-                                }
+                            for (int c = 0; c < 4; ++c) {
+                                acc *= rr[c];
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) acc += v[c * 8 + k];
                             }
                         }
                         // the head's l sits in lane 8 i, a0..a3 in the four lanes after it
@@ -1300,7 +1189,6 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                                                          C.y == tag32 && C.w == tag32);
                                 if (__all(ok)) break;
                                 if (sp.give_up(lane)) { alive = false; break; }
-                                __builtin_amdgcn_s_sleep(ENG_POLL_SLEEP);
                             }
                             if (!alive) break;
                             if (ib + 8 >= nitem && c0 + 8 >= p.nsplit) ENG_ASTAMP(3, 5);      // last partials seen
@@ -1559,9 +1447,6 @@ __device__ __forceinline__ void eng_fast_attn(const float* qkvS, bf16_t* kS, bf1
 //    ((R0 + R1) + R2) + R3 = its readlane chain;
 //  * q (dimension per lane after the rotation) reaches that layout through the head's own slot of yS, which also
 //    carries the scores to "lane j holds score j"; the slot receives the head's output last.
-#ifndef ENG_FAST_ATTN64
-#define ENG_FAST_ATTN64 1
-#endif
 constexpr int DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108, DPP_ROW_SHL12 = 0x10C;   // lane i <- lane i + n of its 16-lane row
 template <int MAXCB, int GQ>
 __device__ __forceinline__ void eng_fast_attn64(const float* qkvS, bf16_t* kS, bf16_t* vS, float* yS, const bf16_t* qn, const bf16_t* kn,
@@ -1675,7 +1560,7 @@ template <int MAXCB, int HD>
 __device__ __forceinline__ void eng_fast_attn_any(const float* qkvS, bf16_t* kS, bf16_t* vS, float* yS, const bf16_t* qn, const bf16_t* kn,
                                                   const float (&cs)[2], const float (&sn)[2], int c, int ncb, int H, int Hkv, float eps,
                                                   float scale, int w, int nw, int lane) {
-    if constexpr (HD == 64 && MAXCB <= 16 && ENG_FAST_ATTN64) {
+    if constexpr (HD == 64 && MAXCB <= 16) {
         const int G = H / Hkv;
         if (G == 2) { eng_fast_attn64<MAXCB, 2>(qkvS, kS, vS, yS, qn, kn, cs[0], sn[0], c, ncb, H, Hkv, eps, scale, w, nw, lane); return; }
         if (G == 1) { eng_fast_attn64<MAXCB, 1>(qkvS, kS, vS, yS, qn, kn, cs[0], sn[0], c, ncb, H, Hkv, eps, scale, w, nw, lane); return; }
@@ -2017,7 +1902,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     if (tid == 0) { *dead = eng_fault_here(p.ctl, ENG_FAULT_FAST, b) ? 1 : 0; *out_count = 0; *sub_count = 0; }
     if (tid == ENG_CW * 64) {                  // one thread owns the registration words
         reg_s[0] = 0; reg_s[1] = 0; reg_s[2] = 1;
-        if (ENG_RELAY && p.rep_stride) eng_register(p.ctl, nb, reg_s, dead);
+        if (p.rep_stride) eng_register(p.ctl, nb, reg_s, dead);
     }
     const unsigned epoch = __hip_atomic_load((eng_gu32*)(p.ctl + ENG_CTL_EPOCH), ENG_RLX);
     const size_t VSTR = (size_t)nb * ENG_LINE;
@@ -2032,7 +1917,6 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     auto drawer = [&](int cb) { return (cb * 37) % nb; };   // the workgroup that draws codebook cb
     bool alive = true;
     const bool pair = p.pair != 0 && p.ncb >= 2;
-    static_assert(ENG_PAD == 0, "the paired first pass assumes linear hand-off vectors");
 
     if (wave < ENG_CW) {
         // =============================== compute waves ===============================
@@ -2220,7 +2104,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
         SampP sp = p.samp;
         int prev_code = 0;
         eng_barrier();                                                  // (registration results in LDS)
-        const EngRelay rl{ENG_RELAY && p.rep_stride != 0, reg_s[1], reg_s[2], p.rep_delta0 + (long)reg_s[0] * p.rep_stride};
+        const EngRelay rl{p.rep_stride != 0, reg_s[1], reg_s[2], p.rep_delta0 + (long)reg_s[0] * p.rep_stride};
         eng_barrier();                                                  // B0
         if (pair) {
             const unsigned tag0 = eng_tag16(epoch), tag1 = eng_tag16(epoch + 1u);

@@ -112,9 +112,14 @@ def state_dict_keys(c: ARShape) -> Dict[str, tuple]:
     return keys
 
 
-def random_weights(c: ARShape, seed: int = 0, dtype=torch.float32, std: Optional[float] = None):
+def random_weights(c: ARShape, seed: int = 0, dtype=torch.float32, std: Optional[float] = None, loud=None):
     """Seeded synthetic weights: normal(0, std) for matrices/embeddings, ones for norm
-    gains (the reference's init rule, llama.py:455-464), generated in fp32 then cast."""
+    gains (the reference's init rule, llama.py:455-464), generated in fp32 then cast.
+
+    loud = (n, factor): n seeded rows of the vocabulary head inside the semantic id range and n of the codebook head's
+    first min(1024, codebook_size) rows are scaled by factors spread over (factor, 2 factor].  With iid normal rows the top-1/top-2 gap of V logits is
+    ~1/20 of their range whatever the scale (order statistics), i.e. about the size of a few bf16 steps; a few loud rows
+    give the decisions the clear margins a trained model has, so that a bf16 parity test can judge nearly all of them."""
     g = torch.Generator().manual_seed(seed)
     std = c.initializer_range if std is None else std
     out = {}
@@ -126,8 +131,19 @@ def random_weights(c: ARShape, seed: int = 0, dtype=torch.float32, std: Optional
             w = 0.02 * torch.randn(shp, generator=g)
         else:
             w = std * torch.randn(shp, generator=g)
-        out[k] = w.to(dtype)
-    return out
+        out[k] = w
+    if loud is not None:
+        n, factor = int(loud[0]), float(loud[1])
+        g2 = torch.Generator().manual_seed(seed + 7919)
+        head = "embeddings.weight" if c.tie_word_embeddings else "output.weight"
+        n_sem = c.semantic_end_id - c.semantic_begin_id + 1
+        rows = c.semantic_begin_id + torch.randperm(n_sem, generator=g2)[:n]
+        # (factor, 2 factor]: unequal loudness spreads the leaders apart
+        scale = factor * (1.0 + torch.arange(n, dtype=torch.float32) / max(n, 1)).unsqueeze(1)
+        out[head][rows] *= scale
+        rows = torch.randperm(min(1024, c.codebook_size), generator=g2)[:n]
+        out["fast_output.weight"][rows] *= scale
+    return {k: w.to(dtype) for k, w in out.items()}
 
 
 # ----------------------------------------------------------------------------- math

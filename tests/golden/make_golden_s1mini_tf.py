@@ -20,6 +20,7 @@ from tests.shapes import make_prompt, s1mini_shape  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 STD, SEED_W, LP, N_NEW = 0.05, 0, 24, 17
+LOUD = (16, 4.0)     # oracle.ar.random_weights: a few loud head rows give the decisions a trained model's margins
 KW = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.0)
 
 
@@ -28,9 +29,10 @@ def main():
     from oracle import ar as O
     llama, inference, _ = import_reference()
     shape = s1mini_shape()
-    w = O.random_weights(shape, seed=SEED_W, std=STD)
+    w = O.random_weights(shape, seed=SEED_W, std=STD, loud=LOUD)
     prompt = make_prompt(shape, LP, seed=1, n_vq=3)
-    out = {"prompt": prompt.numpy(), "std": np.float32(STD), "seed_w": np.int64(SEED_W), "n_new": np.int64(N_NEW)}
+    out = {"prompt": prompt.numpy(), "std": np.float32(STD), "seed_w": np.int64(SEED_W), "n_new": np.int64(N_NEW),
+           "loud_n": np.int64(LOUD[0]), "loud_factor": np.float32(LOUD[1])}
     for tag, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
         model, tok = build_reference_model(llama, shape, w, dtype)
         seq = inference.generate(model=model, prompt=prompt.clone(), max_new_tokens=N_NEW, audio_masks=None,

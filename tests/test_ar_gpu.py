@@ -496,10 +496,10 @@ def test_sampling_kernel_vs_oracle(precision):
     assert not bad, f"{len(bad)}/{n_cases} draws differ: {bad[:8]}"
 
 
-def test_large_vocabulary_sampler_vs_oracle(monkeypatch):
+def test_large_vocabulary_sampler_vs_oracle():
     """The 155 776-way draw (LDS class histogram + cut search in one block, chip-wide race) on identical logits and
-    noise against the oracle: flat and peaked distributions, ties at the top, penalties, top-p from 1e-6 to 1; and the
-    same draws through the global-histogram kernels (FT_SAMPLER_GLOBAL_HIST), which remain the fallback."""
+    noise against the oracle: flat and peaked distributions, ties at the top, penalties, top-p from 1e-6 to 1, and a row
+    whose packed class counters wrap (the exact recount)."""
     import dataclasses
     V = 155776
     n_sem = 2048
@@ -517,7 +517,7 @@ def test_large_vocabulary_sampler_vs_oracle(monkeypatch):
         if trial == 5:
             logits[:70000] = logits.min() - 1   # one class (far below any cut: a cut inside a tie class has no defined
             #                                     member order in the reference) holds > 65 535 logits: the packed
-            #                                     counters wrap and the global-histogram fallback runs
+            #                                     counters wrap and the row is recounted with saturating updates
         window = torch.randint(0, 1024, (R, 16), generator=g).int()
         window[0] = torch.randint(0, V, (16,), generator=g).int()
         q = torch.empty(V).exponential_(1.0, generator=g).clamp_min_(1e-6)
@@ -525,27 +525,14 @@ def test_large_vocabulary_sampler_vs_oracle(monkeypatch):
             want = O.sample(logits.clone()[None, None], torch.tensor(temp), torch.tensor(tp), torch.tensor(rep),
                             window[:, 0], noise=lambda p: q.to(p.dtype))[0].item()
             cases.append((logits, window, q, tp, temp, rep, want))
-    # "lds" (the default): everything in one block; "fused": histogram spread over ceil(V / 4096) blocks, cut search in the
-    # last-arriving one (measured slower, opt-in); "global": the two-launch form
-    # "tail1": count + race + finish as one launch (chained look-back; opt-in, measured equal)
-    for mode in ("lds", "fused", "global", "tail1"):
-        monkeypatch.delenv("FT_SAMPLER_GLOBAL_HIST", raising=False)
-        monkeypatch.delenv("FT_SAMPLER_FUSED", raising=False)
-        monkeypatch.delenv("FT_SAMPLER_TAIL1", raising=False)
-        if mode == "global":
-            monkeypatch.setenv("FT_SAMPLER_GLOBAL_HIST", "1")
-        elif mode == "fused":
-            monkeypatch.setenv("FT_SAMPLER_FUSED", "1")
-        elif mode == "tail1":
-            monkeypatch.setenv("FT_SAMPLER_TAIL1", "1")
-        eng, _ = make_pair(shape, "bf16")
-        bad = []
-        for ci, (logits, window, q, tp, temp, rep, want) in enumerate(cases):
-            got = eng.test_sample(logits.float().numpy(), 0, eng._sampling(temp, tp, rep), window.numpy(), q.numpy())
-            if got != want and not (logits[got] == logits[want]):
-                bad.append((mode, ci, tp, temp, rep, got, want))
-        eng.close()
-        assert not bad, bad[:6]
+    eng, _ = make_pair(shape, "bf16")
+    bad = []
+    for ci, (logits, window, q, tp, temp, rep, want) in enumerate(cases):
+        got = eng.test_sample(logits.float().numpy(), 0, eng._sampling(temp, tp, rep), window.numpy(), q.numpy())
+        if got != want and not (logits[got] == logits[want]):
+            bad.append((ci, tp, temp, rep, got, want))
+    eng.close()
+    assert not bad, bad[:6]
 
 
 def test_state_dict_with_extra_keys_loads_like_strict_false():
@@ -596,7 +583,8 @@ def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
     g = np.load(os.path.join(G, "ar_s1mini_tf.npz"))
     shape = s1mini_shape()
     dtype = torch.float32 if precision == "fp32" else torch.bfloat16
-    w = O.random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]), dtype=dtype)
+    w = O.random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]), dtype=dtype,
+                         loud=(int(g["loud_n"]), float(g["loud_factor"])))
     eng = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,
                       precision=precision, device=0, max_batch=1, max_new_tokens=8)
     eng.load_state_dict(w)
@@ -606,7 +594,7 @@ def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
     T, n_new = prompt.shape[1], int(g["n_new"])
     absmax = max(1.0, float(g[f"{tag}.logit_absmax"]))
     tol = (1e-4 if precision == "fp32" else 0.03) * absmax
-    ltol = (2e-3 if precision == "fp32" else 0.05) * absmax
+    ltol = (2e-3 if precision == "fp32" else 0.03) * absmax
     sp = eng._sampling(0.7, 1e-6, 1.0)
     flips, judged = [], 0
     dflips, djudged, dframes = [], 0, 0
@@ -643,45 +631,17 @@ def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
             dframes += 1
     print(f"{tag}: {judged} decisions equal, legitimate flips (frame, row, reference margin) at {flips}")
     print(f"{tag}: decode loop: {dframes} frames judged, {djudged} decisions equal, legitimate flips at {dflips}")
-    assert dframes >= 3, dframes
-    assert djudged >= 0.6 * dframes * seq.shape[0]
+    assert dframes >= (n_new - 1) // 2, dframes
+    assert djudged >= 0.8 * dframes * seq.shape[0]
     if precision == "bf16":
         assert eng.engine_state()[1] == 0
-    # (random weights at this width give many near-ties in bf16: 2-7 of a frame's 10 decisions have a margin inside the
-    # tolerance; a flip ends the judging of its frame only, the next frame is forced back onto the golden tokens)
-    assert judged >= 0.6 * n_new * seq.shape[0]
+    # (the fixture's weights have a few loud head rows - oracle.ar.random_weights - so that 143 of the 170 bf16 decisions
+    # clear the tolerance; with iid rows 70 of 170 sat inside it.  A flip ends the judging of its frame only, the next
+    # frame is forced back onto the golden tokens.)
+    assert judged >= 0.8 * n_new * seq.shape[0]
     if precision == "fp32":
         assert len(flips) <= 1
     eng.close()
-
-
-@pytest.mark.parametrize("B", [20, 32])
-def test_wide_path_tail_norm_keeps_the_bits(monkeypatch, B):
-    """17..128 lock-step rows, opt-in FT_TAIL_NORM (measured slower than the launches it removes, kept as an experiment):
-    the RMSNorm that follows a Wo / W2 GEMM runs inside that GEMM's last-finishing block (codec_kernels.h, `tail_out`)
-    - same arithmetic as rmsnorm_llama_rows_kernel, so the frames must equal those of the default run bit for bit, all
-    rows, several frames.  A stale read of the GEMM's output by the last block would show up here."""
-    from fish_tts_amd.ar_engine import ARHipEngine
-    shape = dataclasses.replace(medium_shape(), max_seq_len=256)
-    w = O.random_weights(shape, seed=3, std=0.05, dtype=torch.bfloat16)
-    prompts = [make_prompt(shape, 6 + (7 * i) % 19, seed=900 + i, n_vq=i % 3) for i in range(B)]
-    outs = []
-    for off in (True, False):
-        if off:
-            monkeypatch.delenv("FT_TAIL_NORM", raising=False)
-        else:
-            monkeypatch.setenv("FT_TAIL_NORM", "1")
-        eng = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,
-                          precision="bf16", device=0, max_batch=B, max_new_tokens=32)
-        eng.load_state_dict(w)
-        sp = [eng._sampling(0.7, 0.8, 1.1, seed=i) for i in range(B)]
-        firsts = [eng.prefill(p.numpy(), sp[i], slot=i) for i, p in enumerate(prompts)]
-        frames, n = eng.decode(12, sp, poll=12)
-        outs.append((np.stack(firsts), frames.copy(), n.copy()))
-        eng.close()
-    assert np.array_equal(outs[0][0], outs[1][0])
-    assert np.array_equal(outs[0][2], outs[1][2])
-    assert np.array_equal(outs[0][1], outs[1][1])
 
 
 def test_batch32_wide_path_at_full_depth_vs_oracle_and_single_runs():

@@ -111,6 +111,19 @@ def test_s1_mini_codec_10s_utterance_vs_oracle():
     # per-second error stays flat (no drift along the utterance)
     for k in range(0, T * 2048 - 44100, 44100):
         assert rel_rms(got[0, k: k + 44100], want[0, 0, k: k + 44100].numpy()) <= 2 * REL_RMS_TOL, k
+    # Like for like: the reference runs its codec in bfloat16 on the accelerator (synthesizer.py:289-291), every
+    # parameter and activation rounded to bf16 - the oracle's bf16 mode restates that.  The HIP path keeps f32
+    # accumulators and an f32 residual stream, so it must sit (a) no farther from the bf16 oracle than the two oracle
+    # precisions sit from each other (x 1.25) and (b) closer to the f32 oracle than the bf16 oracle does: the 3e-2 bound
+    # above is then an f32-side bound that the reference's own bf16 arithmetic would not meet.
+    w = C.random_weights(shape, seed=0)
+    with torch.no_grad():
+        want16 = C.CodecOracle(shape, w, dtype=torch.bfloat16).decode(codes, torch.tensor([T]))[0][0, 0].float().numpy()
+    d_or = rel_rms(want16, want[0, 0].numpy())
+    d_g16 = rel_rms(got[0], want16)
+    print(f"215 frames: bf16 oracle vs f32 oracle {d_or:.4f}; GPU vs bf16 oracle {d_g16:.4f}; GPU vs f32 oracle {err:.4f}")
+    assert d_g16 <= 1.25 * d_or, (d_g16, d_or)
+    assert err <= d_or, (err, d_or)
     pre = eng.decode(codes.numpy()[:, :, :150])          # beyond the attention window, not a multiple of any tile
     assert np.array_equal(pre[0], got[0, : 150 * 2048])
     eng.close()

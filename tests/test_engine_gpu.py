@@ -111,34 +111,6 @@ def test_engine_other_depths_and_codebook_counts(monkeypatch, over):
     assert np.array_equal(ha.view(np.uint32), hb.view(np.uint32)), over
 
 
-def test_cut_beside_the_head_gemv_keeps_the_bits(monkeypatch):
-    """Opt-in FT_CUT_BESIDE: the vocabulary draw's histogram + cut kernel runs on a forked stream beside the head GEMV and
-    reads the logits behind the GEMV's per-chunk completion counters (written-through rows).  Measured slower than the serial
-    form, kept as an experiment: at the real vocabulary (155 776) its frames must equal the default's, sampled,
-    with penalties and the EOS ban in play."""
-    shape = s1mini_shape(max_seq_len=1024)
-    prompt = make_prompt(shape, 31, seed=2, n_vq=2).numpy()
-    kw = dict(temperature=0.7, top_p=0.8, repetition_penalty=1.3)
-    outs = []
-    for beside in (False, True):
-        monkeypatch.delenv("FT_NO_ENGINE", raising=False)
-        if beside:
-            monkeypatch.setenv("FT_CUT_BESIDE", "1")
-        else:
-            monkeypatch.delenv("FT_CUT_BESIDE", raising=False)
-        eng, _ = make_pair(shape, "bf16", max_new_tokens=40)
-        sp = eng._sampling(0.7, 0.8, 1.3, seed=3, ban_eos=True)
-        first = eng.prefill(prompt, sp, slot=0)
-        frames, n = eng.decode(24, [sp], poll=24)
-        logits, hidden = eng.debug_state()
-        outs.append((first, frames[0, : n[0]].copy(), logits.copy()))
-        eng.close()
-    assert np.array_equal(outs[0][0], outs[1][0])
-    assert np.array_equal(outs[0][1], outs[1][1])
-    assert np.array_equal(outs[0][2].view(np.uint32), outs[1][2].view(np.uint32))
-    del kw
-
-
 def test_engine_long_run_crosses_the_tag_wrap(monkeypatch):
     """Hand-off tags are 15 bits of an epoch that advances by 64 per launch (two launches per frame): they repeat every
     256 frames.  700 sampled frames (three wraps) on the engine must still equal the launch path's, frame for frame - a

@@ -99,7 +99,7 @@ def test_oracle_pinned_at_s1mini_shapes_by_reference_generated_frames():
     from tests.shapes import s1mini_shape
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ar_s1mini_tf.npz"))
     shape = s1mini_shape()
-    w = O.random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]))
+    w = O.random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]), loud=(int(g["loud_n"]), float(g["loud_factor"])))
     prompt = torch.from_numpy(g["prompt"])
     Lp, n = prompt.shape[1], int(g["n_new"])
     kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.0)
