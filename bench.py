@@ -16,7 +16,9 @@ collective); weights are broadcast once from rank 0 over RCCL.  Rank 0 prints on
 the GPU is never re-executed), relays rank 0's JSON line and exits with the launcher's code.
 
 `--config cfg4`: BASELINE configs[3] - every rank decodes 32 mixed-length utterances (prompts U[16,96], frame budgets
-U[108,430], SURVEY §8-d seed 3 + rank) with continuous batching on its 32 slots; value = all ranks' frames / wall.
+U[108,430], SURVEY §8-d seed 3 + rank) with continuous batching on its 32 slots; every finished utterance is decoded to
+audio by a worker thread on the codec's own stream while the others go on (the pipeline of synthesizer.py:483-584 across a
+batch), all of it inside the timed region; value = all ranks' frames / wall, rtf = wall / audio seconds.
 """
 import argparse
 import json
@@ -139,9 +141,15 @@ def cpu_baseline(args_dict, sd, prompt, tok, frames=32, codec_frames=N_FRAMES, t
     return out
 
 
-def mixed_batch(eng, tok, n_utt, seed, burst=8, reps=2):
+def mixed_batch(eng, tok, n_utt, seed, burst=8, reps=2, codec=None, info=None):
     """BASELINE configs[2]: n_utt utterances (prompts U[16,96], frame budgets U[108,430]) with continuous batching;
-    returns (frames, seconds) of the last of `reps` passes (the first pass warms the graphs of every batch width)."""
+    returns (frames, seconds) of the last of `reps` passes (the first pass warms the graphs of every batch width).
+    codec: every finished utterance's codes are decoded to audio by a worker thread (its own HIP stream) while the batch
+    goes on; the pass ends when the last waveform is there.  info: receives the pass's counters (lock-step frame steps,
+    cached positions read, audio samples)."""
+    import queue
+    import threading
+
     import numpy as np
     from fish_tts_amd.batch import Utterance, run_batch
     rng = np.random.default_rng(seed)
@@ -155,12 +163,58 @@ def mixed_batch(eng, tok, n_utt, seed, burst=8, reps=2):
     dt = 0.0
     for rep in range(reps):
         utts = [Utterance(prompt(int(l)), int(t), 0.7, 0.8, 1.1, seed=i, ban_eos=True) for i, (l, t) in enumerate(zip(lens, targets))]
+        q, err, samples = queue.Queue(), [], [0]
+        worker = None
+        if codec is not None:
+            def decode_worker():
+                try:
+                    while True:
+                        i = q.get()
+                        if i is None:
+                            return
+                        codes = utts[i].codes()
+                        if codes.shape[1]:
+                            samples[0] += codec.decode(codes[None]).shape[1]
+                except Exception as e:  # noqa: BLE001
+                    err.append(e)
+            worker = threading.Thread(target=decode_worker, daemon=True)
+            worker.start()
         eng.sync()
         t0 = time.perf_counter()
-        run_batch(eng, utts, burst=burst)
+        stats = run_batch(eng, utts, burst=burst, on_done=(q.put if codec is not None else None))
+        if worker is not None:
+            q.put(None)
+            worker.join()
+            if err:
+                raise err[0]
         dt = time.perf_counter() - t0
+        if info is not None:
+            info.update(stats)
+            # cached positions the frames of this pass read: frame f of an utterance attends over Lp + f positions
+            info["kv_positions"] = int(sum(sum(range(int(l), int(l) + u.columns().shape[1])) for l, u in zip(lens, utts)))
+            info["audio_samples"] = samples[0]
     made = sum(u.columns().shape[1] for u in utts)
     return made, dt
+
+
+def lockstep_probe(eng, tok, B, n_frames=128, prompt_len=48):
+    """B utterances of equal length decoded in lock step (no refill): (frames, seconds) of the decode loop alone."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    sps = [eng._sampling(0.7, 0.8, 1.1, seed=i, ban_eos=True) for i in range(B)]
+    prompts = []
+    for i in range(B):
+        p = np.zeros((11, prompt_len), dtype=np.int32)
+        p[0] = rng.integers(0, tok.n_ranks, prompt_len)
+        prompts.append(p)
+    dt = 0.0
+    for rep in range(2):                      # the first pass captures the graph of this width
+        eng.prefill_many(prompts, sps, 0)
+        eng.sync()
+        t0 = time.perf_counter()
+        _, n = eng.decode(n_frames, sps, poll=n_frames)
+        dt = time.perf_counter() - t0
+    return int(n.sum()), dt
 
 
 def main():
@@ -227,40 +281,61 @@ def main():
         ranks_seen = int(seen.item())
 
     if a.config == "cfg4":
+        from fish_tts_amd.codec_engine import CodecHipEngine
         margs = s1_mini_args(max_seq_len=4096)
         eng = ARHipEngine(margs, tok.semantic_begin_id, tok.semantic_end_id, im_end, precision="bf16", device=local_rank,
                           max_batch=32, max_new_tokens=512)
         eng.load_state_dict(sd)
-        made, dtm = 0, 0.0
+        codec = CodecHipEngine.synthetic(device=local_rank, max_frames=440)
+        made, steps_run, kv_pos, audio = 0, 0, 0, 0
         for i in range(max(a.warmup, 1)):     # at least one pass: it captures the graphs of every batch width
-            mixed_batch(eng, tok, 32, seed=1000 + rank, reps=1)
+            mixed_batch(eng, tok, 32, seed=1000 + rank, reps=1, codec=codec)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t_begin = time.perf_counter()
         for i in range(a.steps):
-            m, _ = mixed_batch(eng, tok, 32, seed=3 + rank + 100 * i, reps=1)
+            info = {}
+            m, _ = mixed_batch(eng, tok, 32, seed=3 + rank + 100 * i, reps=1, codec=codec, info=info)
             made += m
+            steps_run += info["frame_steps"]
+            kv_pos += info["kv_positions"]
+            audio += info["audio_samples"]
         eng.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t_begin
         if dist is not None:
-            t = torch.tensor([elapsed, float(made)], device="cuda", dtype=torch.float64)
+            t = torch.tensor([elapsed, float(made), float(steps_run), float(kv_pos), float(audio)], device="cuda", dtype=torch.float64)
             mx, sm = t.clone(), t.clone()
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-            elapsed, made = float(mx[0]), float(sm[1])
+            elapsed, made, steps_run, kv_pos, audio = float(mx[0]), float(sm[1]), float(sm[2]), float(sm[3]), float(sm[4])
         if rank == 0:
+            # roofline of the lock-step frame (the step's dominant chain): every frame step streams the 1.303 GB of weights
+            # once for all its slots, every slot frame reads its own cached positions; per GPU, over the timed region
+            # (prompt passes and codec decodes included in the time, not in the bytes)
+            fb = frame_bytes(margs)
+            nbytes = steps_run * fb["total"] + kv_pos * KV_BYTES_PER_POS
+            achieved = nbytes / world / elapsed / 1e9
+            audio_s = audio / 44100.0
             print(json.dumps({
                 "metric": "semantic tokens/sec", "value": round(made / elapsed, 2), "unit": "tokens/s", "n_gpus": ranks_seen,
                 "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": "openaudio-s1-mini shapes (BASELINE configs[3]): 32 mixed-length utterances per GPU "
-                                       "(prompts U[16,96], 108-430 frames), continuous batching on 32 lock-step slots, AR only",
-                           "parallelism": f"replica x{world}", "frames_total": int(made)},
-                "roofline": None, "cpu_baseline": None}))
+                                       "(prompts U[16,96], 108-430 frames), continuous batching on 32 lock-step slots, every "
+                                       "finished utterance decoded by the DAC codec on a second stream",
+                           "parallelism": f"replica x{world}", "frames_total": int(made), "audio_s": round(audio_s, 2)},
+                "rtf": round(elapsed / audio_s, 5) if audio_s > 0 else None,
+                "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                             "kernel": "lock-step decode frames (one pass over the weights per frame step for all slots + each slot's K/V), per GPU",
+                             "frame_steps": int(steps_run), "ms_per_frame_step": round(elapsed * world / max(steps_run, 1) * 1e3, 4)},
+                "cpu_baseline": None}))
+        codec.close()
+        eng.close()
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -332,7 +407,14 @@ def main():
         # counter runs (rocprofv3 --pmc, profiles/README.md) launch every frame eagerly; the profiler does not survive
         # a stream capture, and the roofline block measures the captured graph: leave it out of such a run
         print(json.dumps({"metric": "semantic tokens/sec", "value": round(frames_total / elapsed, 2), "unit": "tokens/s",
-                          "n_gpus": ranks_seen, "steps": a.steps, "warmup": a.warmup, "note": "FT_NO_GRAPH run: eager frames, no roofline block"}))
+                          "n_gpus": ranks_seen, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "openaudio-s1-mini shapes (BASELINE configs[1]), FT_NO_GRAPH: eager frames (counter runs)",
+                                     "frames_per_step": N_FRAMES, "prompt_len": PROMPT_LEN, "parallelism": f"replica x{world}"},
+                          "roofline": None, "cpu_baseline": None}))
+        if dist is not None:
+            dist.destroy_process_group()
         return
     eng.prefill(prompt, sp)
     NPF = 48
@@ -343,7 +425,9 @@ def main():
     frame_ms = ms_graph / NPF
     achieved = per_frame_bytes / (frame_ms * 1e-3) / 1e9
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if os.path.exists(tpath):  # HBM bytes per frame from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this bench (eager frames)
         traffic = json.load(open(tpath)).get("hbm_bytes_per_frame")
     parts = {}
@@ -356,8 +440,8 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernel": ("one decode frame = ft::slow_engine_kernel + vocabulary head gemv + semantic draw + ft::fast_engine_kernel"
                        if flags == 3 else "one decode frame (launch path: gemv / attention / sampler kernels)"),
-            "launches_per_frame": nodes, "bytes_per_launch": int(per_frame_bytes), "avg_us_per_launch": round(frame_ms * 1e3, 2),
-            "frame_ms": round(frame_ms, 4), "parts": parts}
+            "launches_per_frame": nodes, "bytes_per_frame": int(per_frame_bytes), "frame_us": round(frame_ms * 1e3, 2),
+            "frame_ms": round(frame_ms, 4), "frame_path": eng.frame_path(), "parts": parts}
     try:   # sub-field kept from round 1: the HBM-streamed GEMV launches of the launch path alone
         ms, launches, nbytes = eng.profile_gemv(20, sp)
         roof["gemv_launch_path"] = {"GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "launches": launches,
@@ -396,6 +480,10 @@ def main():
             out["configs"]["configs[2] batch=32 mixed lengths, continuous batching"] = {
                 "frames": int(made), "wall_s": round(dtm, 4), "tokens_per_s": round(made / dtm, 1),
                 "ar_rtf": round(dtm / (made * 2048 / 44100.0), 5)}
+            made, dtm = lockstep_probe(beng, tok, 32)
+            out["configs"]["lock-step B=32, 48-token prompts, 128 frames (decode loop alone)"] = {
+                "frames": int(made), "wall_s": round(dtm, 4), "tokens_per_s": round(made / dtm, 1),
+                "ms_per_lockstep_frame": round(dtm / 128 * 1e3, 4)}
             beng.close()
             out["configs"]["configs[4] voice cloning B=8 streamed"] = voice_cloning_probe(sd, tok, im_end, local_rank)
         except Exception as e:  # noqa: BLE001

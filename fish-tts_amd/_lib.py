@@ -68,6 +68,9 @@ SYMBOLS = {
     "ft_ar_get_debug": (C.c_int32, [_P, C.c_int32, _P, _P]),
     "ft_codec_decode": (C.c_int32, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     "ft_codec_frame_len": (C.c_int32, [_P]),
+    "ft_codec_stream_begin": (C.c_int32, [_P, C.POINTER(_P)]),
+    "ft_codec_stream_decode": (C.c_int32, [_P, _P, _P, C.c_int32, _P]),
+    "ft_codec_stream_end": (None, [_P, _P]),
     "ft_codec_encode": (C.c_int32, [_P, _P, C.c_int64, _P, _P]),
     "ft_codec_enc_frame_len": (C.c_int32, [_P]),
     "ft_codec_rvq_encode": (C.c_int32, [_P, _P, C.c_int32, _P]),

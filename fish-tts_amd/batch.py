@@ -39,9 +39,11 @@ class Utterance:
         return self.columns()[1:, :-1].copy()
 
 
-def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int = 8, on_frames=None) -> None:
+def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int = 8, on_frames=None, on_done=None) -> dict:
     """Fills `frames` of every utterance.  `burst` = frames per scheduling step (graph replays between host looks);
-    `on_frames(index, (R, k) block)` is called as blocks arrive (streaming consumers).
+    `on_frames(index, (R, k) block)` is called as blocks arrive (streaming consumers), `on_done(index)` when an
+    utterance has its last frame (a codec worker can decode it while the others go on).  Returns counters:
+    lock-step frame steps run and their summed widths.
 
     Scheduling: longest frame budget first (LPT), the longest into the lowest slots; the lock-step width of a burst is
     1 + the highest active slot, so that while the queue drains the batch narrows (cheaper frames) instead of
@@ -56,12 +58,18 @@ def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int =
     sps = [idle_sp] * B
     parked = [False] * B
 
+    stats = {"frame_steps": 0, "slot_frames": 0}
+
     def emit(i: int, block: np.ndarray):
         if block.shape[1] == 0:
             return
         utterances[i].frames.extend(block.T)            # rows of block.T are the (R,) columns
         if on_frames is not None:
             on_frames(i, block)
+
+    def done(i: int):
+        if on_done is not None:
+            on_done(i)
 
     def fill(slot: int) -> None:
         while waiting:
@@ -73,6 +81,7 @@ def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int =
             parked[slot] = False
             emit(i, first[:, None])
             if n_new <= 1 or first[0] == engine.im_end_id:
+                done(i)
                 continue                                  # finished at its first frame: the slot takes the next one
             owner[slot], budget[slot], sps[slot] = i, n_new - 1, sp
             return
@@ -92,6 +101,7 @@ def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int =
             n_new = engine._clamp_new(u.prompt.shape[1], u.max_new_tokens)
             emit(i, firsts[s][:, None])
             if n_new <= 1 or firsts[s][0] == engine.im_end_id:
+                done(i)
                 fill(s)                                   # done at its first frame: the slot takes the next one
             else:
                 owner[s], budget[s], sps[s] = i, n_new - 1, sp0[s]
@@ -107,6 +117,8 @@ def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int =
         width = active[-1] + 1                            # slots above the highest active one are left out
         k = min([burst] + [budget[s] for s in active])
         frames, n = engine.decode(k, sps[:width], poll=k)
+        stats["frame_steps"] += k
+        stats["slot_frames"] += k * width
         for s in active:
             i = owner[s]
             got = int(n[s])
@@ -114,4 +126,6 @@ def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int =
             budget[s] -= got
             ended = got < k or (got > 0 and frames[s, got - 1, 0] == engine.im_end_id)
             if ended or budget[s] <= 0:
+                done(i)
                 fill(s)
+    return stats

@@ -147,6 +147,10 @@ class CodecHipEngine:
                                                  codes.ctypes.data_as(C.c_void_p)), "ft_codec_rvq_encode")
         return codes
 
+    def stream(self) -> "CodecStream":
+        """A streamed decode with carried state: the chunks' waveforms concatenate to the waveform of one decode."""
+        return CodecStream(self)
+
     def decode(self, codes: np.ndarray, lens: Optional[np.ndarray] = None) -> np.ndarray:
         """codes (B, n_codebooks+1, T) or (n_codebooks+1, T) integer -> float32 (B, T*frame_len)."""
         codes = np.asarray(codes)
@@ -161,3 +165,38 @@ class CodecHipEngine:
                                              lens_a.ctypes.data_as(C.c_void_p), audio.ctypes.data_as(C.c_void_p)),
                     "ft_codec_decode")
         return audio
+
+
+class CodecStream:
+    """Successive chunks of ONE utterance's codes (fish_tts/synthesizer.py:513-528 decodes each chunk from zero state;
+    here the causal codec's context - the last 127 frames' K/V of every transformer layer, the last rows of every
+    convolution input - is carried)."""
+
+    def __init__(self, engine: CodecHipEngine):
+        self.engine = engine
+        self._h = C.c_void_p()
+        engine._check(engine.lib.ft_codec_stream_begin(engine._h, C.byref(self._h)), "ft_codec_stream_begin")
+        self.frames = 0
+
+    def decode(self, codes: np.ndarray) -> np.ndarray:
+        """codes (n_codebooks+1, T) integer -> float32 (T * frame_len,): the next T frames of the stream."""
+        e = self.engine
+        codes = np.ascontiguousarray(np.asarray(codes), dtype=np.int32)
+        assert codes.ndim == 2 and codes.shape[0] == e.R, codes.shape
+        T = codes.shape[1]
+        audio = np.empty(T * e.frame_len, dtype=np.float32)
+        e._check(e.lib.ft_codec_stream_decode(e._h, self._h, codes.ctypes.data_as(C.c_void_p), T,
+                                              audio.ctypes.data_as(C.c_void_p)), "ft_codec_stream_decode")
+        self.frames += T
+        return audio
+
+    def close(self) -> None:
+        if self._h:
+            self.engine.lib.ft_codec_stream_end(self.engine._h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -44,7 +44,7 @@ struct CodecState {
     float *x = nullptr, *audio = nullptr;
     bf16_t *xn = nullptr, *qkv = nullptr, *y = nullptr, *g = nullptr;
     bf16_t* big[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t big_elems = 0;
+    size_t big_elems = 0, big_margin = 0;
     int frame_len = 0, up_total = 1;
     // ---- encode side
     struct EncUnit { float *a0, *a2; ConvW c7, c1; };
@@ -493,11 +493,17 @@ ft_status codec_finalize(ft_ctx* ctx) {
     const size_t T = c.max_frames;
     per_frame_max = std::max(per_frame_max, (size_t)s->up_total * 4 * D);  // ConvNeXt hidden
     s->big_elems = T * per_frame_max;
-    for (int i = 0; i < 4; ++i) FT_TRY(cmalloc(ctx, &s->big[i], s->big_elems));
+    // 64 rows of the widest conv input in FRONT of every buffer: a streamed decode puts the previous chunk's last rows there
+    // (the largest halo is 54 rows: k = 7, dilation 9)
+    s->big_margin = (size_t)64 * std::max(c.decoder_dim, D);
+    for (int i = 0; i < 4; ++i) {
+        FT_TRY(cmalloc(ctx, &s->big[i], s->big_elems + s->big_margin));
+        s->big[i] += s->big_margin;
+    }
     FT_TRY(cmalloc(ctx, &s->codes, (size_t)(c.n_codebooks + 1) * T));
     FT_TRY(cmalloc(ctx, &s->x, T * D));
     FT_TRY(cmalloc(ctx, &s->xn, T * D));
-    FT_TRY(cmalloc(ctx, &s->qkv, T * 3 * H));
+    FT_TRY(cmalloc(ctx, &s->qkv, (T + (size_t)c.tf_window) * 3 * H));   // (+ window - 1 rows of carried K/V in a streamed decode)
     FT_TRY(cmalloc(ctx, &s->y, T * H));
     FT_TRY(cmalloc(ctx, &s->g, T * c.tf_ffn));
     FT_TRY(cmalloc(ctx, &s->audio, T * s->frame_len));
@@ -512,6 +518,9 @@ struct GemmIO {
     const float* gamma = nullptr; const float* resid_f32 = nullptr; const bf16_t* resid_bf = nullptr; long ldr = 0;
     float* out_f32 = nullptr; bf16_t* out_bf = nullptr; bf16_t* out_act = nullptr; const float* alpha = nullptr;
     long ldo = 0; int act = ACT_NONE;
+    long msel = 0;     // rows the kernel VARIANT is chosen for (0 = M): a streamed decode picks, for every chunk length, the variant
+                       // a whole utterance of nominal length takes, so that its results do not depend on the chunking
+    int t_min = 0;     // TapGemmP::t_min
 };
 
 static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
@@ -520,7 +529,8 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
     for (int i = 0; i < w.ntap; ++i) p.offs[i] = w.offs[i];
     p.M = io.M; p.N = w.N; p.K = w.K; p.bias = w.bias; p.n_mod = w.n_mod; p.act = io.act; p.gamma = io.gamma;
     p.resid_f32 = io.resid_f32; p.resid_bf = io.resid_bf; p.ldr = io.ldr; p.out_f32 = io.out_f32; p.out_bf = io.out_bf;
-    p.out_act = io.out_act; p.alpha = io.alpha; p.ldo = io.ldo;
+    p.out_act = io.out_act; p.alpha = io.alpha; p.ldo = io.ldo; p.t_min = io.t_min;
+    const long Msel = io.msel > 0 ? io.msel : io.M;
     int halo = 0;
     for (int i = 0; i < w.ntap; ++i) halo = std::max(halo, -w.offs[i]);
     // few rows (the 215-frame transformers, the first up-sampling stage): a 64x64 tile grid leaves most CUs idle and every
@@ -529,7 +539,7 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
     // (measured per GEMM at 215 / 430 / 860 rows: N = 1024 skinny 8-13 us against 21-75 us; N = 3072 equal; N >= 4096
     // the tile kernel wins, 23 against 35 us: its grid is already >= 256 blocks there)
     constexpr long skinny_m = 1024, skinny_n = 2048;
-    if (w.ntap == 1 && w.offs[0] == 0 && io.M <= skinny_m && w.N <= skinny_n && io.T_in >= io.M && w.K % 128 == 0 && w.N % 2 == 0 &&
+    if (w.ntap == 1 && w.offs[0] == 0 && Msel <= skinny_m && w.N <= skinny_n && io.T_in >= io.M && w.K % 128 == 0 && w.N % 2 == 0 &&
         (io.act == ACT_NONE || io.act == ACT_SWIGLU || io.act == ACT_GELU) && !io.out_act) {
         p.ldw = 0;
         skinny_gemm_launch<4>(p, (io.M + 63) / 64, st);
@@ -557,11 +567,11 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
                                                       64 * NWM_ * NWN_, lds8_, st>>>(p);                          \
     } while (0)
         constexpr long tile8_m = 4096, wide_m = 30000;
-        if (vec_ok && io.M >= tile8_m && (w.N % 128 == 0 || w.N % 96 == 0)) {
+        if (vec_ok && Msel >= tile8_m && (w.N % 128 == 0 || w.N % 96 == 0)) {
             // full-width tiles where the whole N fits one block column (A read once): 128 x 192 (N = 192, 384), 256 x 96 (N = 96)
             // (256 x 128 x 32 on 8 waves was measured slower: 4.76 against 4.57 ms per 215-frame decode)
-            if (io.M >= wide_m && w.N % 192 == 0) { FT_TG8(128, 192, 32, 2, 4); return; }
-            if (io.M >= wide_m && w.N == 96) { FT_TG8(256, 96, 32, 4, 2); return; }
+            if (Msel >= wide_m && w.N % 192 == 0) { FT_TG8(128, 192, 32, 2, 4); return; }
+            if (Msel >= wide_m && w.N == 96) { FT_TG8(256, 96, 32, 4, 2); return; }
             if (w.N % 128 == 0) { if (k64) FT_TG8(128, 128, 64, 2, 4); else FT_TG8(128, 128, 32, 2, 4); }
             else { if (k64) FT_TG8(128, 96, 64, 4, 2); else FT_TG8(128, 96, 32, 4, 2); }
             return;
@@ -584,11 +594,42 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
     }
 }
 
-static ft_status decode_one(ft_ctx* ctx, const int32_t* codes_host, int Tfull, int T, float* audio_host) {
+// ---- streamed decode state (ft_codec_stream_*): what the causal codec needs from earlier chunks, two copies of each
+// (a chunk reads one and leaves the other).  The codec is strictly causal: the window-128 attention reads the K / V of
+// the 127 frames before a chunk (vocoder.py:325-332), every causal convolution the last `halo` rows of its input
+// (vocoder.py:411-420, 449-455); with those carried, a chunk's samples are the whole decode's samples, bit for bit.
+constexpr int STREAM_NOMINAL_FRAMES = 215;      // kernel variants are those of a 10 s utterance whatever the chunk length
+struct ft_codec_stream {
+    int t0 = 0;           // frames decoded so far (rope position of the next chunk's first frame)
+    int par = 0;          // which copy is current
+    std::vector<bf16_t*> kv[2];                    // per transformer layer: [window - 1][2 * H * hd], newest rows last
+    struct Tail { bf16_t* buf[2]; int H, C; };
+    std::vector<Tail> tails;                       // in the order decode_one consumes them
+    std::vector<void*> owned;
+};
+
+static int halo_of(const ConvW& w) {
+    int h = 0;
+    for (int i = 0; i < w.ntap; ++i) h = std::max(h, -w.offs[i]);
+    return h;
+}
+
+static ft_status decode_one(ft_ctx* ctx, const int32_t* codes_host, int Tfull, int T, float* audio_host, ft_codec_stream* sc = nullptr) {
     const ft_codec_config& c = ctx->cc;
     CodecState* s = ctx->codec;
     hipStream_t st = s->stream;
     const int D = c.latent_dim, H = c.tf_n_head, hd = c.tf_head_dim, HD = H * hd, R = c.n_codebooks + 1;
+    const long Tn = sc ? STREAM_NOMINAL_FRAMES : 0;           // msel = Tn x rows per frame of the stage (0: by the real row count)
+    const int W1 = c.tf_window - 1;
+    const int nh = sc ? std::min(sc->t0, W1) : 0;             // carried K/V rows in front of the chunk's
+    size_t ti = 0;                                            // next tail of sc->tails
+    // the carried rows of x's earlier chunks in front of x (rows [-H, 0)), and the carry for the next chunk
+    auto roll = [&](bf16_t* x, int rows, int Hh, int C) {
+        if (!sc || Hh == 0) return 0;
+        ft_codec_stream::Tail& tl = sc->tails[ti++];
+        tail_roll_kernel<<<gridfor((long)Hh * C / 8), 256, 0, st>>>(x, tl.buf[sc->par], tl.buf[sc->par ^ 1], rows, Hh, C);
+        return -Hh;
+    };
     // codes of this item, compacted to [R][T]
     std::vector<int> hc((size_t)R * T);
     for (int r = 0; r < R; ++r) memcpy(&hc[(size_t)r * T], codes_host + (size_t)r * Tfull, T * sizeof(int));
@@ -596,52 +637,144 @@ static ft_status decode_one(ft_ctx* ctx, const int32_t* codes_host, int Tfull, i
     RvqP rq{s->codes, s->tables, c.n_codebooks, c.semantic_codebook_size, c.codebook_size, D, T, s->x};
     rvq_gather_kernel<<<dim3(T, 1), 256, 0, st>>>(rq);
     // post transformer (vocoder.py:338-354): residual stream f32, GEMM operands bf16
+    bf16_t* qkv_c = s->qkv + (size_t)nh * 3 * HD;             // this chunk's rows of the q k v work buffer
     for (int l = 0; l < c.n_tf_layer; ++l) {
         const TfLayer& t = s->tf[l];
         rmsnorm_rows_kernel<<<T, 256, 0, st>>>(RowNormP{s->x, t.n1, c.tf_norm_eps, D, s->xn, nullptr});
-        { GemmIO io{s->xn, D, T, T}; io.out_bf = s->qkv; io.ldo = 3 * HD; gemm(st, t.qkv, io); }
-        rope_qk_kernel<<<gridfor((long)T * 2 * H * (hd / 2)), 256, 0, st>>>(s->qkv, s->rope, T, H, hd);
-        window_attn_kernel<<<(T * H + 3) / 4, 256, 0, st>>>(WinAttnP{s->qkv, s->y, T, H, hd, c.tf_window, 1.0f / sqrtf((float)hd)});
-        { GemmIO io{s->y, HD, T, T}; io.gamma = t.g1; io.resid_f32 = s->x; io.ldr = D; io.out_f32 = s->x; io.ldo = D; gemm(st, t.wo, io); }
+        { GemmIO io{s->xn, D, T, T}; io.out_bf = qkv_c; io.ldo = 3 * HD; io.msel = Tn; gemm(st, t.qkv, io); }
+        rope_qk_kernel<<<gridfor((long)T * 2 * H * (hd / 2)), 256, 0, st>>>(qkv_c, s->rope, T, H, hd, sc ? sc->t0 : 0);
+        if (sc) {
+            if (nh > 0) kv_carry_in_kernel<<<gridfor((long)nh * 2 * HD / 8), 256, 0, st>>>(s->qkv, sc->kv[sc->par][l], nh, W1, HD);
+            const int nh2 = std::min(W1, nh + T);
+            if (nh2 > 0) kv_carry_out_kernel<<<gridfor((long)nh2 * 2 * HD / 8), 256, 0, st>>>(s->qkv, sc->kv[sc->par ^ 1][l], nh + T, nh2, W1, HD);
+        }
+        window_attn_kernel<<<(T * H + 3) / 4, 256, 0, st>>>(WinAttnP{s->qkv, s->y, nh + T, H, hd, c.tf_window, 1.0f / sqrtf((float)hd), nh});
+        { GemmIO io{s->y, HD, T, T}; io.gamma = t.g1; io.resid_f32 = s->x; io.ldr = D; io.out_f32 = s->x; io.ldo = D; io.msel = Tn; gemm(st, t.wo, io); }
         rmsnorm_rows_kernel<<<T, 256, 0, st>>>(RowNormP{s->x, t.n2, c.tf_norm_eps, D, s->xn, nullptr});
-        { GemmIO io{s->xn, D, T, T}; io.act = ACT_SWIGLU; io.out_bf = s->g; io.ldo = c.tf_ffn; gemm(st, t.w13, io); }
-        { GemmIO io{s->g, c.tf_ffn, T, T}; io.gamma = t.g2; io.resid_f32 = s->x; io.ldr = D; io.out_f32 = s->x; io.ldo = D; gemm(st, t.w2, io); }
+        { GemmIO io{s->xn, D, T, T}; io.act = ACT_SWIGLU; io.out_bf = s->g; io.ldo = c.tf_ffn; io.msel = Tn; gemm(st, t.w13, io); }
+        { GemmIO io{s->g, c.tf_ffn, T, T}; io.gamma = t.g2; io.resid_f32 = s->x; io.ldr = D; io.out_f32 = s->x; io.ldo = D; io.msel = Tn; gemm(st, t.w2, io); }
     }
     bf16_t *z = s->big[0], *u = s->big[1], *n = s->big[2], *h = s->big[3];
     rmsnorm_rows_kernel<<<T, 256, 0, st>>>(RowNormP{s->x, s->tf_norm, c.tf_norm_eps, D, z, nullptr});
     int Tc = T;
+    long Tnc = Tn;                                            // nominal rows at the current rate
     for (const UpStage& us : s->up) {  // vocoder.py:737-748: convT k=s=2, then ConvNeXt
-        { GemmIO io{z, D, Tc, Tc}; io.out_bf = u; io.ldo = us.ct.N; gemm(st, us.ct, io); }
+        { GemmIO io{z, D, Tc, Tc}; io.out_bf = u; io.ldo = us.ct.N; io.msel = Tnc; gemm(st, us.ct, io); }
         Tc *= us.f;
-        dwconv_ln_kernel<<<Tc, 256, D * sizeof(float), st>>>(DwLnP{u, us.dw_w, us.dw_b, us.ln_w, us.ln_b, Tc, D, n});
-        { GemmIO io{n, D, Tc, Tc}; io.act = ACT_GELU; io.out_bf = h; io.ldo = 4 * D; gemm(st, us.pw1, io); }
-        { GemmIO io{h, 4 * D, Tc, Tc}; io.gamma = us.gamma; io.resid_bf = u; io.ldr = D; io.out_bf = z; io.ldo = D; gemm(st, us.pw2, io); }
+        Tnc *= us.f;
+        const int tm = roll(u, Tc, 6, D);                     // depthwise causal k = 7
+        dwconv_ln_kernel<<<Tc, 256, D * sizeof(float), st>>>(DwLnP{u, us.dw_w, us.dw_b, us.ln_w, us.ln_b, Tc, D, n, tm});
+        { GemmIO io{n, D, Tc, Tc}; io.act = ACT_GELU; io.out_bf = h; io.ldo = 4 * D; io.msel = Tnc; gemm(st, us.pw1, io); }
+        { GemmIO io{h, 4 * D, Tc, Tc}; io.gamma = us.gamma; io.resid_bf = u; io.ldr = D; io.out_bf = z; io.ldo = D; io.msel = Tnc; gemm(st, us.pw2, io); }
     }
     // decoder (vocoder.py:605-640).  Buffers: a = snake'd input of the next conv, r = raw residual
     bf16_t *a = u, *r = n, *hs = h, *a2 = z;
-    { GemmIO io{z, D, Tc, Tc}; io.out_act = a; io.alpha = s->blocks[0].a0; io.ldo = c.decoder_dim; gemm(st, s->conv_in, io); }
+    { GemmIO io{z, D, Tc, Tc}; io.out_act = a; io.alpha = s->blocks[0].a0; io.ldo = c.decoder_dim; io.msel = Tnc;
+      io.t_min = roll(z, Tc, halo_of(s->conv_in), D); gemm(st, s->conv_in, io); }
     // note: conv_in reads z and writes a (= big[1]); z (= big[0]) is free afterwards
     for (size_t bi = 0; bi < s->blocks.size(); ++bi) {
         const DecBlock& b = s->blocks[bi];
         // transposed conv: raw -> r, snake'd by unit 0 -> a2
-        { GemmIO io{a, b.cin, Tc, Tc}; io.out_bf = r; io.out_act = a2; io.alpha = b.u[0].a0; io.ldo = b.ct.N; gemm(st, b.ct, io); }
+        { GemmIO io{a, b.cin, Tc, Tc}; io.out_bf = r; io.out_act = a2; io.alpha = b.u[0].a0; io.ldo = b.ct.N; io.msel = Tnc;
+          io.t_min = roll(a, Tc, halo_of(b.ct), b.cin); gemm(st, b.ct, io); }
         Tc *= b.s;
+        Tnc *= b.s;
         for (int ui = 0; ui < 3; ++ui) {
             const ResUnitW& ru = b.u[ui];
-            { GemmIO io{a2, b.cout, Tc, Tc}; io.out_act = hs; io.alpha = ru.a2; io.ldo = b.cout; gemm(st, ru.c7, io); }
+            { GemmIO io{a2, b.cout, Tc, Tc}; io.out_act = hs; io.alpha = ru.a2; io.ldo = b.cout; io.msel = Tnc;
+              io.t_min = roll(a2, Tc, halo_of(ru.c7), b.cout); gemm(st, ru.c7, io); }
             const float* next_alpha = ui < 2 ? b.u[ui + 1].a0 : (bi + 1 < s->blocks.size() ? s->blocks[bi + 1].a0 : s->a_last);
             bf16_t* act_dst = ui < 2 ? a2 : a;  // the last unit feeds the next block's transposed conv / the output conv
             { GemmIO io{hs, b.cout, Tc, Tc}; io.resid_bf = r; io.ldr = b.cout; io.out_bf = ui < 2 ? r : nullptr;
-              io.out_act = act_dst; io.alpha = next_alpha; io.ldo = b.cout; gemm(st, ru.c1, io); }
+              io.out_act = act_dst; io.alpha = next_alpha; io.ldo = b.cout; io.msel = Tnc; gemm(st, ru.c1, io); }
         }
     }
-    FinalConvP fp{a, s->w_last, s->b_last, Tc, s->c_last, s->audio};
+    FinalConvP fp{a, s->w_last, s->b_last, Tc, s->c_last, s->audio, roll(a, Tc, 6, s->c_last)};
     final_conv_tanh_kernel<<<2048, 256, 0, st>>>(fp);
     FT_HIP(ctx, hipMemcpyAsync(audio_host, s->audio, (size_t)Tc * sizeof(float), hipMemcpyDeviceToHost, st));
     FT_HIP(ctx, hipStreamSynchronize(st));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("codec launch: ") + hipGetErrorString(e));
+    if (sc) {
+        if (ti != sc->tails.size()) return ft_fail(ctx, FT_ERR_STATE, "codec stream: carry bookkeeping out of step");
+        sc->t0 += T;
+        sc->par ^= 1;
+    }
     return FT_OK;
+}
+
+// Streamed decode (second half): successive chunks of one utterance's codes, each decoded with
+// the context its predecessors left.  The reference decodes every chunk from zero state (synthesizer.py:513-528,
+// 591-595: audible restarts at chunk borders); carrying the state is exact because the codec is causal.
+extern "C" ft_status ft_codec_stream_begin(ft_ctx* ctx, ft_codec_stream** out) {
+    if (!ctx || !out) return FT_ERR_ARG;
+    if (!ctx->has_codec || !ctx->codec) return ft_fail(ctx, FT_ERR_STATE, "Vocoder not loaded");
+    if (!ctx->finalized) return ft_fail(ctx, FT_ERR_STATE, "weights not finalized (ft_finalize_weights)");
+    const ft_codec_config& c = ctx->cc;
+    CodecState* s = ctx->codec;
+    FT_HIP(ctx, hipSetDevice(ctx->device));
+    ft_codec_stream* sc = new ft_codec_stream();
+    auto zalloc = [&](bf16_t** q, size_t n) -> bool {
+        void* v = nullptr;
+        if (hipMalloc(&v, n * sizeof(bf16_t) + 64) != hipSuccess) return false;
+        sc->owned.push_back(v);
+        if (hipMemset(v, 0, n * sizeof(bf16_t) + 64) != hipSuccess) return false;
+        *q = (bf16_t*)v;
+        return true;
+    };
+    bool ok = true;
+    const int HD = c.tf_n_head * c.tf_head_dim, W1 = std::max(c.tf_window - 1, 1);
+    for (int k = 0; k < 2 && ok; ++k) {
+        sc->kv[k].resize(c.n_tf_layer);
+        for (int l = 0; l < c.n_tf_layer && ok; ++l) ok = zalloc(&sc->kv[k][l], (size_t)W1 * 2 * HD);
+    }
+    auto tail = [&](int Hh, int C) {
+        if (Hh == 0 || !ok) return;
+        ft_codec_stream::Tail t{{nullptr, nullptr}, Hh, C};
+        ok = zalloc(&t.buf[0], (size_t)Hh * C) && zalloc(&t.buf[1], (size_t)Hh * C);
+        sc->tails.push_back(t);
+    };
+    // the order decode_one consumes them in
+    for (size_t j = 0; j < s->up.size(); ++j) tail(6, c.latent_dim);
+    tail(halo_of(s->conv_in), c.latent_dim);
+    for (const DecBlock& b : s->blocks) {
+        tail(halo_of(b.ct), b.cin);
+        for (int ui = 0; ui < 3; ++ui) tail(halo_of(b.u[ui].c7), b.cout);
+    }
+    tail(6, s->c_last);
+    for (const auto& t : sc->tails) ok = ok && (size_t)t.H * t.C <= s->big_margin && t.C % 8 == 0;
+    if (!ok) {
+        for (void* v : sc->owned) hipFree(v);
+        delete sc;
+        (void)hipGetLastError();
+        return ft_fail(ctx, FT_ERR_NOMEM, "ft_codec_stream_begin: could not set up the carried state");
+    }
+    *out = sc;
+    return FT_OK;
+}
+
+extern "C" ft_status ft_codec_stream_decode(ft_ctx* ctx, ft_codec_stream* sc, const int32_t* codes, int32_t T, float* audio) {
+    if (!ctx || !sc) return FT_ERR_ARG;
+    if (!ctx->has_codec || !ctx->codec) return ft_fail(ctx, FT_ERR_STATE, "Vocoder not loaded");
+    if (!codes || !audio || T < 1) return ft_fail(ctx, FT_ERR_ARG, "ft_codec_stream_decode: bad argument");
+    const ft_codec_config& c = ctx->cc;
+    if (T > c.max_frames) return ft_fail(ctx, FT_ERR_TOO_LONG, "ft_codec_stream_decode: chunk longer than max_frames");
+    if (sc->t0 + T > c.max_frames) return ft_fail(ctx, FT_ERR_TOO_LONG, "ft_codec_stream_decode: stream longer than max_frames (rope table)");
+    CodecState* s = ctx->codec;
+    std::lock_guard<std::mutex> lock(s->mu);
+    FT_HIP(ctx, hipSetDevice(ctx->device));
+    return decode_one(ctx, codes, T, T, audio, sc);
+}
+
+extern "C" void ft_codec_stream_end(ft_ctx* ctx, ft_codec_stream* sc) {
+    if (!sc) return;
+    if (ctx && ctx->codec) {
+        std::lock_guard<std::mutex> lock(ctx->codec->mu);
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->codec->stream);
+        for (void* v : sc->owned) hipFree(v);
+    }
+    delete sc;
 }
 
 extern "C" ft_status ft_codec_decode(ft_ctx* ctx, const int32_t* codes, int32_t B, int32_t T, const int32_t* lens,

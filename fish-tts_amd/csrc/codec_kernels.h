@@ -21,6 +21,8 @@ struct TapGemmP {
     const bf16_t* X;      // [B][T_in][ldx]
     long ldx, x_bstride;
     int T_in;
+    int t_min;            // lowest readable row of X (0; negative in a streamed decode: rows [t_min, 0) hold the previous
+                          // chunk's last rows instead of the causal zero padding)
     const bf16_t* W;      // [ntap][N][K]
     int ntap;
     int offs[8];
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(TapGemmP p) {
                 const int r = c >> 2, q = c & 3;
                 const int t = m0 + r + off;
                 U4 v = U4{0u, 0u, 0u, 0u};
-                if (m0 + r < p.M && t >= 0 && t < p.T_in)
+                if (m0 + r < p.M && t >= p.t_min && t < p.T_in)
                     v = *reinterpret_cast<const U4*>(X + (size_t)t * p.ldx + k0 + q * 8);
                 *reinterpret_cast<U4*>(&As[r * LDS_LD + q * 8]) = v;
             }
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void tapgemm64_kernel(TapGemmP p) {
         for (int u = 0; u < ACH; ++u) {
             const int c = tid + NTHR * u, r = c / QPR, q = c % QPR;
             const int t = m0 + offmin + r;
-            areg[u] = (c < srows * QPR && t >= 0 && t < p.T_in)
+            areg[u] = (c < srows * QPR && t >= p.t_min && t < p.T_in)
                           ? *reinterpret_cast<const U4*>(X + (size_t)t * p.ldx + kc * BK + q * 8) : U4{0u, 0u, 0u, 0u};
         }
     };
@@ -839,7 +841,7 @@ static __global__ __launch_bounds__(256) void rmsnorm_rows_kernel(RowNormP p) {
 }
 
 // ---- RoPE on the q and k thirds of a [T][3*H*hd] bf16 buffer, in place (vocoder.py:145-156)
-static __global__ void rope_qk_kernel(bf16_t* qkv, const float* tab, int T, int H, int hd) {
+static __global__ void rope_qk_kernel(bf16_t* qkv, const float* tab, int T, int H, int hd, int pos0 = 0) {
     const int hp = hd >> 1;
     const long n = (long)T * 2 * H * hp;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -848,7 +850,7 @@ static __global__ void rope_qk_kernel(bf16_t* qkv, const float* tab, int T, int 
         const int t = (int)(i / ((long)hp * 2 * H));
         bf16_t* v = qkv + (size_t)t * 3 * H * hd + (size_t)h * hd + 2 * pr;
         const float x0 = bf16_bits_to_f32(v[0]), x1 = bf16_bits_to_f32(v[1]);
-        const float c = tab[((size_t)t * hp + pr) * 2], s = tab[((size_t)t * hp + pr) * 2 + 1];
+        const float c = tab[((size_t)(t + pos0) * hp + pr) * 2], s = tab[((size_t)(t + pos0) * hp + pr) * 2 + 1];
         v[0] = f32_to_bf16_bits(x0 * c - x1 * s);
         v[1] = f32_to_bf16_bits(x1 * c + x0 * s);
     }
@@ -861,14 +863,15 @@ struct WinAttnP {
     bf16_t* y;          // [T][H*hd]
     int T, H, hd, window;
     float scale;
+    int t0;             // first query row (0; streamed decode: rows [0, t0) are the carried K/V of earlier chunks); y row = t - t0
 };
 static __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnP p) {
     __shared__ float q_s[4][128];
     __shared__ float p_s[4][512];   // window <= 512 (the encoder's transformer, vocoder.py:516)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + wave;
-    if (item >= (long)p.T * p.H) return;
-    const int t = (int)(item / p.H), h = (int)(item % p.H);
+    if (item >= (long)(p.T - p.t0) * p.H) return;
+    const int t = p.t0 + (int)(item / p.H), h = (int)(item % p.H);
     const int hd = p.hd, ld = 3 * p.H * hd;
     const bf16_t* q = p.qkv + (size_t)t * ld + (size_t)h * hd;
     for (int d = lane; d < hd; d += 64) q_s[wave][d] = bf16_bits_to_f32(q[d]);
@@ -902,7 +905,7 @@ static __global__ __launch_bounds__(256) void window_attn_kernel(WinAttnP p) {
         float o = 0.f;
         for (int jj = 0; jj < nk; ++jj)
             o = fmaf(p_s[wave][jj], bf16_bits_to_f32(p.qkv[(size_t)(j0 + jj) * ld + (size_t)(2 * p.H + h) * hd + d]), o);
-        p.y[(size_t)t * p.H * hd + (size_t)h * hd + d] = f32_to_bf16_bits(o / sum);
+        p.y[(size_t)(t - p.t0) * p.H * hd + (size_t)h * hd + d] = f32_to_bf16_bits(o / sum);
     }
 }
 
@@ -915,6 +918,7 @@ struct DwLnP {
     const float* lb;
     int T, C;
     bf16_t* out;       // [T][C]
+    int t_min;         // lowest readable row of x (as TapGemmP::t_min)
 };
 static __global__ __launch_bounds__(256) void dwconv_ln_kernel(DwLnP p) {
     __shared__ float red[8];
@@ -926,7 +930,7 @@ static __global__ __launch_bounds__(256) void dwconv_ln_kernel(DwLnP p) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int tt = t - 6 + k;
-            if (tt >= 0) a = fmaf(p.w[c * 7 + k], bf16_bits_to_f32(p.x[(size_t)tt * p.C + c]), a);
+            if (tt >= p.t_min) a = fmaf(p.w[c * 7 + k], bf16_bits_to_f32(p.x[(long)tt * p.C + c]), a);
         }
         ybuf[c] = a;
         s1 += a;
@@ -953,6 +957,7 @@ struct FinalConvP {
     float bias;
     int T, C;
     float* audio;      // [T]
+    int t_min;         // lowest readable row of xs (as TapGemmP::t_min)
 };
 static __global__ __launch_bounds__(256) void final_conv_tanh_kernel(FinalConvP p) {
     // 16 lanes per output sample, 16 samples per block step.  C % 8 == 0 and C <= 128: lane `sub` owns channels
@@ -971,7 +976,7 @@ static __global__ __launch_bounds__(256) void final_conv_tanh_kernel(FinalConvP 
 #pragma unroll
             for (int k = 0; k < 7; ++k) {
                 const long tt = t - 6 + k;
-                x[k] = (on && tt >= 0) ? *reinterpret_cast<const U4*>(p.xs + (size_t)tt * p.C + sub * 8) : U4{0u, 0u, 0u, 0u};
+                x[k] = (on && tt >= p.t_min) ? *reinterpret_cast<const U4*>(p.xs + tt * p.C + sub * 8) : U4{0u, 0u, 0u, 0u};
             }
             float a = 0.f;
 #pragma unroll
@@ -990,8 +995,8 @@ static __global__ __launch_bounds__(256) void final_conv_tanh_kernel(FinalConvP 
         float a = 0.f;
         for (int k = 0; k < 7; ++k) {
             const long tt = t - 6 + k;
-            if (tt < 0) continue;
-            for (int c = sub; c < p.C; c += 16) a = fmaf(p.w[k * p.C + c], bf16_bits_to_f32(p.xs[(size_t)tt * p.C + c]), a);
+            if (tt < p.t_min) continue;
+            for (int c = sub; c < p.C; c += 16) a = fmaf(p.w[k * p.C + c], bf16_bits_to_f32(p.xs[tt * p.C + c]), a);
         }
         a = row16_sum(a);
         if (sub == 0) p.audio[t] = tanhf(a + p.bias);
@@ -1165,6 +1170,45 @@ static __global__ void snake_rows_kernel(const float* x, const float* alpha, bf1
     const long n = T * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         out[i] = f32_to_bf16_bits(snake_f(x[i], alpha[i % C]));
+}
+
+// ---- streamed decode: carried context (ft_codec_stream_*)
+// A causal convolution of halo H reads rows [-H, 0) of its input: the last H rows of the input of all earlier chunks.
+// tail_roll_kernel (a) copies the carried rows in front of the chunk (x[-H .. 0)) and (b) leaves the carry of the NEXT chunk:
+// the last H rows of (carried rows ++ this chunk's T rows).  16-byte pieces; C % 8 == 0.
+static __global__ void tail_roll_kernel(bf16_t* x, const bf16_t* tail_in, bf16_t* tail_out, int T, int H, int C) {
+    const int per = C / 8;
+    const long n = (long)H * per;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / per), q = (int)(i % per);
+        const U4 old = *reinterpret_cast<const U4*>(tail_in + (size_t)r * C + q * 8);
+        *reinterpret_cast<U4*>(x + ((long)r - H) * C + q * 8) = old;
+        const int src = r + T - H;          // row of the chunk that becomes carried row r (negative: still a carried row)
+        const U4 nv = src >= 0 ? *reinterpret_cast<const U4*>(x + (long)src * C + q * 8)
+                               : *reinterpret_cast<const U4*>(tail_in + (size_t)(r + T) * C + q * 8);
+        *reinterpret_cast<U4*>(tail_out + (size_t)r * C + q * 8) = nv;
+    }
+}
+// The K and V of the last nh rows before a chunk (window attention): kv_in [W1][2 * HD] -> rows [0, nh) of the qkv work
+// buffer (its k and v thirds; carried rows sit at the END of kv_in), and the carry of the next chunk from rows
+// [nh + T - nh2, nh + T) of the work buffer.  Two launches (the second reads what the GEMM wrote after the first).
+static __global__ void kv_carry_in_kernel(bf16_t* qkv, const bf16_t* kv_in, int nh, int W1, int HD) {
+    const int per = 2 * HD / 8;
+    const long n = (long)nh * per;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / per), q = (int)(i % per);
+        *reinterpret_cast<U4*>(qkv + (size_t)r * 3 * HD + HD + q * 8) =
+            *reinterpret_cast<const U4*>(kv_in + (size_t)(W1 - nh + r) * 2 * HD + q * 8);
+    }
+}
+static __global__ void kv_carry_out_kernel(const bf16_t* qkv, bf16_t* kv_out, int rows, int nh2, int W1, int HD) {
+    const int per = 2 * HD / 8;
+    const long n = (long)nh2 * per;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / per), q = (int)(i % per);
+        *reinterpret_cast<U4*>(kv_out + (size_t)(W1 - nh2 + r) * 2 * HD + q * 8) =
+            *reinterpret_cast<const U4*>(qkv + (size_t)(rows - nh2 + r) * 3 * HD + HD + q * 8);
+    }
 }
 
 }  // namespace ft

@@ -276,10 +276,10 @@ class FishTTS:
         """Streaming synthesis: AR generation on this thread, codec decode on a worker thread with two bounded
         queues; each chunk is decoded independently from zero context (synthesizer.py:483-584).
 
-        Extension `seamless=True` (keyword): the codec is strictly causal, so decoding all codes so far and emitting only
-        the new samples yields exactly the waveform of the non-streaming decode - no restart artefacts at chunk
-        boundaries (the stateful streaming decode of SURVEY.md §8-f F4, done by recomputation: a 10 s utterance in
-        20-frame chunks costs ~40 ms of extra codec time in total)."""
+        Extension `seamless=True` (keyword): the codec is strictly causal, so a chunk decoded with the context its
+        predecessors left (the last 127 frames' K/V of the transformer layers, the last rows of every convolution input:
+        CodecStream / ft_codec_stream_*) is exactly that stretch of the non-streaming decode - no restart artefacts at
+        chunk boundaries (the stateful streaming decode of SURVEY.md section 8-f F4), at the cost of one chunk each."""
         from .generation import generate_long
         seamless = bool(kwargs.get("seamless", False))
         prompt_text, prompt_tokens = self._get_prompt_data(references)
@@ -288,22 +288,25 @@ class FishTTS:
         error_holder: List[Exception] = []
 
         def decoder_worker():
-            history, emitted = [], 0
+            stream = None
             try:
+                if seamless:
+                    if self._vocoder is None:
+                        raise RuntimeError("Vocoder not loaded")
+                    stream = self._vocoder.stream()     # carried state: K/V of the last 127 frames, conv tails
                 while True:
                     codes = codes_queue.get()
                     if codes is None:
                         break
-                    if not seamless:
+                    if stream is None:
                         audio_queue.put(self._decode_to_pcm(codes))
-                        continue
-                    history.append(codes)
-                    pcm = self._decode_to_pcm(np.concatenate(history, axis=1))   # prefix decode == prefix of the decode
-                    audio_queue.put(pcm[emitted:])
-                    emitted = len(pcm)
+                    else:
+                        audio_queue.put((stream.decode(np.asarray(codes)) * 32767).astype(np.int16).tobytes())
             except Exception as e:  # noqa: BLE001
                 error_holder.append(e)
             finally:
+                if stream is not None:
+                    stream.close()
                 audio_queue.put(None)
 
         worker = threading.Thread(target=decoder_worker, daemon=True)

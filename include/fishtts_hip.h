@@ -142,6 +142,17 @@ ft_status ft_ar_get_debug(ft_ctx* ctx, int32_t slot, float* logits /*vocab*/, fl
 ft_status ft_codec_decode(ft_ctx* ctx, const int32_t* codes, int32_t B, int32_t T, const int32_t* lens,
                           float* audio);
 int32_t ft_codec_frame_len(const ft_ctx* ctx); /* samples per code frame (2048) */
+/* Streamed decode with carried state (second half).  The reference's synthesize_stream decodes
+ * every chunk from zero state (synthesizer.py:513-528, 591-595); the codec is strictly causal (window-128 attention,
+ * vocoder.py:325-332; left-padded convolutions, vocoder.py:411-420, 449-455), so carrying the last 127 frames' K/V of
+ * every transformer layer and the last `halo` rows of every convolution input makes the chunks of one stream
+ * concatenate to exactly the waveform of one decode of all the codes.  codes: (n_codebooks+1) x T int32 (host), audio:
+ * T * frame_len float32 (host).  A stream holds at most max_frames frames.  Kernel variants are chosen as for a 215-frame
+ * utterance whatever the chunk length, so the result does not depend on the chunking. */
+typedef struct ft_codec_stream ft_codec_stream;
+ft_status ft_codec_stream_begin(ft_ctx* ctx, ft_codec_stream** out);
+ft_status ft_codec_stream_decode(ft_ctx* ctx, ft_codec_stream* st, const int32_t* codes, int32_t T, float* audio);
+void ft_codec_stream_end(ft_ctx* ctx, ft_codec_stream* st);
 /* Codec encode = vocoder.encode(audio, lengths) of encode_reference (synthesizer.py:325-357, vocoder.py:885-904):
  * mono f32 audio at the codec sample rate (host), right-padded to whole frames -> codes (num_codebooks+1) x T'
  * int32 row-major (host, row stride = T' = ceil(n_samples / ft_codec_enc_frame_len)); *out_frames = T'. */

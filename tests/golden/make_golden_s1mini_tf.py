@@ -19,7 +19,7 @@ from tests.golden.make_golden import build_reference_model, import_reference  # 
 from tests.shapes import make_prompt, s1mini_shape  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
-STD, SEED_W, LP, N_NEW = 0.05, 0, 24, 17
+STD, SEED_W, LP, N_NEW = 0.02, 0, 24, 17
 LOUD = (16, 4.0)     # oracle.ar.random_weights: a few loud head rows give the decisions a trained model's margins
 KW = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.0)
 
@@ -44,6 +44,7 @@ def main():
         want = orc.generate(prompt.clone(), N_NEW, frame_taps=taps, **KW).numpy()
         assert np.array_equal(want, out[f"{tag}.seq"]), f"oracle != reference at s1-mini shapes ({tag})"
         margins = np.zeros((len(taps), shape.num_codebooks), dtype=np.float32)
+        scale = np.zeros((len(taps), shape.num_codebooks), dtype=np.float32)      # largest |logit| of each decision's own vector
         top = np.zeros((len(taps), 8), dtype=np.int64)
         topv = np.zeros((len(taps), 8), dtype=np.float32)
         for f, (logits, _, fast) in enumerate(taps):
@@ -51,10 +52,14 @@ def main():
             tk = torch.topk(l, 8)
             top[f], topv[f] = tk.indices.numpy(), tk.values.numpy()
             margins[f, 0] = float(tk.values[0] - tk.values[1])
+            scale[f, 0] = float(l.abs().max())
             for c in range(1, shape.num_codebooks):
-                t2 = torch.topk(fast[c - 1].float().reshape(-1), 2).values
+                fl = fast[c - 1].float().reshape(-1)
+                t2 = torch.topk(fl, 2).values
                 margins[f, c] = float(t2[0] - t2[1])
+                scale[f, c] = float(fl.abs().max())
         out[f"{tag}.margins"] = margins
+        out[f"{tag}.scale"] = scale
         out[f"{tag}.slow_top8"] = top
         out[f"{tag}.slow_top8_logits"] = topv
         out[f"{tag}.logit_absmax"] = np.float32(max(float(t[0].float().abs().max()) for t in taps))

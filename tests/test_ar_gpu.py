@@ -577,7 +577,8 @@ def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
     each of its eleven decisions is judged against the margin the oracle recorded for that very decision, so a legitimate
     flip early on hides nothing behind it (the next k starts from the golden tokens again).  The slow logits of every
     frame are compared with the reference's top-8 values.  fp32: every index equal (margin bound 1e-4 of the logit
-    range: the reference's own exact ties only); bf16: the evaluation-order tolerance 0.03 x range, as elsewhere."""
+    range: the reference's own exact ties only); bf16: the evaluation-order tolerance 0.02 x range - the range being that
+    of the decision's own logit vector (the codebook heads' logits span another range than the vocabulary's)."""
     from fish_tts_amd.ar_engine import ARHipEngine
     from tests.shapes import s1mini_shape
     g = np.load(os.path.join(G, "ar_s1mini_tf.npz"))
@@ -591,10 +592,11 @@ def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
     del w
     prompt, seq = g["prompt"], g[f"{tag}.seq"]
     margins, top_idx, top_val = g[f"{tag}.margins"], g[f"{tag}.slow_top8"], g[f"{tag}.slow_top8_logits"]
+    scale = np.maximum(1.0, g[f"{tag}.scale"])       # largest |logit| of every decision's OWN logit vector (vocabulary / codebook head)
     T, n_new = prompt.shape[1], int(g["n_new"])
     absmax = max(1.0, float(g[f"{tag}.logit_absmax"]))
-    tol = (1e-4 if precision == "fp32" else 0.03) * absmax
-    ltol = (2e-3 if precision == "fp32" else 0.03) * absmax
+    rtol = 1e-4 if precision == "fp32" else 0.02
+    ltol = (2e-3 if precision == "fp32" else 0.02) * absmax
     sp = eng._sampling(0.7, 1e-6, 1.0)
     flips, judged = [], 0
     dflips, djudged, dframes = [], 0, 0
@@ -607,7 +609,8 @@ def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
         for row in range(seq.shape[0]):
             if frame[row] != want[row]:
                 cb = 0 if row <= 1 else row - 1
-                assert float(margins[k, cb]) <= tol, f"frame {k} row {row}: {frame[row]} != {want[row]}, margin {margins[k, cb]}"
+                assert float(margins[k, cb]) <= rtol * float(scale[k, cb]), \
+                    f"frame {k} row {row}: {frame[row]} != {want[row]}, margin {margins[k, cb]}, logit scale {scale[k, cb]}"
                 flips_.append((k, row, round(float(margins[k, cb]), 4)))
                 break                     # the later codebooks of this frame were drawn after a different code
             n_ok += 1
@@ -635,8 +638,10 @@ def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
     assert djudged >= 0.8 * dframes * seq.shape[0]
     if precision == "bf16":
         assert eng.engine_state()[1] == 0
-    # (the fixture's weights have a few loud head rows - oracle.ar.random_weights - so that 143 of the 170 bf16 decisions
-    # clear the tolerance; with iid rows 70 of 170 sat inside it.  A flip ends the judging of its frame only, the next
+    # (the fixture's weights: the reference's own initializer_range 0.02 - at 0.05 the two REFERENCE precisions sit 3-9 % of
+    # the logit range apart after 28 + 4 layers, at 0.02 0.7 % - plus a few loud head rows (oracle.ar.random_weights) for
+    # margins like a trained model's: 159 of the 170 bf16 decisions clear the tolerance of 0.02 x the decision's own logit
+    # range; with iid rows at 0.05, 70 of 170 sat inside 0.03 x range.  A flip ends the judging of its frame only, the next
     # frame is forced back onto the golden tokens.)
     assert judged >= 0.8 * n_new * seq.shape[0]
     if precision == "fp32":

@@ -129,6 +129,83 @@ def test_s1_mini_codec_10s_utterance_vs_oracle():
     eng.close()
 
 
+def test_streamed_decode_with_carried_state_equals_the_whole_decode():
+    """SURVEY.md section 8-f F4, second half (reference: chunks decoded from zero state, synthesizer.py:513-528): a
+    CodecStream carries the K/V of the last 127 frames of every transformer layer and the last rows of every convolution
+    input, so the chunks of one stream concatenate to the waveform of ONE decode of all the codes - bit for bit, at the
+    real widths, for any chunking: the reference's 10 / 20-frame chunks, single frames and chunks shorter than a
+    convolution's halo (54 rows at dilation 9), a chunk longer than the attention window.  Against ft_codec_decode the
+    equality is bit for bit too at this length (215 frames: both pick the same kernel variants; the stream picks them for
+    a nominal 215-frame utterance whatever the chunk length)."""
+    shape = C.CodecShape()
+    eng, _ = make_codec(shape, max_frames=224)
+    g = torch.Generator().manual_seed(5)
+    T = 215
+    codes = torch.zeros(10, T, dtype=torch.long)
+    codes[0] = torch.randint(0, 4096, (T,), generator=g)
+    codes[1:] = torch.randint(0, 1024, (9, T), generator=g)
+    codes = codes.numpy()
+    whole = eng.decode(codes[None])[0]
+
+    def streamed(sizes):
+        st = eng.stream()
+        out, t = [], 0
+        for n in sizes:
+            out.append(st.decode(codes[:, t: t + n]))
+            t += n
+        assert t == T and st.frames == T
+        st.close()
+        return np.concatenate(out)
+    plans = {"reference chunking": [10] + [20] * 10 + [5], "one chunk": [T],
+             "ragged": [1, 1, 2, 3, 1, 40, 7, 130, 1, 29], "window-sized": [128, 87]}
+    for name, sizes in plans.items():
+        got = streamed(sizes)
+        assert got.shape == whole.shape
+        assert np.array_equal(got.view(np.uint32), whole.view(np.uint32)), \
+            (name, int(np.argmax(got != whole)) // 2048, float(np.max(np.abs(got - whole))))
+    # zero-state chunk decodes (the reference's streaming) do differ from it after the first chunk
+    st0 = np.concatenate([eng.decode(codes[None, :, :10])[0], eng.decode(codes[None, :, 10:30])[0]])
+    # (a 10-frame decode picks other kernel variants than a 215-frame one: equal up to the summation order, not bit for bit)
+    assert rel_rms(st0[: 10 * 2048], whole[: 10 * 2048]) <= 1e-2
+    assert rel_rms(st0[10 * 2048:], whole[10 * 2048: 30 * 2048]) > 0.05
+    # a stream is bounded by the rope table (max_frames positions)
+    st = eng.stream()
+    st.decode(codes[:, :200])
+    with pytest.raises(Exception, match="max_frames"):
+        st.decode(codes[:, :30])
+    st.close()
+    eng.close()
+
+
+def test_streamed_decode_other_lengths_and_shapes():
+    """Lengths at which the one-shot decode picks other kernel variants than the stream's nominal ones (the summation
+    order inside a multi-tap convolution then differs): the chunked stream still equals the ONE-CHUNK stream bit for bit,
+    and the one-shot decode within the codec tolerance; and the tiny widths (other kernels, two decoder blocks)."""
+    for shape, T, sizes in ((C.CodecShape(), 60, [10, 20, 20, 10]), (C.CodecShape(), 300, [10] + [20] * 14 + [10]),
+                            (tiny_codec_shape(), 40, [3, 7, 1, 20, 9])):
+        eng, _ = make_codec(shape, max_frames=320)
+        g = torch.Generator().manual_seed(T)
+        codes = torch.zeros(shape.n_codebooks + 1, T, dtype=torch.long)
+        codes[0] = torch.randint(0, shape.semantic_codebook_size, (T,), generator=g)
+        codes[1:] = torch.randint(0, shape.codebook_size, (shape.n_codebooks, T), generator=g)
+        codes = codes.numpy()
+        st = eng.stream()
+        one = st.decode(codes)
+        st.close()
+        st = eng.stream()
+        parts, t = [], 0
+        for n in sizes:
+            parts.append(st.decode(codes[:, t: t + n]))
+            t += n
+        st.close()
+        assert t == T
+        got = np.concatenate(parts)
+        assert np.array_equal(got.view(np.uint32), one.view(np.uint32)), (T, float(np.max(np.abs(got - one))))
+        whole = eng.decode(codes[None])[0]
+        assert rel_rms(one, whole) <= 1e-2, rel_rms(one, whole)
+        eng.close()
+
+
 # ---------------------------------------------------------------------------------------------- encode side (F4)
 def encode_shape():
     """Smallest widths the MFMA tiles take (channels are multiples of 32; encoder transformers have 64-wide heads)."""
