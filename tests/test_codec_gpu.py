@@ -166,7 +166,7 @@ def test_streamed_decode_with_carried_state_equals_the_whole_decode():
     # zero-state chunk decodes (the reference's streaming) do differ from it after the first chunk
     st0 = np.concatenate([eng.decode(codes[None, :, :10])[0], eng.decode(codes[None, :, 10:30])[0]])
     # (a 10-frame decode picks other kernel variants than a 215-frame one: equal up to the summation order, not bit for bit)
-    assert rel_rms(st0[: 10 * 2048], whole[: 10 * 2048]) <= 1e-2
+    assert rel_rms(st0[: 10 * 2048], whole[: 10 * 2048]) <= 2e-2
     assert rel_rms(st0[10 * 2048:], whole[10 * 2048: 30 * 2048]) > 0.05
     # a stream is bounded by the rope table (max_frames positions)
     st = eng.stream()
@@ -202,7 +202,7 @@ def test_streamed_decode_other_lengths_and_shapes():
         got = np.concatenate(parts)
         assert np.array_equal(got.view(np.uint32), one.view(np.uint32)), (T, float(np.max(np.abs(got - one))))
         whole = eng.decode(codes[None])[0]
-        assert rel_rms(one, whole) <= 1e-2, rel_rms(one, whole)
+        assert rel_rms(one, whole) <= 2e-2, rel_rms(one, whole)
         eng.close()
 
 
