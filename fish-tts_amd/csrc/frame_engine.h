@@ -1310,18 +1310,24 @@ struct FastEngP {
 #define ENG_GSTAMP(k) do { if (p.stamps && atid == 0) p.stamps[(((size_t)b * p.ncb + cb) * nL + nL - 1) * 16 + (k)] = eng_rt(); } while (0)
 constexpr int ENG_FQ = 2, ENG_FF = 3, ENG_FO = 1;   // units per compute wave: QKV 8 rows -> 2, W13 12 pairs -> 3, Wo / W2 / head 4 rows -> 1
 
-// barrier among the four gathering waves only (LDS counter, never reset)
+// The draw's barriers.  The four gathering waves draw; the compute waves have nothing to do meanwhile, so they FOLLOW: they
+// sit in the workgroup's hardware barrier once per barrier of the draw (eng_draw_follow) and leave when the draw says it
+// is over.  A barrier among the four drawing waves alone had to be an LDS counter they spin on (~0.2 us each, eight per
+// draw); the hardware barrier costs a few dozen cycles.
+// `end_at` (LDS): 0 while the number of barriers of the current draw is not known yet, then that number - written by the
+// drawing waves in front of their last barrier; a follower leaves when its own barrier count equals it (so it does not
+// matter whether it reads the word before or after that last barrier).
 struct EngSub {
-    int* count;
-    int phase;
-    __device__ __forceinline__ void sync(int lane) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        ++phase;
-        if (lane == 0) __hip_atomic_fetch_add((eng_lds_int)count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load((eng_lds_int)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < phase * ENG_GW) __builtin_amdgcn_s_sleep(0);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    }
+    int* end_at;
+    int n;           // barriers of the current draw so far
+    __device__ __forceinline__ void sync(int) { ++n; eng_barrier(); }
 };
+__device__ __forceinline__ void eng_draw_follow(const int* end_at) {
+    for (int c = 1;; ++c) {
+        eng_barrier();
+        if (*reinterpret_cast<const volatile int*>(end_at) == c) break;
+    }
+}
 
 // The attention of one fast layer at codebook position c for the heads h = w, w + nw, .. (fast_attn_kernel's arithmetic:
 // one wave per head, lane d owns dimension d (and d + 64)); q/k/v of this position come from qkvS (LDS, f32), the
@@ -1747,6 +1753,8 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre
                              max(__builtin_amdgcn_readlane(km, 32), __builtin_amdgcn_readlane(km, 48)));
                     kmx = (uint32_t)km << 16;
                 }
+                // (measured and not kept: two bits per step, the three candidates' masses summed side by side - the step is
+                // bound by its ~65 select / add instructions per candidate, not by the dependent sums: 3.7 against 3.4 us)
                 for (int bit = 31; bit >= 16; --bit) {
                     const uint32_t cand = kstar | (1u << bit);
                     if (cand > kmx) continue;
@@ -2030,6 +2038,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                     eng_gemv<NTD, 1, SO, PRO_RMSNORM, EPI_STORE>(wh, xA, D, p.eps, nullptr, nullptr, blog(1) + eng_pub(b, h_lo), tag1, nullptr,
                                                                  h_lo, h_hi, cw, lane, eo);
                     __builtin_amdgcn_sched_barrier(0);
+                    eng_draw_follow(sub_count);
                 }
             }
         }
@@ -2096,6 +2105,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 eng_gemv<NTD, 1, SO, PRO_RMSNORM, EPI_STORE>(wh, xA, D, p.eps, nullptr, nullptr, blog(par) + eng_pub(b, h_lo), tag, nullptr,
                                                              h_lo, h_hi, cw, lane, eo);
                 __builtin_amdgcn_sched_barrier(0);
+                eng_draw_follow(sub_count);
             }
         }
     } else {
@@ -2228,9 +2238,11 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                     // draw is a deterministic function of logits, frame and seed): no hand-off of the code, the next step's
                     // embedding row can be fetched at once.  Workgroup drawer(cb) alone does the frame bookkeeping (finish_draw).
                     eng_gather_x(rl, blog(par), layV, 0, p.V, tag, logS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 57);
+                    sub.n = 0;
+                    if (atid == 0) *sub_count = *dead ? 1 : 0;       // (a workgroup that gave up draws nothing: one barrier, then on)
                     sub.sync(lane);
                     ENG_GSTAMP(11);
-                    if (!*dead) {
+                    if (*reinterpret_cast<volatile int*>(sub_count) == 0) {
                         const int last = cb == p.ncb - 1;
                         const int nfv = pre.nfv;
                         EngSampLds S{redbuf, pen_id, pen_val, amv, ami, wcnt, prL, keyL, cut};
@@ -2238,7 +2250,8 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                                                           p.stamps ? p.stamps + (((size_t)b * p.ncb + cb) * nL + nL - 1) * 16 : nullptr);
                         ENG_GSTAMP(14);
                         const int R = p.ncb + 1;
-                        if (atid == 0) codes_s[cb] = code;
+                        if (atid == 0) { codes_s[cb] = code; *sub_count = sub.n + 1; }
+                        sub.sync(lane);      // the draw's last barrier: the compute waves stop following
                         prev_code = code;    // (every thread holds the drawn code: the next step's embedding row is fetched from it)
                         if (b == drawer(cb)) {
                             if (atid == 0) sp.tokn[cb + 1] = code;
