@@ -455,15 +455,16 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
     const int HD = c.n_head * c.head_dim;
     const int qkvN = (c.n_head + 2 * c.n_local_heads) * c.head_dim;
     auto per = [&](int units) { return (units + nb - 1) / nb; };
-    const bool shape_ok = c.dim == 1024 && HD == 2048 && c.intermediate_size == 3072 && c.head_dim == 128 &&
-                          c.n_head == 2 * c.n_local_heads && c.fast_dim == c.dim && c.n_layer >= 1 && c.n_layer < ENG_EPOCH_STEP &&
+    // (the kernels carry these widths as compile-time constants: frame_engine.h ENG_D ..)
+    const bool shape_ok = c.dim == ENG_D && c.n_head == ENG_H && c.n_local_heads == ENG_HKV && c.head_dim == ENG_HD &&
+                          c.intermediate_size == ENG_F && HD == 2048 && c.fast_dim == c.dim && c.n_layer >= 1 && c.n_layer < ENG_EPOCH_STEP &&
                           per(qkvN) <= ENG_SQ * ENG_CW && per(c.dim) <= ENG_SO * ENG_CW && per(c.intermediate_size) <= ENG_SF * ENG_CW &&
                           qkvN % (4 * nb) == 0 && c.dim % (4 * nb) == 0 && c.intermediate_size % (4 * nb) == 0 && per(qkvN) <= ENG_LINE &&
-                          c.n_local_heads * ctx->nsplit_max <= nb && c.head_dim % (4 * ctx->nsplit_max) == 0 && nb >= 64;
+                          c.n_local_heads * ctx->nsplit_max <= nb && c.head_dim % (4 * ctx->nsplit_max) == 0 && nb == ENG_NB;
     if (!shape_ok) {
         char buf[256];
-        snprintf(buf, sizeof buf, "widths outside the engine's instantiation (dim %d, heads %d/%d x %d, ffn %d, fast_dim %d on %d CUs; "
-                 "built for 1024, 16/8 x 128, 3072, 1024 on 128 or 256 CUs)", c.dim, c.n_head, c.n_local_heads, c.head_dim,
+        snprintf(buf, sizeof buf, "widths outside the engine's instantiation (dim %d, heads %d / %d x %d, ffn %d, fast_dim %d on %d CUs; "
+                 "built for 1024, 16 / 8 x 128, 3072, 1024 on 256 CUs)", c.dim, c.n_head, c.n_local_heads, c.head_dim,
                  c.intermediate_size, c.fast_dim, nb);
         why = buf;
         return false;
@@ -527,13 +528,13 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
     // ---- fast codebook loop
     const int HDf = c.fast_n_head * c.fast_head_dim;
     const int fqkvN = (c.fast_n_head + 2 * c.fast_n_local_heads) * c.fast_head_dim;
-    const bool fast_ok = !getenv("FT_NO_FAST_ENGINE") && c.fast_dim == 1024 && HDf == 1024 && c.fast_intermediate_size == 3072 &&
-                         c.fast_head_dim == 64 && c.fast_n_head % c.fast_n_local_heads == 0 && c.n_fast_layer >= 1 &&
+    const bool fast_ok = !getenv("FT_NO_FAST_ENGINE") && c.fast_dim == ENG_FD && c.fast_n_head == ENG_FH && c.fast_n_local_heads == ENG_FHKV &&
+                         c.fast_head_dim == ENG_FHD && c.fast_intermediate_size == ENG_FF_DIM && ctx->fastV == ENG_FV && HDf == 1024 && c.n_fast_layer >= 1 &&
                          c.num_codebooks >= 2 && c.num_codebooks <= 10 && fqkvN % (4 * nb) == 0 && ctx->fastV % (4 * nb) == 0 &&
                          per(fqkvN) <= ENG_FQ * ENG_CW && per(c.fast_dim) <= ENG_FO * ENG_CW && per(c.fast_intermediate_size) <= ENG_FF * ENG_CW &&
                          per(ctx->fastV) <= ENG_FO * ENG_CW && per(fqkvN) <= ENG_LINE && ctx->fastV <= 1024 && c.codebook_size <= 65536 &&
                          true;
-    if (!fast_ok) { why += "; fast loop on launches (FT_NO_FAST_ENGINE, or fast widths outside 1024 / 16 x 64 / 3072, <= 10 codebooks)"; return true; }
+    if (!fast_ok) { why += "; fast loop on launches (FT_NO_FAST_ENGINE, or fast widths outside 1024 / 16 + 8 heads x 64 / 3072 / 1024 codes used, <= 10 codebooks)"; return true; }
     // from here on a failure keeps the slow engine and leaves the fast loop on launches
     auto fast_off = [&](const std::string& w2) { why += "; fast loop on launches (" + w2 + ")"; return true; };
     std::vector<EngLayer> hf(c.n_fast_layer);

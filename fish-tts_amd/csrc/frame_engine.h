@@ -26,6 +26,10 @@
 
 namespace ft {
 
+// the one shape class the engine is instantiated for (openaudio-s1-mini's widths, any depth): slow stack / fast stack
+constexpr int ENG_D = 1024, ENG_H = 16, ENG_HKV = 8, ENG_HD = 128, ENG_F = 3072;
+constexpr int ENG_FD = 1024, ENG_FH = 16, ENG_FHKV = 8, ENG_FHD = 64, ENG_FF_DIM = 3072, ENG_FV = 1024;
+constexpr int ENG_NB = 256;              // workgroups of an engine launch = CUs of the chip (8 XCDs x 32)
 constexpr int ENG_WAVES = 8;             // waves per workgroup (one workgroup per CU; 256 VGPRs per wave)
 constexpr int ENG_THREADS = ENG_WAVES * 64;
 constexpr int ENG_CW = 4;                // waves 0..3 own weight rows
@@ -665,11 +669,16 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     constexpr int SQ = ENG_SQ, SF = ENG_SF, SO = ENG_SO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x, nb = gridDim.x;
+    const int b = blockIdx.x;
+    constexpr int nb = ENG_NB;            // workgroups = CUs (the host launches exactly this many, one per CU)
     const int cw = wave;                  // compute-wave index (valid when < ENG_CW)
     const int gw = wave - ENG_CW;         // gather-wave index (valid when >= 0)
     const int atid = tid - ENG_CW * 64;   // thread index inside the attention group (waves 4..7 = 256 threads)
-    const int D = p.D, F = p.F, hd = p.hd, hp = hd >> 1, HD = p.H * hd;
+    // The widths are compile-time constants: the host's shape gate (engine.hip: eng_setup_try) admits exactly these.  With
+    // run-time widths the kernel spilled ~300 scalar registers into vector lanes and divided by run-time values on its
+    // chains (the y layout map alone: six integer divisions per gathered piece).
+    constexpr int D = ENG_D, F = ENG_F, hd = ENG_HD, hp = hd >> 1, H = ENG_H, Hkv = ENG_HKV, HD = H * hd, QKVN = (H + 2 * Hkv) * hd;
+    static_assert(G == H / Hkv, "query heads per kv head");
     float* xA = smem;                     // layer input
     float* yS = xA + D;                   // attention output
     float* xB = yS + HD;                  // x' = x + Wo y
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     float* q_s = qS + (G + 2) * hd;       // [G][hd] normalised, rotated
     float* k_new = q_s + G * hd;          // [hd]
     float* v_new = k_new + hd;            // [hd]
-    const int LPP = hd >> 3, PPW = 64 / LPP, NSLOT = 4 * PPW;
+    constexpr int LPP = hd >> 3, PPW = 64 / LPP, NSLOT = 4 * PPW;
     float* ml_s = v_new + hd;             // [NSLOT][G][2]
     float* acc_s = ml_s + NSLOT * G * 2;  // [NSLOT][G][hd]
     float* mscr = acc_s + NSLOT * G * hd; // [64][6] split-merge exchange
@@ -690,7 +699,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     if (tid == ENG_CW * 64) {             // one thread owns the registration words
         reg_s[0] = 0; reg_s[1] = 0; reg_s[2] = 1;
         if (XL || p.rep_stride) eng_register(p.ctl, nb, reg_s, dead);
-        if (XL && (reg_s[2] * p.Hkv != nb || reg_s[0] >= p.Hkv || reg_s[1] >= reg_s[2] || p.nsplit != reg_s[2])) {
+        if (XL && (reg_s[2] * Hkv != nb || reg_s[0] >= Hkv || reg_s[1] >= reg_s[2] || p.nsplit != reg_s[2])) {
             // census failed (the workgroups are not spread Hkv x nb / Hkv over the XCDs): nobody may rely on XCD-local data
             if (!__hip_atomic_load((eng_gu32*)(p.ctl + ENG_CTL_ABORT), ENG_RLX)) __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_WHERE), 9998u, ENG_RLX);
             __hip_atomic_store((eng_gu32*)(p.ctl + ENG_CTL_ABORT), 1u, ENG_RLX);
@@ -703,8 +712,8 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     unsigned long long clk0 = 0, rt0 = 0;
     if (p.stamps) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = eng_rt(); }
     const size_t VSTR = (size_t)nb * ENG_LINE;       // dwords per padded vector buffer (one line per workgroup)
-    const EngLayout layD{D / nb}, layF{F / nb}, layQ{p.qkvN / nb}, layLin{0};
-    const int natt = p.Hkv * p.nsplit;
+    const EngLayout layD{D / nb}, layF{F / nb}, layQ{QKVN / nb}, layLin{0};
+    const int natt = Hkv * p.nsplit;
     const int chunk = (pos + p.nsplit) / p.nsplit;   // positions per KV split (attn_decode_kernel's rule)
     const int grp = lane / LPP, gl = lane % LPP;
 
@@ -744,8 +753,8 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     if (wave < ENG_CW) {
         // =============================== compute waves: rows of the four matrices ===============================
         int q_lo, q_hi, o_lo, o_hi, f_lo, f_hi, d_lo, d_hi;
-        eng_units(p.qkvN, b, nb, q_lo, q_hi);
-        if (XL) { q_lo = 0; q_hi = p.qkvN / nb; }          // local units of this workgroup (rows: rmq below)
+        eng_units(QKVN, b, nb, q_lo, q_hi);
+        if (XL) { q_lo = 0; q_hi = QKVN / nb; }          // local units of this workgroup (rows: rmq below)
         eng_units(D, b, nb, o_lo, o_hi);
         eng_units(F, b, nb, f_lo, f_hi);     // (w1_i, w3_i) pairs
         eng_units(D, b, nb, d_lo, d_hi);
@@ -764,9 +773,9 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
         }
         eng_barrier();                                              // (registration results in LDS)
         // XL: which rows of Wqkv are this workgroup's is known only now (kv head = its XCD, share = its rank there)
-        const int xnq = G * hd * p.Hkv / nb, xnk = hd * p.Hkv / nb;
-        const EngRowQkvX rmq{reg_s[0] * G * hd + reg_s[1] * xnq, (p.H + reg_s[0]) * hd + reg_s[1] * xnk,
-                             (p.H + p.Hkv + reg_s[0]) * hd + reg_s[1] * xnk, xnq, xnk};
+        const int xnq = G * hd * Hkv / nb, xnk = hd * Hkv / nb;
+        const EngRowQkvX rmq{reg_s[0] * G * hd + reg_s[1] * xnq, (H + reg_s[0]) * hd + reg_s[1] * xnk,
+                             (H + Hkv + reg_s[0]) * hd + reg_s[1] * xnk, xnq, xnk};
         if (XL) {
             const EngLayer l0 = eng_layer(p.layers, 0);
             eng_issue(wq, l0.wqkv, l0.attn_norm, D, q_lo, q_hi, cw, lane, p.nt, rmq);
@@ -912,8 +921,8 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 // q heads of the group (G*hd granules), new k, new v (hd each): one gathering wave per piece
                 constexpr int QFL = XL ? 2 : 0;      // (XL: written inside this XCD)
                 if (gw == 0) eng_gather<EngIdent, QFL>(gq, layQ, kvh * G * hd, G * hd, tag, qS, 0, 1, lane, p.ctl, dead, li * 8 + 1);
-                if (gw == 1) eng_gather<EngIdent, QFL>(gq, layQ, (p.H + kvh) * hd, hd, tag, qS + G * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
-                if (gw == 2) eng_gather<EngIdent, QFL>(gq, layQ, (p.H + p.Hkv + kvh) * hd, hd, tag, qS + (G + 1) * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
+                if (gw == 1) eng_gather<EngIdent, QFL>(gq, layQ, (H + kvh) * hd, hd, tag, qS + G * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
+                if (gw == 2) eng_gather<EngIdent, QFL>(gq, layQ, (H + Hkv + kvh) * hd, hd, tag, qS + (G + 1) * hd, 0, 1, lane, p.ctl, dead, li * 8 + 1);
                 eng_barrier(); if (*dead) break;                    // BA
                 ENG_ASTAMP(0, 1);
                 if (gw >= 0) {
@@ -1019,12 +1028,14 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                             }
                         }
                     }
+                    ENG_ASTAMP(0, 7);
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         if (gl == 0) { ml_s[(slot * G + g) * 2] = mrun[g]; ml_s[(slot * G + g) * 2 + 1] = lrun[g]; }
 #pragma unroll
                         for (int e = 0; e < 8; ++e) acc_s[(size_t)(slot * G + g) * hd + gl * 8 + e] = acc[g][e];
                     }
+                    ENG_ASTAMP(0, 8);
                 }
                 eng_barrier();
                 ENG_ASTAMP(0, 3);
@@ -1069,7 +1080,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                             if (p.nsplit == 1) {
                                 eng_put(p.gy + (size_t)par * HD, head * hd + e, round_bf16(O / L), tag);
                             } else {
-                                unsigned long long* gp = p.gpart + (((size_t)par * p.H + head) * p.nsplit + split) * (hd + 2);
+                                unsigned long long* gp = p.gpart + (((size_t)par * H + head) * p.nsplit + split) * (hd + 2);
                                 if (XL) {       // the mergers are this XCD's workgroups: the partials stay in its L2
                                     eng_put64_local(gp, e, O, tag32);
                                     if (e == 0) { eng_put64_local(gp, hd, M, tag32); eng_put64_local(gp, hd + 1, L, tag32); }
@@ -1094,7 +1105,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                     // (l, a0..a3; lanes 8 i + q) then add them in split order from LDS.
                     const int item = lane >> 5, s = lane & 31, e = split * 4;
                     const int head = kvh * G + item;
-                    const unsigned long long* gs = p.gpart + (((size_t)par * p.H + head) * p.nsplit + s) * (hd + 2);
+                    const unsigned long long* gs = p.gpart + (((size_t)par * H + head) * p.nsplit + s) * (hd + 2);
                     EngSpin sp{p.ctl, dead, 0, 0, li * 8 + 2};
                     U4 A, B, C;
                     bool alive = true;
@@ -1177,7 +1188,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                         const int g = item_on ? it / e4n : 0;
                         const int e = split * epb + (item_on ? (it % e4n) * 4 : 0);
                         const int head = kvh * G + g;
-                        const unsigned long long* gp = p.gpart + ((size_t)par * p.H + head) * p.nsplit * (hd + 2);
+                        const unsigned long long* gp = p.gpart + ((size_t)par * H + head) * p.nsplit * (hd + 2);
                         float M = -INFINITY, L = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
                         for (int c0 = 0; c0 < p.nsplit && alive; c0 += 8) {
                             const bool son = item_on && c0 + s8 < p.nsplit;
@@ -1876,16 +1887,18 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     constexpr int SQ = ENG_FQ, SF = ENG_FF, SO = ENG_FO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x, nb = gridDim.x;
+    const int b = blockIdx.x;
+    constexpr int nb = ENG_NB;            // workgroups = CUs (the host launches exactly this many, one per CU)
     const int cw = wave, gw = wave - ENG_CW, atid = tid - ENG_CW * 64;
-    const int D = p.D, F = p.F, hd = p.hd, HD = p.H * hd, KVW = p.Hkv * hd;
+    // compile-time widths, as in slow_engine_kernel (the host's gate admits exactly these)
+    constexpr int D = ENG_FD, F = ENG_FF_DIM, hd = HDIM, H = ENG_FH, Hkv = ENG_FHKV, HD = H * hd, KVW = Hkv * hd, QKVN = (H + 2 * Hkv) * hd, V = ENG_FV;
     float* xA = smem;                          // layer input
     float* qkvS = xA + D;                      // gathered q, k, v of this position
-    float* yS = qkvS + p.qkvN;                 // attention output
+    float* yS = qkvS + QKVN;                 // attention output
     float* xB = yS + HD;                       // x' = x + Wo y
     float* gS = xB + D;                        // SwiGLU output
     float* logS = gS + F;                      // [V] logits (drawing workgroup)
-    float* outS = logS + p.V;                  // [ENG_MAX_OUT]
+    float* outS = logS + V;                  // [ENG_MAX_OUT]
     float* redbuf = outS + ENG_MAX_OUT;        // sampling scratch ...
     int* pen_id = reinterpret_cast<int*>(redbuf + 8);
     float* pen_val = reinterpret_cast<float*>(pen_id + 32);
@@ -1906,7 +1919,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     float* xB1 = xA1 + D;
     float* gS1 = xB1 + D;
     float* qkvS1 = gS1;
-    float* yS1 = gS1 + p.qkvN;
+    float* yS1 = gS1 + QKVN;
     if (tid == 0) { *dead = eng_fault_here(p.ctl, ENG_FAULT_FAST, b) ? 1 : 0; *out_count = 0; *sub_count = 0; }
     if (tid == ENG_CW * 64) {                  // one thread owns the registration words
         reg_s[0] = 0; reg_s[1] = 0; reg_s[2] = 1;
@@ -1914,7 +1927,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     }
     const unsigned epoch = __hip_atomic_load((eng_gu32*)(p.ctl + ENG_CTL_EPOCH), ENG_RLX);
     const size_t VSTR = (size_t)nb * ENG_LINE;
-    const EngLayout layD{D / nb}, layF{F / nb}, layQ{p.qkvN / nb}, layV{p.V / nb};
+    const EngLayout layD{D / nb}, layF{F / nb}, layQ{QKVN / nb}, layV{V / nb};
     const int nL = p.n_layer;
     // hand-off buffers of (step parity, layer)
     auto bx = [&](int par, int l) { return p.gx + ((size_t)par * (nL + 1) + l) * VSTR; };
@@ -1929,10 +1942,10 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     if (wave < ENG_CW) {
         // =============================== compute waves ===============================
         int q_lo, q_hi, o_lo, o_hi, f_lo, f_hi, h_lo, h_hi;
-        eng_units(p.qkvN, b, nb, q_lo, q_hi);
+        eng_units(QKVN, b, nb, q_lo, q_hi);
         eng_units(D, b, nb, o_lo, o_hi);
         eng_units(F, b, nb, f_lo, f_hi);
-        eng_units(p.V, b, nb, h_lo, h_hi);
+        eng_units(V, b, nb, h_lo, h_hi);
         EngW<NTD, 1, SQ> wq;
         EngW<NTA, 1, SO> wo;
         EngW<NTD, 2, SF> wf;
@@ -1989,9 +2002,9 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 __builtin_amdgcn_sched_barrier(0);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b: qkvS, qkvS1
                 ENG_FSTAMP(2);
-                eng_fast_attn_any<MAXCB, HDIM>(qkvS, kL, vL, yS, l.qn, l.kn, r0c, r0s, 0, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_fast_attn_any<MAXCB, HDIM>(qkvS, kL, vL, yS, l.qn, l.kn, r0c, r0s, 0, p.ncb, H, Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 eng_barrier();                                          // position 0's K/V rows in LDS
-                eng_fast_attn_any<MAXCB, HDIM>(qkvS1, kL, vL, yS1, l.qn, l.kn, r1c, r1s, 1, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_fast_attn_any<MAXCB, HDIM>(qkvS1, kL, vL, yS1, l.qn, l.kn, r1c, r1s, 1, p.ncb, H, Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 ENG_FSTAMP(9);
                 eng_barrier();                                          // B2: yS, yS1
                 ENG_FSTAMP(3);
@@ -2070,7 +2083,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b: qkvS
                 ENG_FSTAMP(2);
                 eng_fast_attn_any<MAXCB, HDIM>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
-                                         rcs, rsn, cb, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                                         rcs, rsn, cb, p.ncb, H, Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 ENG_FSTAMP(9);
                 eng_barrier();                                          // B2: yS
                 ENG_FSTAMP(3);
@@ -2142,11 +2155,11 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                     }
                 }
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1
-                eng_gather_x2(rl, EngSrc2{{bq(0, li), bq(1, li)}, {qkvS, qkvS1}, {tag0, tag1}}, p.qkvN, gw, ENG_GW, lane, p.ctl, dead, wh + 1);
+                eng_gather_x2(rl, EngSrc2{{bq(0, li), bq(1, li)}, {qkvS, qkvS1}, {tag0, tag1}}, QKVN, gw, ENG_GW, lane, p.ctl, dead, wh + 1);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b
-                eng_fast_attn_any<MAXCB, HDIM>(qkvS, kL, vL, yS, l.qn, l.kn, r0c, r0s, 0, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_fast_attn_any<MAXCB, HDIM>(qkvS, kL, vL, yS, l.qn, l.kn, r0c, r0s, 0, p.ncb, H, Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 eng_barrier();
-                eng_fast_attn_any<MAXCB, HDIM>(qkvS1, kL, vL, yS1, l.qn, l.kn, r1c, r1s, 1, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                eng_fast_attn_any<MAXCB, HDIM>(qkvS1, kL, vL, yS1, l.qn, l.kn, r1c, r1s, 1, p.ncb, H, Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 eng_barrier();                                          // B2
                 if (tail0) eng_gather_x2(rl, EngSrc2{{bxb(0, li), bxb(1, li)}, {xB, xB1}, {tag0, tag1}}, D, gw, ENG_GW, lane, p.ctl, dead, wh + 2);
                 else eng_gather_x(rl, bxb(1, li), layD, 0, D, tag1, xB1, gw, ENG_GW, lane, p.ctl, dead, wh + 2);
@@ -2183,11 +2196,11 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                     // the code this workgroup drew in the previous step: that row of the codebook-embedding table
                     const int code = prev_code;
                     const int d0 = atid * 8;
-                    if (p.qkv0_tab && D <= ENG_GW * 64 * 8 && p.qkvN <= ENG_GW * 64 * 8) {
+                    if (p.qkv0_tab && D <= ENG_GW * 64 * 8 && QKVN <= ENG_GW * 64 * 8) {
                         // the embedding row and layer 0's q k v of that row (a lookup instead of a phase and a hand-off):
                         // both loads in flight together
                         const U4 ue = eng_ldg16<false>(p.fast_emb + (size_t)code * D + (d0 < D ? d0 : 0));
-                        const U4 uq = eng_ldg16<false>(p.qkv0_tab + (size_t)code * p.qkvN + (d0 < p.qkvN ? d0 : 0));
+                        const U4 uq = eng_ldg16<false>(p.qkv0_tab + (size_t)code * QKVN + (d0 < QKVN ? d0 : 0));
                         float e8[8], q8[8];
                         Vec<bf16_t>::unpack(ue, e8);
                         Vec<bf16_t>::unpack(uq, q8);
@@ -2195,7 +2208,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) xA[d0 + j] = e8[j];
                         }
-                        if (d0 < p.qkvN) {
+                        if (d0 < QKVN) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) qkvS[d0 + j] = q8[j];
                         }
@@ -2207,9 +2220,9 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                             for (int j = 0; j < 8; ++j) xA[d + j] = e8[j];
                         }
                         if (p.qkv0_tab) {
-                            for (int d = d0; d < p.qkvN; d += ENG_GW * 64 * 8) {
+                            for (int d = d0; d < QKVN; d += ENG_GW * 64 * 8) {
                                 float e8[8];
-                                Vec<bf16_t>::unpack(eng_ldg16<false>(p.qkv0_tab + (size_t)code * p.qkvN + d), e8);
+                                Vec<bf16_t>::unpack(eng_ldg16<false>(p.qkv0_tab + (size_t)code * QKVN + d), e8);
 #pragma unroll
                                 for (int j = 0; j < 8; ++j) qkvS[d + j] = e8[j];
                             }
@@ -2218,10 +2231,10 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 }
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1
                 if (!(li == 0 && cb >= 2 && p.qkv0_tab))
-                    eng_gather_x(rl, bq(par, li), layQ, 0, p.qkvN, tag, qkvS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 1);
+                    eng_gather_x(rl, bq(par, li), layQ, 0, QKVN, tag, qkvS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 1);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B1b
                 eng_fast_attn_any<MAXCB, HDIM>(qkvS, kvS + (size_t)(li * 2) * p.ncb * KVW, kvS + (size_t)(li * 2 + 1) * p.ncb * KVW, yS, l.qn, l.kn,
-                                         rcs, rsn, cb, p.ncb, p.H, p.Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
+                                         rcs, rsn, cb, p.ncb, H, Hkv, p.eps, p.scale, wave, ENG_WAVES, lane);
                 eng_barrier();                                          // B2
                 eng_gather_x(rl, bxb(par, li), layD, 0, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 2);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B3
@@ -2237,7 +2250,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                     // ---- the draw of codebook cb (inference.py:134-149).  EVERY workgroup gathers the logits and draws (the
                     // draw is a deterministic function of logits, frame and seed): no hand-off of the code, the next step's
                     // embedding row can be fetched at once.  Workgroup drawer(cb) alone does the frame bookkeeping (finish_draw).
-                    eng_gather_x(rl, blog(par), layV, 0, p.V, tag, logS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 57);
+                    eng_gather_x(rl, blog(par), layV, 0, V, tag, logS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + 57);
                     sub.n = 0;
                     if (atid == 0) *sub_count = *dead ? 1 : 0;       // (a workgroup that gave up draws nothing: one barrier, then on)
                     sub.sync(lane);

@@ -138,16 +138,16 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 13; ++k) printf("   %-24s %7.2f %7.2f %7.2f\n", names[k], lo[k] / cnt / 100.0, md[k] / cnt / 100.0, hi[k] / cnt / 100.0);
     }
     {   // the attention turn seen by the workgroups that hold a (kv head, split) role in the layer
-        const char* an[7] = {"turn starts (polls q k v)", "q k v gathered (BA)", "norm + rotation done (BB)", "scores + values done (BC)", "partials published",
-                             "merger: last partials seen", "merger: y published"};
-        double lo[7] = {0}, md[7] = {0}, hi[7] = {0};
+        const char* an[9] = {"turn starts (polls q k v)", "q k v gathered (BA)", "norm + rotation done (BB)", "scores + values done (BC)", "partials published",
+                             "merger: last partials seen", "merger: y published", "  (position walk done)", "  (slot results in LDS)"};
+        double lo[9] = {0}, md[9] = {0}, hi[9] = {0};
         int cnt = 0;
         const size_t off = (size_t)nb * n_layer * 16;
         for (int li = 4; li < n_layer; ++li) {
             unsigned long long t0 = 0;
             for (int b = 0; b < nb; ++b) t0 = std::max(t0, st[((size_t)b * n_layer + li - 1) * 16 + 8]);
             std::vector<unsigned long long> v;
-            for (int k = 0; k < 7; ++k) {
+            for (int k = 0; k < 9; ++k) {
                 v.clear();
                 for (int b = 0; b < nb; ++b) { const unsigned long long x = st[off + ((size_t)b * n_layer + li) * 16 + k]; if (x) v.push_back(x); }
                 if (v.empty()) continue;
@@ -157,7 +157,7 @@ int main(int argc, char** argv) {
             ++cnt;
         }
         printf("attention turn (role workgroups only), same reading:\n");
-        for (int k = 0; k < 7; ++k) printf("   %-28s %7.2f %7.2f %7.2f\n", an[k], lo[k] / cnt / 100.0, md[k] / cnt / 100.0, hi[k] / cnt / 100.0);
+        for (int k = 0; k < 9; ++k) printf("   %-28s %7.2f %7.2f %7.2f\n", an[k], lo[k] / cnt / 100.0, md[k] / cnt / 100.0, hi[k] / cnt / 100.0);
     }
     printf("shader clock during the launch: %.2f GHz\n", (double)st[14] / (double)st[15] * 0.1);
     {   // the x' gather of gw0: first-pass round trip, passes needed
