@@ -270,6 +270,62 @@ __device__ __forceinline__ void eng_gather_x(const EngRelay& rl, const unsigned*
     eng_gather<DMap, 1>(rep, lay, u0, n, tag, dst, gw, ngw, lane, ctl, dead, where, dmap, dbg);
 }
 
+// The packed form (three values per 8-byte granule, eng_gemv<.., PK3>): n values (n % 384 == 0) = n / 384 pieces of 1 KiB;
+// lane l of a piece holds two granules = values 6 l .. 6 l + 5 of the piece.
+static_assert(ENG_F % 384 == 0 && (ENG_F / ENG_NB) % 3 == 0 && ENG_FF_DIM % 384 == 0 && (ENG_FF_DIM / ENG_NB) % 3 == 0,
+              "packed SwiGLU hand-off: whole 1 KiB pieces, whole triples per workgroup");
+__device__ __forceinline__ bool eng_tags3_ok(const U4& v, unsigned tag) { return (v.y >> 16) == tag && (v.w >> 16) == tag; }
+__device__ __forceinline__ void eng_unpack3_to_lds(float* dst, const U4& v) {
+    float2 a, b, c;
+    a.x = __uint_as_float(v.x << 16); a.y = __uint_as_float(v.x & 0xffff0000u);
+    b.x = __uint_as_float(v.y << 16); b.y = __uint_as_float(v.z << 16);
+    c.x = __uint_as_float(v.z & 0xffff0000u); c.y = __uint_as_float(v.w << 16);
+    reinterpret_cast<float2*>(dst)[0] = a; reinterpret_cast<float2*>(dst)[1] = b; reinterpret_cast<float2*>(dst)[2] = c;
+}
+template <int FL = 0>
+__device__ __forceinline__ void eng_gather3(const unsigned* g, int n, unsigned tag, float* dst, int gw, int ngw, int lane, unsigned* ctl,
+                                            int* dead, int where) {
+    const int npiece = n / 384;
+    EngSpin sp{ctl, dead, 0, 0, where};
+    for (int p0 = gw; p0 < npiece; p0 += 3 * ngw) {
+        const int c0 = p0;
+        const int c1 = p0 + ngw < npiece ? p0 + ngw : c0;
+        const int c2 = p0 + 2 * ngw < npiece ? p0 + 2 * ngw : c0;
+        const unsigned* a0 = g + c0 * 256 + lane * 4;
+        const unsigned* a1 = g + c1 * 256 + lane * 4;
+        const unsigned* a2 = g + c2 * 256 + lane * 4;
+        U4 a, b, c;
+        for (;;) {
+            if (c1 == c0) { eng_ld1_sc1<FL>(a0, a); b = a; c = a; }
+            else eng_ld3_sc1<FL>(a0, a1, a2, a, b, c);
+            if (__all(eng_tags3_ok(a, tag) && eng_tags3_ok(b, tag) && eng_tags3_ok(c, tag))) break;
+            if (sp.give_up(lane)) return;
+        }
+        eng_unpack3_to_lds(dst + c0 * 384 + lane * 6, a);
+        if (c1 != c0) eng_unpack3_to_lds(dst + c1 * 384 + lane * 6, b);
+        if (c2 != c0) eng_unpack3_to_lds(dst + c2 * 384 + lane * 6, c);
+    }
+}
+__device__ __forceinline__ void eng_gather3_x(const EngRelay& rl, const unsigned* g, int n, unsigned tag, float* dst, int gw, int ngw,
+                                              int lane, unsigned* ctl, int* dead, int where) {
+    if (!rl.on) { eng_gather3(g, n, tag, dst, gw, ngw, lane, ctl, dead, where); return; }
+    unsigned* rep = const_cast<unsigned*>(g) + rl.delta;
+    const int npiece = n / 384;
+    for (int p = rl.rank; p < npiece; p += rl.nr) {      // import duty, as in eng_gather_x
+        if (p % ngw != gw) continue;
+        const int o = p * 256 + lane * 4;
+        EngSpin sp{ctl, dead, 0, 0, where};
+        U4 a;
+        for (;;) {
+            eng_ld1_sc1(g + o, a);
+            if (__all(eng_tags3_ok(a, tag))) break;
+            if (sp.give_up(lane)) return;
+        }
+        *reinterpret_cast<U4*>(rep + o) = a;
+    }
+    eng_gather3<1>(rep, n, tag, dst, gw, ngw, lane, ctl, dead, where);
+}
+
 // Two vectors of the same length n (n % 256 == 0) gathered as ONE list of 2 * npiece pieces (the two rows of the fast
 // loop's first pass): piece P < npiece belongs to vector 0, the others to vector 1.
 struct EngSrc2 { const unsigned* g[2]; float* dst[2]; unsigned tag[2]; };
@@ -474,7 +530,10 @@ __device__ __forceinline__ void eng_gemv_qkv_local(const EngW<NT, 1, MAXS>& r, c
     }
 }
 
-template <int NT, int RPU, int MAXS, int PRO, int EPI>
+// PK3: the vector is handed over as 8-byte granules of THREE values {v0 | v1 << 16, v2 | tag << 16} (the SwiGLU vector: 3072
+// values are 8 KB instead of 12, and its hand-off is the longest of a layer); gout then points at the vector's base and the
+// workgroup's units must be a multiple of three (12 at 256 workgroups).
+template <int NT, int RPU, int MAXS, int PRO, int EPI, bool PK3 = false>
 __device__ __forceinline__ void eng_gemv(const EngW<NT, RPU, MAXS>& r, const float* xs, int K, float eps, const bf16_t* bias,
                                          const float* resid, unsigned* gout, unsigned tag, float* plain, int u_lo, int u_hi,
                                          int cw, int lane, EngOut& eo) {
@@ -488,7 +547,14 @@ __device__ __forceinline__ void eng_gemv(const EngW<NT, RPU, MAXS>& r, const flo
     if (old + 1 == eo.seq * ENG_CW) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         const int n = u_hi - u_lo;
-        if (lane < n) {
+        if constexpr (PK3) {
+            if (lane * 3 < n) {
+                const unsigned w0 = (__float_as_uint(eo.vals[3 * lane]) >> 16) | (__float_as_uint(eo.vals[3 * lane + 1]) & 0xffff0000u);
+                const unsigned w1 = (__float_as_uint(eo.vals[3 * lane + 2]) >> 16) | (tag << 16);
+                __hip_atomic_store((eng_gu64*)(reinterpret_cast<unsigned long long*>(gout) + (u_lo / 3 + lane)),
+                                   ((unsigned long long)w1 << 32) | w0, ENG_RLX);
+            }
+        } else if (lane < n) {
             const float o = eo.vals[lane];
             eng_put(gout, lane, o, tag);
             if (plain) plain[u_lo + lane] = o;
@@ -713,8 +779,10 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     if (p.stamps) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = eng_rt(); }
     const size_t VSTR = (size_t)nb * ENG_LINE;       // dwords per padded vector buffer (one line per workgroup)
     const EngLayout layD{D / nb}, layF{F / nb}, layQ{QKVN / nb}, layLin{0};
-    const int natt = Hkv * p.nsplit;
-    const int chunk = (pos + p.nsplit) / p.nsplit;   // positions per KV split (attn_decode_kernel's rule)
+    // (XL: one split per workgroup of the XCD - a compile-time 32; the host passes the same number, checked with the census)
+    const int nsplit = XL ? nb / Hkv : p.nsplit;
+    const int natt = Hkv * nsplit;
+    const int chunk = (pos + nsplit) / nsplit;   // positions per KV split (attn_decode_kernel's rule)
     const int grp = lane / LPP, gl = lane % LPP;
 
     // ---- embedding of the input column, every workgroup for itself (embed_kernel's arithmetic), all threads; then the
@@ -819,7 +887,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             __builtin_amdgcn_sched_barrier(0);
             eng_barrier(); if (*dead) break;                        // B3
             ENG_STAMP(5);
-            eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, D, p.eps, nullptr, nullptr, p.gg + (size_t)par * VSTR + eng_pub(b, f_lo), tag, nullptr, f_lo, f_hi, cw, lane, eo);
+            eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU, true>(wf, xB, D, p.eps, nullptr, nullptr, p.gg + (size_t)par * VSTR, tag, nullptr, f_lo, f_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(6);
             if (more) eng_issue(wf, ln.w13, ln.ffn_norm, D, f_lo, f_hi, cw, lane, p.nt);
@@ -873,7 +941,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             for (int st = 0; st < ENG_KVST; ++st) { kpf[st] = U4{0u, 0u, 0u, 0u}; vpf[st] = U4{0u, 0u, 0u, 0u}; }
             if (att_next < 0) return;
             const int a = role(att_next);
-            const int kvh = a / p.nsplit, split = a % p.nsplit;
+            const int kvh = a / nsplit, split = a % nsplit;
             const int lo = split * chunk, hi = min(lo + chunk, pos + 1);
             if (lane < hp) {
                 if (plan_qn) { gq0 = eng_ldg_bf16(plan_qn, 2 * lane); gq1 = eng_ldg_bf16(plan_qn, 2 * lane + 1); }
@@ -893,7 +961,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
         if (!XL) { kv_plan(0); kv_issue(); }
         eng_barrier();                                              // (registration results in LDS)
         const EngRelay rl{p.rep_stride != 0, reg_s[1], reg_s[2], p.rep_delta0 + (long)reg_s[0] * p.rep_stride};
-        if (XL) { x_role = reg_s[0] * p.nsplit + reg_s[1]; kv_plan(0); kv_issue(); }
+        if (XL) { x_role = reg_s[0] * nsplit + reg_s[1]; kv_plan(0); kv_issue(); }
         // rotation entries of this position (the same for every layer)
         float rope_c = 1.f, rope_s = 0.f;
         if (lane < hp) { rope_c = p.rope[((size_t)pos * hp + lane) * 2]; rope_s = p.rope[((size_t)pos * hp + lane) * 2 + 1]; }
@@ -910,7 +978,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             const int a = role(li);
             if (a >= 0) {     // (workgroup-uniform)
                 kv_plan(li + 1);                                    // the turn after this one (scalar fetches land during this turn)
-                const int kvh = a / p.nsplit, split = a % p.nsplit;
+                const int kvh = a / nsplit, split = a % nsplit;
                 const int lo = split * chunk;
                 const int hi = min(lo + chunk, pos + 1);
                 bf16_t* kc = l.kc + p.cache_off + (size_t)kvh * p.n_slots * hd;
@@ -1077,10 +1145,10 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                         }
                         if (idx < G * hd) {
                             const int head = kvh * G + g;
-                            if (p.nsplit == 1) {
+                            if (nsplit == 1) {
                                 eng_put(p.gy + (size_t)par * HD, head * hd + e, round_bf16(O / L), tag);
                             } else {
-                                unsigned long long* gp = p.gpart + (((size_t)par * H + head) * p.nsplit + split) * (hd + 2);
+                                unsigned long long* gp = p.gpart + (((size_t)par * H + head) * nsplit + split) * (hd + 2);
                                 if (XL) {       // the mergers are this XCD's workgroups: the partials stay in its L2
                                     eng_put64_local(gp, e, O, tag32);
                                     if (e == 0) { eng_put64_local(gp, hd, M, tag32); eng_put64_local(gp, hd + 1, L, tag32); }
@@ -1097,7 +1165,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 // one head; lane 8 * i + s polls split c0 + s of item i (O[0..3], m, l = three 16-byte loads), the
                 // values cross to the item's first lane through LDS, which merges in split order.
                 ENG_ASTAMP(0, 4);
-                if (XL && gw == 3 && p.nsplit == 32 && hd == 128 && G == 2) {
+                if (XL && gw == 3 && nsplit == 32 && hd == 128 && G == 2) {
                     // ---- XL merge, ONE poll round: this workgroup merges elements [4 split, 4 split + 4) of its kv head's two query
                     // heads; lane 32 i + s polls split s of head i (O[0..3], m, l = three 16-byte loads).  merge_splits4's
                     // arithmetic: splits in chunks of 8, running maximum, rescale at each chunk, sums taken split by split.
@@ -1105,7 +1173,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                     // (l, a0..a3; lanes 8 i + q) then add them in split order from LDS.
                     const int item = lane >> 5, s = lane & 31, e = split * 4;
                     const int head = kvh * G + item;
-                    const unsigned long long* gs = p.gpart + (((size_t)par * H + head) * p.nsplit + s) * (hd + 2);
+                    const unsigned long long* gs = p.gpart + (((size_t)par * H + head) * nsplit + s) * (hd + 2);
                     EngSpin sp{p.ctl, dead, 0, 0, li * 8 + 2};
                     U4 A, B, C;
                     bool alive = true;
@@ -1176,8 +1244,8 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                     }
                     ENG_ASTAMP(3, 6);
                 } else
-                if (p.nsplit > 1 && gw == 3) {
-                    const int epb = hd / p.nsplit;            // elements per workgroup and head (multiple of 4)
+                if (nsplit > 1 && gw == 3) {
+                    const int epb = hd / nsplit;            // elements per workgroup and head (multiple of 4)
                     const int e4n = epb >> 2;
                     const int nitem = G * e4n;
                     EngSpin sp{p.ctl, dead, 0, 0, li * 8 + 2};
@@ -1188,10 +1256,10 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                         const int g = item_on ? it / e4n : 0;
                         const int e = split * epb + (item_on ? (it % e4n) * 4 : 0);
                         const int head = kvh * G + g;
-                        const unsigned long long* gp = p.gpart + ((size_t)par * H + head) * p.nsplit * (hd + 2);
+                        const unsigned long long* gp = p.gpart + ((size_t)par * H + head) * nsplit * (hd + 2);
                         float M = -INFINITY, L = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                        for (int c0 = 0; c0 < p.nsplit && alive; c0 += 8) {
-                            const bool son = item_on && c0 + s8 < p.nsplit;
+                        for (int c0 = 0; c0 < nsplit && alive; c0 += 8) {
+                            const bool son = item_on && c0 + s8 < nsplit;
                             const unsigned long long* gs = gp + (size_t)(son ? c0 + s8 : 0) * (hd + 2);
                             U4 A, B, C;
                             for (;;) {
@@ -1202,7 +1270,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                                 if (sp.give_up(lane)) { alive = false; break; }
                             }
                             if (!alive) break;
-                            if (ib + 8 >= nitem && c0 + 8 >= p.nsplit) ENG_ASTAMP(3, 5);      // last partials seen
+                            if (ib + 8 >= nitem && c0 + 8 >= nsplit) ENG_ASTAMP(3, 5);      // last partials seen
                             // lane 8 i + s holds split c0 + s of item i: the weights are formed in parallel, the sums are
                             // taken in split order by the item's first lane (row_shl reads lane + s of the 16-lane row)
                             const float m_ = son ? __uint_as_float(C.x) : -INFINITY;
@@ -1239,7 +1307,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             }
             {
                 // y is stored per attention workgroup: [kvh][split][g][hd / nsplit] (each 128-byte line written by one of them)
-                const int epb = hd / p.nsplit, ns = p.nsplit;
+                const int epb = hd / nsplit, ns = nsplit;
                 auto ymap = [=](int i) { const int a2 = i / (G * epb), r2 = i % (G * epb), g2 = r2 / epb, eo = r2 % epb;
                                          return ((a2 / ns) * G + g2) * hd + (a2 % ns) * epb + eo; };
                 eng_gather_x(rl, p.gy + (size_t)par * HD, layLin, 0, HD, tag, yS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 3, ymap);
@@ -1258,7 +1326,7 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 unsigned long long* q = p.stamps + ((size_t)b * p.n_layer + li) * 16;
                 q[10] = t_poll0; q[11] = t_poll1; q[12] = eng_rt();
             }
-            eng_gather_x(rl, p.gg + (size_t)par * VSTR, layF, 0, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 5);
+            eng_gather3_x(rl, p.gg + (size_t)par * VSTR, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 5);
             eng_barrier(); if (*dead) break;                        // B4
         }
     }
@@ -1619,12 +1687,12 @@ __device__ __forceinline__ EngDrawPre eng_draw_pre(const SampP& p, int tid) {
     }
     const float* qrow = nullptr;
     if (p.noise && d.nfv < p.noise_rows) qrow = p.noise + (size_t)d.nfv * p.noise_row_len + p.noise_off;
-    draw_noise4(p, d.ctl, qrow, 4 * tid, d.nfv, 0, p.V, d.q4);
+    draw_noise4(p, d.ctl, qrow, 4 * tid, d.nfv, 0, ENG_FV, d.q4);
     return d;
 }
 __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre& pre, const float* L, const EngSampLds& S, EngSub& sub, int tid, int lane, int wave,
                                                 unsigned long long* stp = nullptr) {
-    const int V = p.V;
+    constexpr int V = ENG_FV;          // (= p.V: the host's gate admits only this many used codes)
     const RowCtl ctl = pre.ctl;
     const int nfv = pre.nfv;
     const int R = p.ncb + 1;
@@ -2024,7 +2092,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                     eng_gemv2<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, xB1, D, p.eps, nullptr, nullptr, nullptr, bg(0, li) + eng_pub(b, f_lo),
                                                                    bg(1, li) + eng_pub(b, f_lo), tag0, tag1, f_lo, f_hi, cw, lane, eo);
                 else
-                    eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB1, D, p.eps, nullptr, nullptr, bg(1, li) + eng_pub(b, f_lo), tag1, nullptr,
+                    eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU, true>(wf, xB1, D, p.eps, nullptr, nullptr, bg(1, li), tag1, nullptr,
                                                                   f_lo, f_hi, cw, lane, eo);
                 __builtin_amdgcn_sched_barrier(0);
                 ENG_FSTAMP(6);
@@ -2095,7 +2163,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 __builtin_amdgcn_sched_barrier(0);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B3: xB
                 ENG_FSTAMP(5);
-                eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, D, p.eps, nullptr, nullptr, bg(par, li) + eng_pub(b, f_lo), tag, nullptr,
+                eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU, true>(wf, xB, D, p.eps, nullptr, nullptr, bg(par, li), tag, nullptr,
                                                               f_lo, f_hi, cw, lane, eo);
                 __builtin_amdgcn_sched_barrier(0);
                 ENG_FSTAMP(6);
@@ -2165,7 +2233,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 else eng_gather_x(rl, bxb(1, li), layD, 0, D, tag1, xB1, gw, ENG_GW, lane, p.ctl, dead, wh + 2);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B3
                 if (tail0) eng_gather_x2(rl, EngSrc2{{bg(0, li), bg(1, li)}, {gS, gS1}, {tag0, tag1}}, F, gw, ENG_GW, lane, p.ctl, dead, wh + 3);
-                else eng_gather_x(rl, bg(1, li), layF, 0, F, tag1, gS1, gw, ENG_GW, lane, p.ctl, dead, wh + 3);
+                else eng_gather3_x(rl, bg(1, li), F, tag1, gS1, gw, ENG_GW, lane, p.ctl, dead, wh + 3);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B4
             }
         }
@@ -2238,7 +2306,7 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 eng_barrier();                                          // B2
                 eng_gather_x(rl, bxb(par, li), layD, 0, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 2);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B3
-                eng_gather_x(rl, bg(par, li), layF, 0, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 3);
+                eng_gather3_x(rl, bg(par, li), F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 3);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B4
             }
             if (!alive) break;
