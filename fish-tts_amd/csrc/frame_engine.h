@@ -734,7 +734,7 @@ template <int NTD, int NTA, int NTF, int G, bool XL = false>
 __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     constexpr int SQ = ENG_SQ, SF = ENG_SF, SO = ENG_SO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: uniform branches, row offsets in SGPRs)
     const int b = blockIdx.x;
     constexpr int nb = ENG_NB;            // workgroups = CUs (the host launches exactly this many, one per CU)
     const int cw = wave;                  // compute-wave index (valid when < ENG_CW)
@@ -1954,7 +1954,7 @@ template <int NTD, int NTA, int NTF, int MAXCB, int HDIM>
 __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
     constexpr int SQ = ENG_FQ, SF = ENG_FF, SO = ENG_FO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: uniform branches, row offsets in SGPRs)
     const int b = blockIdx.x;
     constexpr int nb = ENG_NB;            // workgroups = CUs (the host launches exactly this many, one per CU)
     const int cw = wave, gw = wave - ENG_CW, atid = tid - ENG_CW * 64;
