@@ -62,7 +62,7 @@ __device__ __forceinline__ void gemv_issue(const GemvP& p, const int row0, const
     }
 }
 
-template <typename WT, int NT, int R, bool ROUND, typename XLoad>
+template <typename WT, int NT, int R, int ROUND, typename XLoad>
 __device__ __forceinline__ void gemv_finish(const GemvP& p, const int m, const int row0, const int lane,
                                             U4 (&raw)[R][NT], XLoad xload) {
     constexpr int VEC = Vec<WT>::N;
@@ -143,14 +143,14 @@ __device__ __forceinline__ void gemv_finish(const GemvP& p, const int m, const i
     }
 }
 
-template <typename WT, int NT, int R, bool ROUND, typename XLoad>
+template <typename WT, int NT, int R, int ROUND, typename XLoad>
 __device__ __forceinline__ void gemv_rows(const GemvP& p, const int m, const int row0, const int lane, XLoad xload) {
     U4 raw[R][NT];
     gemv_issue<WT, NT, R>(p, row0, lane, raw);
     gemv_finish<WT, NT, R, ROUND>(p, m, row0, lane, raw, xload);
 }
 
-template <typename WT, int NT, int R, bool ROUND>
+template <typename WT, int NT, int R, int ROUND>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvP p) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvP p) {
 // Lock-step batches: MB utterance rows share one pass over the weights (each wave keeps MB activation vectors in
 // registers).  Per row the arithmetic (order of the fma chain, wave reduction, roundings) is exactly that of
 // gemv_kernel, so a batched run reproduces the single-utterance run bit for bit.
-template <typename WT, int NT, int R, int MB, bool ROUND>
+template <typename WT, int NT, int R, int MB, int ROUND>
 __global__ __launch_bounds__(256) void gemv_mb_kernel(GemvP p, int Mrows) {
     constexpr int VEC = Vec<WT>::N;
     constexpr int TILE = 64 * VEC;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void gemv_mb_kernel(GemvP p, int Mrows) {
 }
 
 // RMSNorm of S rows for the MFMA prefill (llama.py:172-177): f32 normalise, round, * gain, round -> bf16
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 __global__ __launch_bounds__(256) void rmsnorm_llama_rows_kernel(const float* x, const void* gain_, float eps, int D,
                                                                  bf16_t* out) {
     __shared__ float red[4];
@@ -309,7 +309,7 @@ struct EmbedP {
     float inv_div;  // (float)sqrt(ncb+1), used as a divisor
 };
 
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 __global__ __launch_bounds__(256) void embed_kernel(EmbedP p) {
     const int m = blockIdx.y;
     const int* tk = p.toks + (size_t)m * p.tok_m_stride + p.col;
@@ -376,7 +376,7 @@ struct AttnP {
     bf16_t* q_out;   // kv_only pass: the normalised, rotated queries [row][H*hd] for the MFMA prompt attention
 };
 
-template <typename WT, int G, bool ROUND>
+template <typename WT, int G, int ROUND>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int kvh = blockIdx.x, split = blockIdx.y, m = blockIdx.z;
@@ -404,8 +404,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     const int slot = wave * PPW + grp;
     auto load_kv = [&](int j, float(&kv)[8], float(&vv)[8]) {
         if constexpr (sizeof(WT) == 2) {
-            Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(kc) + (size_t)j * hd + gl * 8, kv);
-            Vec<bf16_t>::load(reinterpret_cast<const bf16_t*>(vc) + (size_t)j * hd + gl * 8, vv);
+            Vec<WT>::load(kc + (size_t)j * hd + gl * 8, kv);
+            Vec<WT>::load(vc + (size_t)j * hd + gl * 8, vv);
         } else {
             const float* kf = reinterpret_cast<const float*>(kc) + (size_t)j * hd + gl * 8;
             const float* vf = reinterpret_cast<const float*>(vc) + (size_t)j * hd + gl * 8;
@@ -584,7 +584,7 @@ __device__ __forceinline__ void merge_splits4(const AttnP& a, size_t base, int e
 // Wo GEMV (+ residual) whose input vector is assembled on the fly from the split-KV partials of
 // attn_decode_kernel: y[head][e] = sum_s O_s w_s / sum_s l_s w_s, w_s = exp(m_s - max m).  Saves the
 // separate combine launch; each lane merges only the 8 (4) consecutive elements it multiplies.
-template <typename WT, int NT, int R, bool ROUND>
+template <typename WT, int NT, int R, int ROUND>
 __global__ __launch_bounds__(256) void gemv_attn_combine_kernel(GemvP p, AttnP a) {
     extern __shared__ __attribute__((aligned(16))) float y_s[];  // [H*hd]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void gemv_attn_combine_kernel(GemvP p, AttnP a
 
 // Split-KV merge as its own launch (wide lock-step batches: the Wo product is an MFMA GEMM over all rows, so the merge
 // cannot ride inside it).  Same arithmetic as above; writes the bf16 operand copy.  grid (M), 256 threads.
-template <bool ROUND>
+template <int ROUND>
 __global__ __launch_bounds__(256) void attn_combine_rows_kernel(AttnP a) {
     const int m = blockIdx.x, tid = threadIdx.x;
     const int K = a.H * a.hd;
@@ -656,7 +656,7 @@ constexpr int FAST_MAXCB = 16;
 
 // One wave per query head: lane d owns dimension d (hd <= 64) or dimensions d and d+64 (hd = 128).
 // All K/V rows of the <= num_codebooks cached positions are fetched in one round trip.
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 __global__ __launch_bounds__(64) void fast_attn_kernel(FastAttnP a, float* y, int ldy) {
     const int h = blockIdx.x, m = blockIdx.y, lane = threadIdx.x;
     const int hd = a.hd, hp = hd >> 1, H = a.H, Hkv = a.Hkv, G = H / Hkv, c = a.c, ncb = a.ncb;
@@ -902,7 +902,7 @@ __device__ __forceinline__ void finish_draw(const SampP& p, const int m, const i
     }
 }
 
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 __global__ __launch_bounds__(1024) void sample_block_kernel(SampP p) {
     __shared__ float red[16];
     __shared__ int redi[16];
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(1024) void sample_block_kernel(SampP p) {
         if (!removed(tot)) {
             all_kept = true;
         } else {
-            const int lowbit = ROUND ? 16 : 0;
+            const int lowbit = ROUND == 1 ? 16 : 0;
             for (int bit = 31; bit >= lowbit; --bit) {
                 const uint32_t cand = kstar | (1u << bit);
                 float ms = 0.f;
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(1024) void sample_block_kernel(SampP p) {
             }
             // class kstar: member count, mass strictly above; a member's mass follows from its
             // (unique) logit value, recovered by inverting the order-preserving key
-            const uint32_t cmask = ROUND ? 0xffff0000u : 0xffffffffu;
+            const uint32_t cmask = ROUND == 1 ? 0xffff0000u : 0xffffffffu;
             float above = 0.f, cnt = 0.f;
             for (int i = tid; i < V; i += T) {
                 const float l = L[i];
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(1024) void sample_block_kernel(SampP p) {
     // -- temperature, softmax over the kept set, exponential race (inference.py:57-61, 24-27)
     int winner = am.i;
     if (!only_top) {
-        const uint32_t cmask = ROUND ? 0xffff0000u : 0xffffffffu;
+        const uint32_t cmask = ROUND == 1 ? 0xffff0000u : 0xffffffffu;
         const float Tc = fmaxf(ctl.temperature, 1e-5f);
         auto kept = [&](int i, float l) {
             if (all_kept) return true;
@@ -1100,7 +1100,7 @@ struct Red4 {
     }
 };
 
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 __global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
     __shared__ float redbuf[8];
     __shared__ int pen_id[32];
@@ -1171,7 +1171,7 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
     const float Z = red.sum(z);
     const float tp = rb<ROUND>(ctl.top_p);
     auto removed = [&](float cum) { return rb<ROUND>(cum) > tp; };
-    constexpr uint32_t cmask = ROUND ? 0xffff0000u : 0xffffffffu;
+    constexpr uint32_t cmask = ROUND == 1 ? 0xffff0000u : 0xffffffffu;
     uint32_t key[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1200,7 +1200,7 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
             if (!removed(tot)) {
                 all_kept = 1;
             } else {
-                constexpr int lowbit = ROUND ? 16 : 0;
+                constexpr int lowbit = ROUND == 1 ? 16 : 0;
                 for (int bit = 31; bit >= lowbit; --bit) {
                     const uint32_t cand = kstar | (1u << bit);
                     float ms = 0.f;

@@ -36,12 +36,25 @@ __device__ __forceinline__ bf16_t f32_to_bf16_bits(float x) {
     const __bf16 h = (__bf16)x;
     return __builtin_bit_cast(bf16_t, h);
 }
-template <bool ROUND> __device__ __forceinline__ float rb(float x) { return ROUND ? round_bf16(x) : x; }
 
-// element load/store for the two storage types the engine supports (bf16 bits, f32)
+// precision="fp16" (synthesizer.py:125-126): IEEE half storage, its own type so the templates can tell it from bf16 bits
+struct f16_t { uint16_t bits; };
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
+__device__ __forceinline__ float round_f16(float x) { return (float)(_Float16)x; }     // RNE, overflow -> inf as torch's cast
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float x) {
+    const _Float16 h = (_Float16)x;
+    return __builtin_bit_cast(uint16_t, h);
+}
+// the model precision's rounding: ROUND = 0 none (f32), 1 bf16, 2 fp16 (a bool true converts to 1)
+enum { RND_NONE = 0, RND_BF16 = 1, RND_F16 = 2 };
+template <int ROUND> __device__ __forceinline__ float rb(float x) { return ROUND == 1 ? round_bf16(x) : ROUND == 2 ? round_f16(x) : x; }
+
+// element load/store for the storage types the engine supports (bf16 bits, fp16, f32)
 __device__ __forceinline__ float ld_elem(const bf16_t* p, size_t i) { return bf16_bits_to_f32(p[i]); }
+__device__ __forceinline__ float ld_elem(const f16_t* p, size_t i) { return f16_bits_to_f32(p[i].bits); }
 __device__ __forceinline__ float ld_elem(const float* p, size_t i) { return p[i]; }
 __device__ __forceinline__ void st_elem(bf16_t* p, size_t i, float v) { p[i] = f32_to_bf16_bits(v); }
+__device__ __forceinline__ void st_elem(f16_t* p, size_t i, float v) { p[i].bits = f32_to_f16_bits(v); }
 __device__ __forceinline__ void st_elem(float* p, size_t i, float v) { p[i] = v; }
 
 // 16-byte vector of weights -> VEC f32 values (VEC = 8 for bf16, 4 for f32)
@@ -61,6 +74,20 @@ template <> struct Vec<bf16_t> {
         v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
         v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
     }
+    __device__ static __forceinline__ void zero(float (&v)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+};
+template <> struct Vec<f16_t> {
+    static constexpr int N = 8;
+    __device__ static __forceinline__ void unpack(const U4& r, float (&v)[8]) {
+        v[0] = f16_bits_to_f32(r.x & 0xffffu); v[1] = f16_bits_to_f32(r.x >> 16);
+        v[2] = f16_bits_to_f32(r.y & 0xffffu); v[3] = f16_bits_to_f32(r.y >> 16);
+        v[4] = f16_bits_to_f32(r.z & 0xffffu); v[5] = f16_bits_to_f32(r.z >> 16);
+        v[6] = f16_bits_to_f32(r.w & 0xffffu); v[7] = f16_bits_to_f32(r.w >> 16);
+    }
+    __device__ static __forceinline__ void load(const f16_t* p, float (&v)[8]) { unpack(*reinterpret_cast<const U4*>(p), v); }
     __device__ static __forceinline__ void zero(float (&v)[8]) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = 0.f;

@@ -108,7 +108,7 @@ static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static ft_status ar_validate(ft_ctx* ctx) {
     const ft_ar_config& c = ctx->c;
     auto bad = [&](const char* m) { return ft_fail(ctx, FT_ERR_UNSUPPORTED, m); };
-    if (c.dtype != FT_BF16 && c.dtype != FT_F32) return bad("dtype must be FT_BF16 or FT_F32");
+    if (c.dtype != FT_BF16 && c.dtype != FT_F32 && c.dtype != FT_F16) return bad("dtype must be FT_BF16, FT_F16 or FT_F32");
     if (c.dim % 8 || c.fast_dim % 8 || c.intermediate_size % 8 || c.fast_intermediate_size % 8)
         return bad("dim / intermediate sizes must be multiples of 8");
     if (!pow2(c.head_dim) || c.head_dim < 8 || c.head_dim > 128) return bad("head_dim must be a power of two in [8,128]");
@@ -127,7 +127,7 @@ static ft_status ar_validate(ft_ctx* ctx) {
 static ft_status ar_alloc(ft_ctx* ctx) {
     const ft_ar_config& c = ctx->c;
     const size_t M = c.max_batch;
-    ctx->esz = c.dtype == FT_BF16 ? 2 : 4;
+    ctx->esz = c.dtype == FT_F32 ? 4 : 2;
     ctx->n_slots = c.max_seq_len + ((8 - c.max_seq_len % 8) % 8);  // llama.py:387
     const char* ns = getenv("FT_ATTN_NSPLIT");
     ctx->nsplit = ns ? atoi(ns) : (ctx->n_slots > 512 ? 8 : 1);
@@ -318,7 +318,8 @@ extern "C" ft_status ft_load_weight(ft_ctx* ctx, const char* name, const void* s
                      (long long)shape[i], (long long)t.shape[i]);
             return ft_fail(ctx, FT_ERR_ARG, buf);
         }
-    if (src_dtype != FT_F32 && src_dtype != FT_BF16) return ft_fail(ctx, FT_ERR_ARG, "src_dtype must be FT_F32 or FT_BF16");
+    if (src_dtype != FT_F32 && src_dtype != FT_BF16 && src_dtype != FT_F16)
+        return ft_fail(ctx, FT_ERR_ARG, "src_dtype must be FT_F32, FT_BF16 or FT_F16");
     FT_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t n = t.numel();
     const size_t ssz = src_dtype == FT_F32 ? 4 : 2, dsz = t.dtype == FT_F32 ? 4 : 2;
@@ -332,10 +333,14 @@ extern "C" ft_status ft_load_weight(ft_ctx* ctx, const char* name, const void* s
     hipError_t e = hipMemcpy(stage, src, (size_t)n * ssz, hipMemcpyDefault);
     if (e == hipSuccess) {
         const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-        if (src_dtype == FT_F32)
-            convert_kernel<float, bf16_t><<<blocks, 256, 0, ctx->stream>>>((const float*)stage, (bf16_t*)t.p, n);
-        else
-            convert_kernel<bf16_t, float><<<blocks, 256, 0, ctx->stream>>>((const bf16_t*)stage, (float*)t.p, n);
+        auto to = [&](auto* sp) {
+            if (t.dtype == FT_F32) convert_kernel<<<blocks, 256, 0, ctx->stream>>>(sp, (float*)t.p, n);
+            else if (t.dtype == FT_BF16) convert_kernel<<<blocks, 256, 0, ctx->stream>>>(sp, (bf16_t*)t.p, n);
+            else convert_kernel<<<blocks, 256, 0, ctx->stream>>>(sp, (f16_t*)t.p, n);
+        };
+        if (src_dtype == FT_F32) to((const float*)stage);
+        else if (src_dtype == FT_BF16) to((const bf16_t*)stage);
+        else to((const f16_t*)stage);
         e = hipStreamSynchronize(ctx->stream);
     }
     hipFree(stage);
@@ -719,7 +724,7 @@ static void enqueue_slow_engine(Launch& L, const int* toks, long tok_row_stride,
 }
 
 
-template <typename WT, bool ROUND, int R>
+template <typename WT, int ROUND, int R>
 static void gemv_nt(Launch& L, const GemvP& p, int nt) {
     const dim3 grid((p.N + 4 * R - 1) / (4 * R), L.M), block(256);
 #define FT_NT(n) case n: gemv_kernel<WT, n, R, ROUND><<<grid, block, 0, L.s>>>(p); break;
@@ -734,7 +739,7 @@ static int pick_nt(int K, int vec) {
     return -1;
 }
 
-template <typename WT, bool ROUND, int R, int MB>
+template <typename WT, int ROUND, int R, int MB>
 static void gemv_mb_nt(Launch& L, const GemvP& p, int nt) {
     const dim3 grid((p.N + 4 * R - 1) / (4 * R), (L.M + MB - 1) / MB), block(256);
 #define FT_NT(n) case n: gemv_mb_kernel<WT, n, R, MB, ROUND><<<grid, block, 0, L.s>>>(p, L.M); break;
@@ -742,7 +747,7 @@ static void gemv_mb_nt(Launch& L, const GemvP& p, int nt) {
 #undef FT_NT
 }
 
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 static void gemv(Launch& L, GemvP p, int R) {
     const int nt = pick_nt(p.K, Vec<WT>::N);
     if (nt < 0) { L.err = hipErrorInvalidValue; return; }
@@ -786,7 +791,7 @@ static int rows_per_wave(int N, int M) {
     return 1;
 }
 
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 static void attn_decode(Launch& L, const AttnP& p) {
     ft_ctx* ctx = L.ctx;
     const int G = p.H / p.Hkv;
@@ -810,7 +815,7 @@ static void attn_decode(Launch& L, const AttnP& p) {
     (void)ctx;
 }
 
-template <typename WT, bool ROUND, int R>
+template <typename WT, int ROUND, int R>
 static void gemv_combine_nt(Launch& L, const GemvP& p, const AttnP& a, int nt) {
     const dim3 grid((p.N + 4 * R - 1) / (4 * R), L.M), block(256);
 #define FT_NT(n) case n: gemv_attn_combine_kernel<WT, n, R, ROUND><<<grid, block, (size_t)a.H * a.hd * sizeof(float), L.s>>>(p, a); break;
@@ -819,7 +824,7 @@ static void gemv_combine_nt(Launch& L, const GemvP& p, const AttnP& a, int nt) {
 }
 
 // fast_project_in on the pre-norm hidden state (llama.py:453,590); identity when fast_dim == dim
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 static void enqueue_fproj(Launch& L) {
     ft_ctx* ctx = L.ctx;
     const ft_ar_config& c = ctx->c;
@@ -832,7 +837,7 @@ static void enqueue_fproj(Launch& L) {
 }
 
 // One slow-transformer pass over the current input column of rows [m0, m0+M) (llama.py:400-453).
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long tok_m_stride, int col, bool with_head) {
     ft_ctx* ctx = L.ctx;
     const ft_ar_config& c = ctx->c;
@@ -856,7 +861,7 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
     for (int li = 0; li < c.n_layer; ++li) {
         const FtLayer& l = ctx->layers[li];
         if (wide) {
-            if constexpr (ROUND) {
+            if constexpr (ROUND == RND_BF16) {
                 const int D = c.dim, HD = c.n_head * c.head_dim, F = c.intermediate_size, M = L.M;
                 bf16_t* xn = ctx->mb_xn + (size_t)m0 * D;
                 bf16_t* ybf = ctx->mb_ybf + (size_t)m0 * HD;
@@ -956,12 +961,12 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
 }
 
 // final norm + vocabulary head (llama.py:446-451)
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 static void enqueue_head(Launch& L) {
     ft_ctx* ctx = L.ctx;
     const ft_ar_config& c = ctx->c;
     if (wide_batch(L)) {
-        if constexpr (ROUND) {
+        if constexpr (ROUND == RND_BF16) {
             bf16_t* xn = ctx->mb_xn + (size_t)L.m0 * c.dim;
             if (ctx->wide_fuse && L.M <= ctx->wide_fuse_max && c.n_layer > 0 && c.vocab_size % 2 == 0) {  // x and its partials: last slow W2
                 PfX nrm; nrm.gain = ctx->norm; nrm.ss_in = ctx->mb_ss + (size_t)L.m0 * (std::max(c.dim, c.fast_dim) / 16 + 1); nrm.nblk = c.dim / 16;
@@ -982,7 +987,7 @@ static void enqueue_head(Launch& L) {
     gemv<WT, ROUND>(L, h, rows_per_wave(h.N, L.M));
 }
 
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 static void enqueue_sample(Launch& L, int cb, bool last) {
     if (L.gemv_only) return;
     ft_ctx* ctx = L.ctx;
@@ -1000,7 +1005,7 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
     s.last = last ? 1 : 0; s.tok = ctx->d_tok + (size_t)m0 * R; s.pos = ctx->d_pos + m0; s.done = ctx->d_done + m0;
     if (s.V <= 1024) {
         sample_small_kernel<WT, ROUND><<<L.M, 256, 0, L.s>>>(s);
-    } else if (ROUND) {
+    } else if (ROUND == RND_BF16) {
         // large vocabulary, bf16: the histogram of the 65 536 bf16 classes and the search of the top-p cut on it in ONE block
         // per row (LDS counters), then index-ordered tie handling and the chip-wide race
         SampBigP b{};
@@ -1027,7 +1032,7 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
 }
 
 // The fast transformer over codebook positions 0..ncb-1 with its sampling (inference.py:115-149).
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 static void enqueue_fast_step(Launch& L, const int cb) {
     ft_ctx* ctx = L.ctx;
     const ft_ar_config& c = ctx->c;
@@ -1044,7 +1049,7 @@ static void enqueue_fast_step(Launch& L, const int cb) {
             const FtLayer& l = ctx->flayers[li];
             const float* xl = li == 0 ? xin : xf;
             if (wide) {
-                if constexpr (ROUND) {
+                if constexpr (ROUND == RND_BF16) {
                     const int HDf = Hf * hdf, Ff = c.fast_intermediate_size, M = L.M;
                     bf16_t* xn = ctx->mb_xn + (size_t)m0 * Df;
                     bf16_t* ybf = ctx->mb_ybf + (size_t)m0 * HDf;
@@ -1117,7 +1122,7 @@ static void enqueue_fast_step(Launch& L, const int cb) {
         }
         if (cb == 0) return;  // logits of position 0 are discarded (inference.py:122)
         if (wide) {
-            if constexpr (ROUND) {
+            if constexpr (ROUND == RND_BF16) {
                 bf16_t* xn = ctx->mb_xn + (size_t)m0 * Df;
                 if (ctx->wide_fuse && L.M <= ctx->wide_fuse_max && c.n_fast_layer > 0 && ctx->fastV % 2 == 0) {
                     PfX nrm; nrm.gain = ctx->fast_norm; nrm.ss_in = ctx->mb_ss + (size_t)m0 * (std::max(c.dim, c.fast_dim) / 16 + 1); nrm.nblk = Df / 16;
@@ -1142,18 +1147,18 @@ static void enqueue_fast_step(Launch& L, const int cb) {
 }
 
 // One full frame: slow pass on the current column, semantic sample, fast codebooks (inference.py:83-155).
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 static void enqueue_frame_tail(Launch& L);
 
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 static void enqueue_frame_t(Launch& L, const int* toks, long trs, long tms, int col) {
-    if (ROUND && eng_slow_ok(L)) enqueue_slow_engine(L, toks, trs, tms, col);
+    if (ROUND == RND_BF16 && eng_slow_ok(L)) enqueue_slow_engine(L, toks, trs, tms, col);
     else enqueue_slow<WT, ROUND>(L, toks, trs, tms, col, true);
     enqueue_frame_tail<WT, ROUND>(L);
 }
 
 // everything after the slow layers: vocabulary head, semantic draw, the fast codebooks
-template <typename WT, bool ROUND>
+template <typename WT, int ROUND>
 static void enqueue_frame_tail(Launch& L) {
     ft_ctx* ctx = L.ctx;
     const int ncb = ctx->c.num_codebooks;
@@ -1163,17 +1168,19 @@ static void enqueue_frame_tail(Launch& L) {
     }
     enqueue_head<WT, ROUND>(L);
     enqueue_sample<WT, ROUND>(L, 0, ncb == 1);
-    if (ROUND && eng_fast_ok(L)) { enqueue_fast_engine(L); return; }
+    if (ROUND == RND_BF16 && eng_fast_ok(L)) { enqueue_fast_engine(L); return; }
     for (int cb = 0; cb < ncb; ++cb) enqueue_fast_step<WT, ROUND>(L, cb);
 }
 
 static void enqueue_frame(Launch& L, const int* toks, long trs, long tms, int col) {
-    if (L.ctx->c.dtype == FT_BF16) enqueue_frame_t<bf16_t, true>(L, toks, trs, tms, col);
-    else enqueue_frame_t<float, false>(L, toks, trs, tms, col);
+    if (L.ctx->c.dtype == FT_BF16) enqueue_frame_t<bf16_t, RND_BF16>(L, toks, trs, tms, col);
+    else if (L.ctx->c.dtype == FT_F16) enqueue_frame_t<f16_t, RND_F16>(L, toks, trs, tms, col);
+    else enqueue_frame_t<float, RND_NONE>(L, toks, trs, tms, col);
 }
 static void enqueue_slow_only(Launch& L, const int* toks, long trs, long tms, int col) {
-    if (L.ctx->c.dtype == FT_BF16) enqueue_slow<bf16_t, true>(L, toks, trs, tms, col, false);
-    else enqueue_slow<float, false>(L, toks, trs, tms, col, false);
+    if (L.ctx->c.dtype == FT_BF16) enqueue_slow<bf16_t, RND_BF16>(L, toks, trs, tms, col, false);
+    else if (L.ctx->c.dtype == FT_F16) enqueue_slow<f16_t, RND_F16>(L, toks, trs, tms, col, false);
+    else enqueue_slow<float, RND_NONE>(L, toks, trs, tms, col, false);
 }
 
 // ------------------------------------------------------------------------------------------ AR API
@@ -1428,8 +1435,9 @@ extern "C" ft_status ft_ar_first_frames(ft_ctx* ctx, int32_t slot0, int32_t n, c
     Launch L{ctx, ctx->stream, slot0, n, 0};
     const bool on_engine = n == 1 && eng_in_use(ctx);
     auto tail = [&]() {
-        if (c.dtype == FT_BF16) { enqueue_fproj<bf16_t, true>(L); enqueue_frame_tail<bf16_t, true>(L); }
-        else { enqueue_fproj<float, false>(L); enqueue_frame_tail<float, false>(L); }
+        if (c.dtype == FT_BF16) { enqueue_fproj<bf16_t, RND_BF16>(L); enqueue_frame_tail<bf16_t, RND_BF16>(L); }
+        else if (c.dtype == FT_F16) { enqueue_fproj<f16_t, RND_F16>(L); enqueue_frame_tail<f16_t, RND_F16>(L); }
+        else { enqueue_fproj<float, RND_NONE>(L); enqueue_frame_tail<float, RND_NONE>(L); }
     };
     tail();
     if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("first-frame launch: ") + hipGetErrorString(L.err));
@@ -1940,8 +1948,9 @@ extern "C" ft_status ft_test_sample(ft_ctx* ctx, const float* logits, int32_t cb
         ctx->noise = nullptr; ctx->noise_rows = 0;
     }
     Launch L{ctx, ctx->stream, 0, 1, 0};
-    if (c.dtype == FT_BF16) enqueue_sample<bf16_t, true>(L, cb, false);
-    else enqueue_sample<float, false>(L, cb, false);
+    if (c.dtype == FT_BF16) enqueue_sample<bf16_t, RND_BF16>(L, cb, false);
+    else if (c.dtype == FT_F16) enqueue_sample<f16_t, RND_F16>(L, cb, false);
+    else enqueue_sample<float, RND_NONE>(L, cb, false);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     ctx->noise = saved; ctx->noise_rows = srows; ctx->noise_row_len = slen;
     if (tmp) hipFree(tmp);

@@ -26,12 +26,12 @@ typedef int32_t ft_status;
 
 enum { FT_OK = 0, FT_ERR_ARG = 1, FT_ERR_HIP = 2, FT_ERR_STATE = 3, FT_ERR_UNSUPPORTED = 4,
        FT_ERR_NOMEM = 5, FT_ERR_TOO_LONG = 6, FT_ERR_MISSING_WEIGHT = 7 };
-enum { FT_F32 = 0, FT_BF16 = 1 };
+enum { FT_F32 = 0, FT_BF16 = 1, FT_F16 = 2 };   /* FT_F16: the AR model only (precision="fp16", synthesizer.py:125-126) */
 
 /* Field names and meaning = config.json / DualARModelArgs (fish_tts/models/llama.py:31-123);
  * the three token ids come from the tokenizer layout (fish_tts/models/tokenizer.py:83-101). */
 typedef struct ft_ar_config {
-    int32_t dtype;  /* FT_BF16 | FT_F32: model precision (fish_tts/synthesizer.py:122-128) */
+    int32_t dtype;  /* FT_BF16 | FT_F16 | FT_F32: model precision (fish_tts/synthesizer.py:122-128) */
     int32_t vocab_size, n_layer, n_head, dim, intermediate_size, n_local_heads, head_dim;
     float rope_base, norm_eps;
     int32_t max_seq_len, tie_word_embeddings, attention_qkv_bias, attention_o_bias, attention_qk_norm;
@@ -81,7 +81,7 @@ const char* ft_last_error(const ft_ctx* ctx); /* ctx may be NULL: last create-ti
 
 /* Weight ingestion under the reference's state-dict names (llama.py:349-359,510-535 after the
  * wq/wk/wv->wqkv fuse of llama.py:222-227; codec names as vocoder.py modules after weight-norm
- * folding).  `src` may be a host or a device pointer; `src_dtype` FT_F32|FT_BF16; the tensor is
+ * folding).  `src` may be a host or a device pointer; `src_dtype` FT_F32|FT_BF16|FT_F16; the tensor is
  * converted to the ctx precision and repacked.  Replaces load_state_dict (llama.py:498). */
 ft_status ft_load_weight(ft_ctx* ctx, const char* name, const void* src, int32_t src_dtype,
                          const int64_t* shape, int32_t ndim);
