@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(CSRC, "libfishtts_hip.so")
 
 FT_OK = 0
 FT_ERR_ARG, FT_ERR_HIP, FT_ERR_STATE, FT_ERR_UNSUPPORTED, FT_ERR_NOMEM, FT_ERR_TOO_LONG, FT_ERR_MISSING_WEIGHT = range(1, 8)
-FT_F32, FT_BF16 = 0, 1
+FT_F32, FT_BF16, FT_F16 = 0, 1, 2
 
 
 class ft_ar_config(C.Structure):

@@ -52,13 +52,13 @@ class ARHipEngine:
     def __init__(self, args: DualARModelArgs, semantic_begin_id: int, semantic_end_id: int, im_end_id: int,
                  precision: str = "bf16", device: int = 0, max_batch: int = 1, max_new_tokens: int = 2048,
                  codec_cfg: Optional[L.ft_codec_config] = None):
-        if precision not in ("bf16", "fp32"):
-            raise NotImplementedError(f"precision {precision!r}: the MI355X path implements 'bf16' and 'fp32'")
+        if precision not in ("bf16", "fp16", "fp32"):
+            raise ValueError(f"precision {precision!r}: expected 'bf16', 'fp16' or 'fp32' (synthesizer.py:122-128)")
         self.args = args
         self.precision = precision
         self.lib = L.load()
         c = L.ft_ar_config()
-        c.dtype = L.FT_BF16 if precision == "bf16" else L.FT_F32
+        c.dtype = {"bf16": L.FT_BF16, "fp16": L.FT_F16, "fp32": L.FT_F32}[precision]
         for name in ("vocab_size", "n_layer", "n_head", "dim", "intermediate_size", "n_local_heads", "head_dim",
                      "max_seq_len", "codebook_size", "num_codebooks", "n_fast_layer", "fast_dim", "fast_n_head",
                      "fast_n_local_heads", "fast_head_dim", "fast_intermediate_size"):
@@ -111,11 +111,11 @@ class ARHipEngine:
         load_state_dict(strict=False, assign=True) (llama.py:498) for EXTRA keys only: a name the model does not
         have is skipped (returns False); a wrong shape or rank still raises."""
         t = t.detach()
-        if t.dtype not in (torch.float32, torch.bfloat16):
+        if t.dtype not in (torch.float32, torch.bfloat16, torch.float16):
             t = t.float()
         t = t.contiguous()
         shape = (C.c_int64 * t.dim())(*t.shape)
-        dt = L.FT_F32 if t.dtype == torch.float32 else L.FT_BF16
+        dt = {torch.float32: L.FT_F32, torch.bfloat16: L.FT_BF16, torch.float16: L.FT_F16}[t.dtype]
         st = self.lib.ft_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), dt, shape, t.dim())
         if not strict and st == L.FT_ERR_ARG and self.lib.ft_last_error(self._h).startswith(b"unknown weight name"):
             logger.debug("checkpoint key %s is not a weight of this model: skipped", name)

@@ -74,8 +74,6 @@ class FishTTS:
         if device != "cuda":
             raise RuntimeError("fish_tts_amd runs the hot path on an MI355X only: device must be 'cuda' "
                                "(there is no CPU fallback)")
-        if precision == "fp16":
-            raise NotImplementedError("precision 'fp16' is not implemented on the MI355X path; use 'bf16' or 'fp32'")
         if _synthetic is not None:
             self._load_synthetic(**_synthetic)
         else:
@@ -128,7 +126,7 @@ class FishTTS:
         from .weights import random_state_dict
         import torch
         self._tokenizer = tokenizer
-        dtype = torch.bfloat16 if self._precision == "bf16" else torch.float32
+        dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(self._precision, torch.float32)
         self._engine = ARHipEngine(args, tokenizer.semantic_begin_id, tokenizer.semantic_end_id,
                                    tokenizer.get_token_id(IM_END_TOKEN), precision=self._precision,
                                    device=self._gpu_index, max_batch=self._max_batch, max_new_tokens=max_new_tokens)

@@ -258,6 +258,10 @@ def main():
         from tests.golden import make_golden_codec
         make_golden_codec.gen_encode(vocoder)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "f16":            # only the precision="fp16" fixtures (synthesizer.py:125-126)
+        gen_ar(llama, inference, "ar_tiny_f16", tiny_shape(), torch.float16, T=9, n_new=16)
+        gen_ar(llama, inference, "ar_tinyb_f16", tiny_shape_b(), torch.float16, T=12, n_new=12)
+        return
     gen_ar(llama, inference, "ar_tiny_f32", tiny_shape(), torch.float32, T=9, n_new=16)
     gen_ar(llama, inference, "ar_tiny_bf16", tiny_shape(), torch.bfloat16, T=9, n_new=16)
     gen_ar(llama, inference, "ar_tinyb_f32", tiny_shape_b(), torch.float32, T=12, n_new=12)

@@ -14,7 +14,7 @@ def args_from_shape(shape: O.ARShape):
 def make_pair(shape: O.ARShape, precision: str, seed: int = 0, max_batch: int = 1, max_new_tokens: int = 64,
               std=None):
     from fish_tts_amd.ar_engine import ARHipEngine
-    dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(precision, torch.float32)
     w = O.random_weights(shape, seed=seed, std=std)
     orc = O.AROracle(shape, w, dtype)
     eng = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,

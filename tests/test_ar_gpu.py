@@ -62,7 +62,8 @@ def _oracle_scores(shape, taps, want, T, col, row, kw, tape):
 
 @pytest.mark.parametrize("name,shape_fn,precision,n_new", [
     ("ar_tiny_f32", tiny_shape, "fp32", 16), ("ar_tiny_bf16", tiny_shape, "bf16", 16),
-    ("ar_tinyb_f32", tiny_shape_b, "fp32", 12), ("ar_tinyb_bf16", tiny_shape_b, "bf16", 12)])
+    ("ar_tinyb_f32", tiny_shape_b, "fp32", 12), ("ar_tinyb_bf16", tiny_shape_b, "bf16", 12),
+    ("ar_tiny_f16", tiny_shape, "fp16", 16), ("ar_tinyb_f16", tiny_shape_b, "fp16", 12)])
 def test_greedy_matches_golden(name, shape_fn, precision, n_new):
     gold = np.load(os.path.join(G, name + ".npz"))
     shape = shape_fn()
@@ -72,7 +73,8 @@ def test_greedy_matches_golden(name, shape_fn, precision, n_new):
     sp = eng._sampling(0.7, 1e-6, 1.0)
     eng.prefill(prompt, sp)
     logits, hidden = eng.debug_state()
-    tol = 2e-4 if precision == "fp32" else 0.08  # bf16: a few ulp of O(4) logits after 2+2 layers
+    # bf16: a few ulp of O(4) logits after 2+2 layers; fp16 has three more mantissa bits
+    tol = {"fp32": 2e-4, "bf16": 0.08, "fp16": 0.01}[precision]
     assert np.max(np.abs(logits - gold["frame0.logits"])) <= tol * max(1.0, np.max(np.abs(gold["frame0.logits"])))
     assert np.max(np.abs(hidden - gold["frame0.hidden"])) <= tol * max(1.0, np.max(np.abs(gold["frame0.hidden"])))
     for cname, kw in GREEDY:
@@ -84,7 +86,7 @@ def test_greedy_matches_golden(name, shape_fn, precision, n_new):
             orc.reset()
             orc.generate(torch.from_numpy(prompt), n_new, frame_taps=taps, **kw)
             col, row = div
-            assert _margin_ok(taps, col - prompt.shape[1], row, 1e-5 if precision == "fp32" else 0.06), \
+            assert _margin_ok(taps, col - prompt.shape[1], row, {"fp32": 1e-5, "bf16": 0.06, "fp16": 0.0075}[precision]), \
                 f"{cname}: diverged at column {col}, row {row}\n{seq}\n{want}"
         # streaming flavour: EOS frame included, identical frames otherwise
         blocks = list(eng.generate_streaming(prompt, n_new, chunk=5, **kw))
@@ -93,7 +95,7 @@ def test_greedy_matches_golden(name, shape_fn, precision, n_new):
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("shape_fn", [tiny_shape, tiny_shape_b])
 def test_sampled_with_injected_noise(shape_fn, precision):
     shape = shape_fn()
@@ -456,13 +458,13 @@ def test_generation_is_clamped_to_the_cache_like_the_reference():
     eng.close()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_sampling_kernel_vs_oracle(precision):
     """The sampling kernel alone, on identical logits and identical Exp(1) noise, against
     inference.py:30-80 as restated (and golden-pinned) in oracle.ar.sample."""
     shape = tiny_shape()
     eng, _ = make_pair(shape, precision)
-    dtype = torch.bfloat16 if precision == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(precision, torch.float32)
     g = torch.Generator().manual_seed(11)
     R = shape.num_codebooks + 1
     bad = []

@@ -22,6 +22,8 @@ CASES = [("greedy_rep1.0", dict(temperature=0.7, top_p=1e-6, repetition_penalty=
     ("ar_tiny_bf16", tiny_shape, torch.bfloat16, 16),
     ("ar_tinyb_f32", tiny_shape_b, torch.float32, 12),
     ("ar_tinyb_bf16", tiny_shape_b, torch.bfloat16, 12),
+    ("ar_tiny_f16", tiny_shape, torch.float16, 16),          # precision="fp16" (synthesizer.py:125-126)
+    ("ar_tinyb_f16", tiny_shape_b, torch.float16, 12),
 ])
 def test_ar_oracle_matches_reference(name, shape_fn, dtype, n_new):
     torch.set_num_threads(4)
