@@ -278,11 +278,12 @@ def test_kv_split_count_follows_context_length(monkeypatch, Lp, want_splits):
     assert np.max(np.abs(la - lb)) < 1e-4
 
 
-def test_lockstep_batch_equals_single(monkeypatch):
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_lockstep_batch_equals_single(monkeypatch, precision):
     shape = tiny_shape()
     kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
     prompts = [make_prompt(shape, 7 + 3 * i, seed=10 + i, n_vq=2).numpy() for i in range(3)]
-    eng, _ = make_pair(shape, "bf16", max_batch=3)
+    eng, _ = make_pair(shape, precision, max_batch=3)
     singles = [eng.generate(p, 9, **kw) for p in prompts]
     sp = eng._sampling(0.7, 1e-6, 1.1)
     firsts = [eng.prefill(p, sp, slot=i) for i, p in enumerate(prompts)]
@@ -339,7 +340,8 @@ def test_prefix_kv_reuse_at_model_widths_vs_oracle():
     eng.close()
 
 
-def test_batch32_mixed_lengths_equals_single(monkeypatch):
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_batch32_mixed_lengths_equals_single(monkeypatch, precision):
     """BASELINE configs[2]: 32 utterances of mixed prompt lengths and mixed frame budgets in one captured lock-step
     graph; every utterance reproduces its own single-slot run (EOS allowed, so lengths differ).  FT_NO_WIDE keeps the
     batch on the multi-row FMA GEMV, whose per-row arithmetic is that of the single run (the MFMA batch path sums in
@@ -349,7 +351,7 @@ def test_batch32_mixed_lengths_equals_single(monkeypatch):
     B = 32
     kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
     prompts = [make_prompt(shape, 5 + (7 * i) % 23, seed=100 + i, n_vq=i % 4).numpy() for i in range(B)]
-    eng, _ = make_pair(shape, "bf16", max_batch=B)
+    eng, _ = make_pair(shape, precision, max_batch=B)
     singles = [eng.generate(p, 12, **kw) for p in prompts]
     sp = eng._sampling(0.7, 1e-6, 1.1)
     firsts = [eng.prefill(p, sp, slot=i) for i, p in enumerate(prompts)]
