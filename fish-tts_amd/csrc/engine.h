@@ -112,6 +112,10 @@ struct ft_ctx {
     // A hand-off that timed out (ENG_CTL_ABORT) is survivable: the host clears the control words and the hand-off pools,
     // redoes the affected frames on the launch path (eng_suspended) and turns the engine off for this context after
     // ENG_MAX_STRIKES such events.  eng_why says, in words, which frame path this context takes and why.
+    // batch form of the codebook loop (batch_engine.h): 2..32 lock-step rows, opt-in (FT_BATCH_ENGINE)
+    bool engb_on = false;
+    unsigned* engb_g = nullptr;
+    size_t engb_words = 0, engb_bytes = 0, engb_lds = 0;
     bool eng_suspended = false;
     int eng_strikes = 0, eng_last_where = 0;
     bool eng_owner = false;         // this context holds its device's engine slot (one engine context per device and process)

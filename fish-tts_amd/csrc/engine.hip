@@ -3,6 +3,7 @@
 #include "engine.h"
 #include "ar_kernels.h"
 #include "frame_engine.h"
+#include "batch_engine.h"
 #include "codec_kernels.h"
 
 #include <math.h>
@@ -422,19 +423,22 @@ static ft_status ar_finalize(ft_ctx* ctx) {
 // widths at any depth); every other configuration keeps the launch path.  It needs every workgroup resident at once:
 // one per CU, sized by the device's CU count - so only ONE context per device and process may run it (two would each
 // hold part of the CUs and time each other out), and nothing in here is fatal: whatever fails leaves the launch path.
+constexpr int EB_STAMP_WORDS = 3 * 10 * 8 * 16;
+static unsigned long long* g_eb_stamps = nullptr;      // diagnostics of the batch codebook loop (FT_EB_STAMPS)
 constexpr int ENG_MAX_STRIKES = 2;      // hand-off time-outs after which a context stops using the engine
 static std::mutex g_eng_mu;
 static std::map<int, ft_ctx*> g_eng_owner;      // device -> the context whose engine runs there
 
 static void eng_release(ft_ctx* ctx) {
     void* eb[] = {ctx->eng_layers, ctx->eng_flayers, ctx->eng_gx /* pool: gxb, gg, gy, gqkv live in it */,
-                  ctx->eng_gpart, ctx->eng_fast_g, ctx->eng_ctl, ctx->eng_qkv0_tab};
+                  ctx->eng_gpart, ctx->eng_fast_g, ctx->eng_ctl, ctx->eng_qkv0_tab, ctx->engb_g};
     for (void* q : eb) if (q) hipFree(q);
     ctx->eng_layers = ctx->eng_flayers = nullptr;
     ctx->eng_gx = ctx->eng_gqkv = ctx->eng_gy = ctx->eng_gxb = ctx->eng_gg = ctx->eng_fast_g = ctx->eng_ctl = nullptr;
     ctx->eng_gpart = nullptr;
     ctx->eng_qkv0_tab = nullptr;
-    ctx->eng_on = ctx->eng_fast_on = false;
+    ctx->engb_g = nullptr;
+    ctx->eng_on = ctx->eng_fast_on = ctx->engb_on = false;
     if (ctx->eng_owner) {
         std::lock_guard<std::mutex> lk(g_eng_mu);
         auto it = g_eng_owner.find(ctx->device);
@@ -592,7 +596,30 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
         }
     }
     ctx->eng_fast_on = true;
+    // ---- the codebook loop of a lock-step batch (2..32 rows) as one launch: opt-in while it has no recovery of its own
+    if (getenv("FT_BATCH_ENGINE") && ctx->eng_relay && c.max_batch >= 2 && c.num_codebooks <= 10 && c.n_fast_layer <= 8) {
+        const size_t per_par = ((nLf + 1) * (size_t)EB_M * ENG_FD + nLf * (size_t)EB_M * (fqkvN + HDf + ENG_FD + ENG_FF_DIM) + (size_t)EB_M * ENG_FV);
+        ctx->engb_words = 2 * per_par + (size_t)c.num_codebooks * EB_M;
+        ctx->engb_words = (ctx->engb_words + 63) & ~(size_t)63;
+        ctx->engb_bytes = ctx->engb_words * 4 * 9;
+        ctx->engb_lds = engb_fast_lds_bytes((int)nLf, c.num_codebooks);
+        int occb = 0;
+        if (ctx->engb_lds <= lds_cap &&
+            hip_ok2(hipMalloc((void**)&ctx->engb_g, ctx->engb_bytes), "hipMalloc(batch hand-off pool)") &&
+            hip_ok2(hipMemset(ctx->engb_g, 0, ctx->engb_bytes), "hipMemset(batch hand-off pool)") &&
+            hip_ok2(hipFuncSetAttribute((const void*)fastb_engine_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->engb_lds),
+                    "hipFuncSetAttribute(fastb_engine_kernel)") &&
+            hip_ok2(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occb, (const void*)fastb_engine_kernel<10>, ENG_THREADS, ctx->engb_lds),
+                    "hipOccupancyMaxActiveBlocksPerMultiprocessor") && occb >= 1)
+        {
+            ctx->engb_on = true;
+            if (getenv("FT_EB_STAMPS") && !g_eb_stamps && hipMalloc((void**)&g_eb_stamps, EB_STAMP_WORDS * 8) == hipSuccess)
+                (void)hipMemset(g_eb_stamps, 0, EB_STAMP_WORDS * 8);
+        }
+        else if (ctx->engb_g) { hipFree(ctx->engb_g); ctx->engb_g = nullptr; }
+    }
     why = ctx->eng_xl ? "slow stack (one kv head per XCD) and codebook loop on the frame engine" : "slow stack and codebook loop on the frame engine";
+    if (ctx->engb_on) why += "; codebook loop of 2..32 lock-step rows as one launch (FT_BATCH_ENGINE, experimental)";
     return true;
 }
 
@@ -658,6 +685,55 @@ static bool eng_slow_ok(const Launch& L) {
 static bool eng_fast_ok(const Launch& L) {
     const ft_ctx* ctx = L.ctx;
     return ctx->eng_fast_on && !ctx->eng_suspended && L.M == 1 && !L.gemv_only && !ctx->prof;
+}
+static bool engb_ok(const Launch& L) {
+    const ft_ctx* ctx = L.ctx;
+    return ctx->engb_on && !ctx->eng_suspended && L.M >= 2 && L.M <= EB_M && !L.gemv_only && !ctx->prof;
+}
+
+// The codebook loop of one frame of a lock-step batch (rows m0 .. m0 + M) as one launch (batch_engine.h).
+static void enqueue_fastb_engine(Launch& L) {
+    ft_ctx* ctx = L.ctx;
+    const ft_ar_config& c = ctx->c;
+    const int m0 = L.m0, R = c.num_codebooks + 1;
+    const size_t nLf = c.n_fast_layer;
+    const size_t QKVN = (size_t)(c.fast_n_head + 2 * c.fast_n_local_heads) * c.fast_head_dim, HDf = (size_t)c.fast_n_head * c.fast_head_dim;
+    FastBEngP p{};
+    p.layers = ctx->eng_flayers; p.n_layer = c.n_fast_layer; p.ncb = c.num_codebooks; p.M = L.M;
+    p.eps = c.norm_eps; p.scale = (float)(1.0 / sqrt((double)c.fast_head_dim));
+    p.rope = ctx->frope; p.fast_norm = (const bf16_t*)ctx->fast_norm; p.fast_out = (const bf16_t*)ctx->fast_out;
+    p.fast_emb = (const bf16_t*)ctx->fast_emb;
+    p.hid = ctx->hid + (size_t)m0 * c.fast_dim; p.femb = ctx->femb + (size_t)m0 * c.fast_dim;
+    unsigned* g = ctx->engb_g;
+    p.gx = g; g += 2 * (nLf + 1) * (size_t)EB_M * ENG_FD;
+    p.gqkv = g; g += 2 * nLf * (size_t)EB_M * QKVN;
+    p.gy = g; g += 2 * nLf * (size_t)EB_M * HDf;
+    p.gxb = g; g += 2 * nLf * (size_t)EB_M * ENG_FD;
+    p.gg = g; g += 2 * nLf * (size_t)EB_M * ENG_FF_DIM;
+    p.glog = g; g += 2 * (size_t)EB_M * ENG_FV;
+    p.gcode = g;
+    p.ctl = ctx->eng_ctl;
+    p.rep_delta0 = (long)ctx->engb_words; p.rep_stride = (long)ctx->engb_words;
+    SampP s{};
+    s.logits = nullptr; s.ldl = ctx->fastV; s.V = ctx->fastV;
+    s.ctl = ctx->d_ctl + m0; s.tokn = ctx->d_tokn + (size_t)m0 * R; s.seq = ctx->d_seq + (size_t)m0 * R * ctx->cap;
+    s.cap = ctx->cap; s.nf = ctx->d_nf + m0; s.cb = 1; s.ncb = c.num_codebooks; s.sem_begin = c.semantic_begin_id;
+    s.im_end = c.im_end_id; s.cbsize = c.codebook_size; s.fast_emb = ctx->fast_emb;
+    s.femb = ctx->femb + (size_t)m0 * c.fast_dim; s.Df = c.fast_dim; s.noise = ctx->noise;
+    s.noise_row_len = ctx->noise_row_len; s.noise_rows = ctx->noise_rows; s.noise_off = 0; s.last = 0;
+    s.tok = ctx->d_tok + (size_t)m0 * R; s.pos = ctx->d_pos + m0; s.done = ctx->d_done + m0;
+    p.samp = s;
+    p.noise_cb_stride = ctx->fastV; p.noise_off1 = c.vocab_size;
+    p.stamps = g_eb_stamps;
+    fastb_engine_kernel<10><<<ENG_NB, ENG_THREADS, ctx->engb_lds, L.s>>>(p);
+    L.chk();
+}
+// diagnostics: the in-kernel time stamps of the last batch codebook-loop launch (FT_EB_STAMPS set at context creation)
+extern "C" int32_t ft_test_eb_stamps(unsigned long long* out, int32_t n) {
+    if (!g_eb_stamps) return 0;
+    const int m = n < EB_STAMP_WORDS ? n : EB_STAMP_WORDS;
+    if (hipMemcpy(out, g_eb_stamps, (size_t)m * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return m;
 }
 
 // The whole codebook loop of one frame (steps 0 .. num_codebooks-1 with their draws) as one launch; runs after the
@@ -1169,6 +1245,7 @@ static void enqueue_frame_tail(Launch& L) {
     enqueue_head<WT, ROUND>(L);
     enqueue_sample<WT, ROUND>(L, 0, ncb == 1);
     if (ROUND == RND_BF16 && eng_fast_ok(L)) { enqueue_fast_engine(L); return; }
+    if (ROUND == RND_BF16 && engb_ok(L)) { enqueue_fastb_engine(L); return; }
     for (int cb = 0; cb < ncb; ++cb) enqueue_fast_step<WT, ROUND>(L, cb);
 }
 
@@ -1527,7 +1604,7 @@ extern "C" void ft_ar_kv_free(ft_ctx* ctx, ft_kv_snapshot* snap) {
 
 // the captured grids depend on the batch width, on the KV split count and on whether the frame engine serves the frame
 static int graph_key(const ft_ctx* ctx, int M, int frames) {
-    const bool eng = (ctx->eng_on || ctx->eng_fast_on) && !ctx->eng_suspended;
+    const bool eng = (ctx->eng_on || ctx->eng_fast_on || ctx->engb_on) && !ctx->eng_suspended;
     return (M * 64 + ctx->nsplit) + (frames > 1 ? frames * (1 << 20) : 0) + (eng ? (1 << 28) : 0);
 }
 
@@ -1700,6 +1777,7 @@ static ft_status eng_recover(ft_ctx* ctx, bool* aborted) {
     if (ctx->eng_gx) FT_HIP(ctx, hipMemsetAsync(ctx->eng_gx, 0, ctx->eng_pool_bytes, ctx->stream));
     if (ctx->eng_gpart) FT_HIP(ctx, hipMemsetAsync(ctx->eng_gpart, 0, ctx->eng_gpart_bytes, ctx->stream));
     if (ctx->eng_fast_g) FT_HIP(ctx, hipMemsetAsync(ctx->eng_fast_g, 0, ctx->eng_fast_bytes, ctx->stream));
+    if (ctx->engb_g) FT_HIP(ctx, hipMemsetAsync(ctx->engb_g, 0, ctx->engb_bytes, ctx->stream));
     FT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // (epoch is a stack word)
     char buf[256];
     if (ctx->eng_strikes >= ENG_MAX_STRIKES) {

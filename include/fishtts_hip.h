@@ -191,6 +191,10 @@ const char* ft_ar_frame_path(const ft_ctx* ctx);
 /* Test hook: workgroup `wg` of the next slow-stack (which = 0) or codebook-loop (which = 1) engine launch publishes
  * nothing, so the launch times out (one shot).  Exercises the recovery described above. */
 ft_status ft_test_engine_fault(ft_ctx* ctx, int32_t which, int32_t wg);
+/* Diagnostics, no reference counterpart: the in-kernel time stamps (100 MHz ticks) of the last launch of the experimental
+ * batch codebook loop (FT_BATCH_ENGINE and FT_EB_STAMPS set when the context was created; tools/batch_engine_probe.py).
+ * Returns the number of words copied, 0 when there are none. */
+int32_t ft_test_eb_stamps(unsigned long long* out, int32_t n);
 /* Test hook: one draw of the sampling kernel (inference.py:30-80) on caller-supplied logits.
  * cb = 0 draws from `vocab_size` logits, cb >= 1 from min(1024, codebook_size); window is the
  * (num_codebooks+1) x 16 penalty window of inference.py:187-191 or NULL (no penalty); q the Exp(1)

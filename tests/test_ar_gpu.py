@@ -362,13 +362,17 @@ def test_batch32_mixed_lengths_equals_single(monkeypatch, precision):
     eng.close()
 
 
-@pytest.mark.parametrize("B", [8, 19])
-def test_wide_batch_vs_oracle(B):
+@pytest.mark.parametrize("B,batch_engine", [(8, False), (19, False), (19, True), (32, True)])
+def test_wide_batch_vs_oracle(monkeypatch, B, batch_engine):
     """Lock-step batches of >= 8 utterances run every Linear as an M-row MFMA GEMM (skinny split-K kernel), which sums
     in a different order than the single-utterance GEMV: each utterance must follow the oracle up to a decision whose
     top-1/top-2 margin is inside the bf16 evaluation-order tolerance."""
     shape = medium_shape()
+    if batch_engine:
+        # the codebook loop of the whole batch as ONE persistent launch (batch_engine.h; opt-in): same judgement
+        monkeypatch.setenv("FT_BATCH_ENGINE", "1")
     eng, orc = make_pair(shape, "bf16", std=0.05, max_batch=B)
+    assert ("FT_BATCH_ENGINE" in eng.frame_path()) == batch_engine, eng.frame_path()
     kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
     sp = eng._sampling(0.7, 1e-6, 1.1)
     prompts = [make_prompt(shape, 9 + (3 * i) % 11, seed=300 + i, n_vq=i % 4) for i in range(B)]
@@ -389,6 +393,7 @@ def test_wide_batch_vs_oracle(B):
             assert _margin_ok(taps, col - p.shape[1], row, 0.03 * scale), f"utterance {i} diverged at {div}\n{got}\n{want}"
         checked += 1
     assert checked >= 7
+    assert eng.engine_state()[1] == 0, eng.engine_state()          # no hand-off timed out
     eng.close()
 
 
