@@ -447,6 +447,29 @@ static void eng_release(ft_ctx* ctx) {
     }
 }
 
+// One 512-thread workgroup of `fn` with `lds` bytes of dynamic LDS on one CU: computed from the kernel's own attributes -
+// waves per SIMD = 512 registers / the wave's (gfx950: one 512-entry file per SIMD lane, allocated in steps of 8), four SIMDs,
+// eight waves to place.  hipOccupancyMaxActiveBlocksPerMultiprocessor is only logged: measured on this runtime it answers 0
+// or 1 for the SAME kernel and attributes depending on what the process ran before (it then budgets 256 registers per lane),
+// and a false 0 would silently cost the engine.  Should the answer here ever be wrong the other way, the launches time out
+// and the recovery turns the engine off after ENG_MAX_STRIKES.
+static bool eng_fits_cu(const void* fn, size_t lds, size_t lds_cap, const char* name, std::string& why) {
+    hipFuncAttributes fa{};
+    const hipError_t fe = hipFuncGetAttributes(&fa, fn);
+    if (fe != hipSuccess) { (void)hipGetLastError(); why = std::string("hipFuncGetAttributes: ") + hipGetErrorString(fe); return false; }
+    const int regs = std::max(fa.numRegs, 1), per_simd = 512 / (((regs + 7) / 8) * 8);
+    const bool fits = per_simd * 4 >= ENG_THREADS / 64 && lds + fa.sharedSizeBytes <= lds_cap && fa.maxThreadsPerBlock >= ENG_THREADS;
+    if (getenv("FT_LOG")) {
+        int occ = -1;
+        const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, ENG_THREADS, lds);
+        if (oe != hipSuccess) (void)hipGetLastError();
+        fprintf(stderr, "fish_tts_amd: %s engine kernel: %d registers (%d waves per SIMD), %zu B of LDS of %zu: %s (the occupancy query says %d)\n",
+                name, fa.numRegs, per_simd, lds + fa.sharedSizeBytes, lds_cap, fits ? "fits a CU" : "does not fit a CU", occ);
+    }
+    if (!fits) why = std::string("a ") + name + " workgroup does not fit one CU (registers / LDS)";
+    return fits;
+}
+
 // false: `why` says what kept the engine off (allocations made so far are released by the caller)
 static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
     const ft_ar_config& c = ctx->c;
@@ -526,11 +549,8 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
     const void* slow_fn = ctx->eng_xl ? (const void*)slow_engine_kernel<2, 4, 6, 2, true> : (const void*)slow_engine_kernel<2, 4, 6, 2, false>;
     if (!hip_ok(hipFuncSetAttribute(slow_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->eng_lds_slow),
                 "hipFuncSetAttribute(slow_engine_kernel)")) return false;
-    // every workgroup must be resident at once: ask the runtime whether one fits a CU at all (registers, LDS, waves)
-    int occ = 0;
-    if (!hip_ok(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, slow_fn, ENG_THREADS, ctx->eng_lds_slow),
-                "hipOccupancyMaxActiveBlocksPerMultiprocessor")) return false;
-    if (occ < 1) { why = "a slow-stack workgroup does not fit one CU (occupancy query)"; return false; }
+    // every workgroup must be resident at once, one per CU: does one fit a CU at all (registers, LDS, waves)?
+    if (!eng_fits_cu(slow_fn, ctx->eng_lds_slow, lds_cap, "slow-stack", why)) return false;
     ctx->eng_on = true;
     why = ctx->eng_xl ? "slow stack on the frame engine (one kv head per XCD)" : "slow stack on the frame engine";
 
@@ -577,10 +597,7 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
     ctx->eng_lds_fast = std::max(ctx->eng_lds_fast, (size_t)82 * 1024);
     if (!hip_ok2(hipFuncSetAttribute((const void*)fast_engine_kernel<2, 2, 6, 10, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)ctx->eng_lds_fast), "hipFuncSetAttribute(fast_engine_kernel)")) return fast_off(w2);
-    occ = 0;
-    if (!hip_ok2(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)fast_engine_kernel<2, 2, 6, 10, 64>, ENG_THREADS,
-                                                              ctx->eng_lds_fast), "hipOccupancyMaxActiveBlocksPerMultiprocessor")) return fast_off(w2);
-    if (occ < 1) return fast_off("a codebook-loop workgroup does not fit one CU (occupancy query)");
+    if (!eng_fits_cu((const void*)fast_engine_kernel<2, 2, 6, 10, 64>, ctx->eng_lds_fast, lds_cap, "codebook-loop", w2)) return fast_off(w2);
     // layer 0's q k v of every codebook-embedding row a draw can select (codes < fastV): 4 MB at the s1-mini widths
     if (getenv("FT_NO_QKV0") == nullptr && c.num_codebooks > 2) {
         const size_t tb = (size_t)ctx->fastV * fqkvN * sizeof(bf16_t);
@@ -603,14 +620,13 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
         ctx->engb_words = (ctx->engb_words + 63) & ~(size_t)63;
         ctx->engb_bytes = ctx->engb_words * 4 * 9;
         ctx->engb_lds = engb_fast_lds_bytes((int)nLf, c.num_codebooks);
-        int occb = 0;
+        std::string wb;
         if (ctx->engb_lds <= lds_cap &&
             hip_ok2(hipMalloc((void**)&ctx->engb_g, ctx->engb_bytes), "hipMalloc(batch hand-off pool)") &&
             hip_ok2(hipMemset(ctx->engb_g, 0, ctx->engb_bytes), "hipMemset(batch hand-off pool)") &&
             hip_ok2(hipFuncSetAttribute((const void*)fastb_engine_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->engb_lds),
                     "hipFuncSetAttribute(fastb_engine_kernel)") &&
-            hip_ok2(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occb, (const void*)fastb_engine_kernel<10>, ENG_THREADS, ctx->engb_lds),
-                    "hipOccupancyMaxActiveBlocksPerMultiprocessor") && occb >= 1)
+            eng_fits_cu((const void*)fastb_engine_kernel<10>, ctx->engb_lds, lds_cap, "batch codebook-loop", wb))
         {
             ctx->engb_on = true;
             if (getenv("FT_EB_STAMPS") && !g_eb_stamps && hipMalloc((void**)&g_eb_stamps, EB_STAMP_WORDS * 8) == hipSuccess)
