@@ -579,19 +579,20 @@ def test_state_dict_with_extra_keys_loads_like_strict_false():
     eng.close()
 
 
-@pytest.mark.parametrize("tag,precision", [("f32", "fp32"), ("bf16", "bf16")])
-def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
-    """The real shapes (28+4 layers, V = 155 776): 17 frames the REFERENCE generated (fp32 and bf16, repetition penalty
-    1.0, tests/golden/make_golden_s1mini_tf.py).  For every k the engine prefills prompt + golden[:k] and yields frame k;
-    each of its eleven decisions is judged against the margin the oracle recorded for that very decision, so a legitimate
-    flip early on hides nothing behind it (the next k starts from the golden tokens again).  The slow logits of every
-    frame are compared with the reference's top-8 values.  fp32: every index equal (margin bound 1e-4 of the logit
-    range: the reference's own exact ties only); bf16: the evaluation-order tolerance 0.03 x range - the range being that
-    of the decision's own logit vector (the codebook heads' logits span another range than the vocabulary's)."""
+def _teacher_forced(g, pre, tag, precision, max_seq_len, min_judged=0.8, launch_path=False):
+    """Shared body of the teacher-forced reference comparisons: `g` an .npz written by tests/golden/make_golden_s1mini_tf*.py,
+    `pre` the key prefix of the block ("" or "p250." ...).  For every k the engine prefills prompt + golden[:k] and yields
+    frame k; each of its eleven decisions is judged against the margin the oracle recorded for that very decision, so a
+    legitimate flip early on hides nothing behind it (the next k starts from the golden tokens again).  The slow logits
+    of every frame are compared with the reference's top-8 values.  fp32: margin bound 1e-4 of the logit range (the
+    reference's own exact ties only); bf16: the evaluation-order tolerance 0.03 x range - the range being that of the
+    decision's own logit vector (the codebook heads' logits span another range than the vocabulary's).  Whenever frame k
+    came out as the reference's, ONE decode-loop step (bf16: the persistent frame engine unless launch_path) must yield
+    the reference's frame k + 1 under the same judgement: with repetition penalty 1.0 frame k + 1 is the same function of
+    prompt + golden[:k + 1] whether the prompt pass or the loop yields it."""
     from fish_tts_amd.ar_engine import ARHipEngine
     from tests.shapes import s1mini_shape
-    g = np.load(os.path.join(G, "ar_s1mini_tf.npz"))
-    shape = s1mini_shape()
+    shape = s1mini_shape(max_seq_len=max_seq_len)
     dtype = torch.float32 if precision == "fp32" else torch.bfloat16
     w = O.random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]), dtype=dtype,
                          loud=(int(g["loud_n"]), float(g["loud_factor"])))
@@ -599,18 +600,18 @@ def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
                       precision=precision, device=0, max_batch=1, max_new_tokens=8)
     eng.load_state_dict(w)
     del w
-    prompt, seq = g["prompt"], g[f"{tag}.seq"]
-    margins, top_idx, top_val = g[f"{tag}.margins"], g[f"{tag}.slow_top8"], g[f"{tag}.slow_top8_logits"]
-    scale = np.maximum(1.0, g[f"{tag}.scale"])       # largest |logit| of every decision's OWN logit vector (vocabulary / codebook head)
+    prompt, seq = g[f"{pre}prompt"], g[f"{pre}{tag}.seq"]
+    margins, top_idx, top_val = g[f"{pre}{tag}.margins"], g[f"{pre}{tag}.slow_top8"], g[f"{pre}{tag}.slow_top8_logits"]
+    scale = np.maximum(1.0, g[f"{pre}{tag}.scale"])       # largest |logit| of every decision's OWN logit vector (vocabulary / codebook head)
     T, n_new = prompt.shape[1], int(g["n_new"])
-    absmax = max(1.0, float(g[f"{tag}.logit_absmax"]))
+    absmax = max(1.0, float(g[f"{pre}{tag}.logit_absmax"]))
     rtol = 1e-4 if precision == "fp32" else 0.03
     ltol = (2e-3 if precision == "fp32" else 0.02) * absmax
     sp = eng._sampling(0.7, 1e-6, 1.0)
     flips, judged = [], 0
     dflips, djudged, dframes = [], 0, 0
     if precision == "bf16":
-        assert eng.engine_state()[0] == 3, eng.frame_path()      # the decode-loop frames below come from the frame engine
+        assert eng.engine_state()[0] == (0 if launch_path else 3), eng.frame_path()   # which path the decode-loop frames below come from
 
     def judge(frame, k, flips_):
         n_ok = 0
@@ -630,10 +631,6 @@ def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
         logits, _ = eng.debug_state()
         assert np.max(np.abs(logits[top_idx[k]] - top_val[k])) <= ltol, (k, logits[top_idx[k]], top_val[k])
         judged += judge(first, k, flips)
-        # The DECODE-LOOP frame (bf16: the persistent frame engine) judged directly against the reference: with
-        # repetition penalty 1.0 frame k + 1 is the same function of prompt + golden[:k + 1] whether the prompt pass or the
-        # loop yields it, so whenever frame k came out as the reference's, one decode step must yield the reference's
-        # frame k + 1 - each decision within the margin the reference recorded for it, the slow logits within ltol.
         if k + 1 < n_new and np.array_equal(first, seq[:, T + k]):
             frames, cnt = eng.decode(1, [sp], poll=1)
             assert cnt[0] == 1
@@ -641,21 +638,76 @@ def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
             assert np.max(np.abs(logits[top_idx[k + 1]] - top_val[k + 1])) <= ltol, (k + 1, logits[top_idx[k + 1]], top_val[k + 1])
             djudged += judge(frames[0, 0], k + 1, dflips)
             dframes += 1
-    print(f"{tag}: {judged} decisions equal, legitimate flips (frame, row, reference margin) at {flips}")
-    print(f"{tag}: decode loop: {dframes} frames judged, {djudged} decisions equal, legitimate flips at {dflips}")
+    print(f"{pre}{tag}: {judged} decisions equal, legitimate flips (frame, row, reference margin) at {flips}")
+    print(f"{pre}{tag}: decode loop: {dframes} frames judged, {djudged} decisions equal, legitimate flips at {dflips}")
     assert dframes >= (n_new - 1) // 2, dframes
-    assert djudged >= 0.8 * dframes * seq.shape[0]
-    if precision == "bf16":
+    assert djudged >= min_judged * dframes * seq.shape[0]
+    if precision == "bf16" and not launch_path:
         assert eng.engine_state()[1] == 0
-    # (the fixture's weights: the reference's own initializer_range 0.02 - at 0.05 the two REFERENCE precisions sit 3-9 % of
-    # the logit range apart after 28 + 4 layers, at 0.02 0.7 % - plus a few loud head rows (oracle.ar.random_weights) for
-    # margins like a trained model's: 154 of the 170 bf16 decisions clear the tolerance of 0.03 x the decision's own logit
-    # range (a flip at 0.021 x range was seen); with iid rows at 0.05, 70 of 170 sat inside 0.03 x range.  A flip ends the judging of its frame only, the next
-    # frame is forced back onto the golden tokens.)
-    assert judged >= 0.8 * n_new * seq.shape[0]
+    assert judged >= min_judged * n_new * seq.shape[0]
     if precision == "fp32":
         assert len(flips) <= 1
     eng.close()
+
+
+@pytest.mark.parametrize("tag,precision", [("f32", "fp32"), ("bf16", "bf16")])
+def test_s1mini_teacher_forced_every_decision_vs_reference(tag, precision):
+    """The real shapes (28+4 layers, V = 155 776): 17 frames the REFERENCE generated (fp32 and bf16, repetition penalty
+    1.0, tests/golden/make_golden_s1mini_tf.py) after a 24-token prompt: cached positions 24..41.
+    (the fixture's weights: the reference's own initializer_range 0.02 - at 0.05 the two REFERENCE precisions sit 3-9 % of
+    the logit range apart after 28 + 4 layers, at 0.02 0.7 % - plus a few loud head rows (oracle.ar.random_weights) for
+    margins like a trained model's: 154 of the 170 bf16 decisions clear the tolerance of 0.03 x the decision's own logit
+    range (a flip at 0.021 x range was seen); with iid rows at 0.05, 70 of 170 sat inside 0.03 x range.  A flip ends the
+    judging of its frame only, the next frame is forced back onto the golden tokens.)"""
+    _teacher_forced(np.load(os.path.join(G, "ar_s1mini_tf.npz")), "", tag, precision, max_seq_len=128)
+
+
+@pytest.mark.parametrize("tag,precision", [("f32", "fp32"), ("bf16", "bf16")])
+@pytest.mark.parametrize("block,min_judged", [("p250", 0.9), ("p780", 0.6)])
+def test_s1mini_teacher_forced_at_the_positions_the_bench_runs(monkeypatch, block, min_judged, tag, precision):
+    """The same judgement at the cached positions the headline workloads decode at (tests/golden/
+    make_golden_s1mini_tf_long.py, reference-generated): a 250-position prompt (the end of the bench's 10 s utterance,
+    positions 48..263) and a 780-position one (configs[4]: 30 s reference + text, positions 777..992), mostly VQ
+    columns, 8 frames each.  The prompt pass runs the MFMA prefill over the long prompt; the decode-loop step attends
+    over 250 / 780 cached positions (bf16: inside the frame engine's 32-way XCD-local split).  p250's reference margins all
+    clear the tolerance (every decision is judged); p780's loud rows collide more often (about 20 % of its decisions sit
+    inside 0.03 x range in the reference itself), hence the lower judged floor there."""
+    g = np.load(os.path.join(G, "ar_s1mini_tf_long.npz"))
+    _teacher_forced(g, block + ".", tag, precision, max_seq_len=int(g["max_seq_len"]), min_judged=min_judged)
+
+
+@pytest.mark.parametrize("block", ["p250", "p780"])
+def test_s1mini_teacher_forced_long_positions_on_the_launch_path(monkeypatch, block):
+    """bf16 with FT_NO_ENGINE: the decode-loop step of the launch path (split-KV attn_decode_kernel + the merge inside
+    the Wo GEMV) at 250 / 780 cached positions, judged against the reference fixture - the path every configuration
+    outside the frame engine's gate takes."""
+    monkeypatch.setenv("FT_NO_ENGINE", "1")
+    g = np.load(os.path.join(G, "ar_s1mini_tf_long.npz"))
+    _teacher_forced(g, block + ".", "bf16", "bf16", max_seq_len=int(g["max_seq_len"]),
+                    min_judged=0.9 if block == "p250" else 0.6, launch_path=True)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("Lp", [300, 900])
+def test_launch_path_decode_at_long_context_vs_oracle(monkeypatch, precision, Lp):
+    """Single-slot decode on the launch path at the s1-mini widths (2+2 layers so the oracle follows in seconds) after
+    a 300- / 900-position prompt: the split-KV decode attention (8-32 splits at these lengths) against the ORACLE, not
+    against another split count.  fp32: indices equal unless the oracle's own margin is an exact tie; bf16: a divergence
+    must sit inside 0.03 x the logit range of the oracle's decision."""
+    monkeypatch.setenv("FT_NO_ENGINE", "1")
+    shape = medium_shape(max_seq_len=1024)
+    eng, orc = make_pair(shape, precision, std=0.05, max_new_tokens=16)
+    prompt = make_prompt(shape, Lp, seed=40 + Lp, n_vq=Lp - 40)
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    got = eng.generate(prompt.numpy(), 8, **kw)
+    taps = []
+    want = orc.generate(prompt.clone(), 8, frame_taps=taps, **kw).numpy()
+    eng.close()
+    div = first_divergence(got, want)
+    if div is not None:
+        col, row = div
+        scale = max(1.0, float(taps[0][0].float().abs().max()))
+        assert _margin_ok(taps, col - Lp, row, (1e-4 if precision == "fp32" else 0.03) * scale), (div, got[:, Lp:], want[:, Lp:])
 
 
 def test_batch32_wide_path_at_full_depth_vs_oracle_and_single_runs():
