@@ -82,7 +82,6 @@ SYMBOLS = {
     "ft_ar_engine_state": (C.c_int32, [_P, _P, _P, _P]),
     "ft_ar_frame_path": (C.c_char_p, [_P]),
     "ft_test_engine_fault": (C.c_int32, [_P, C.c_int32, C.c_int32]),
-    "ft_test_eb_stamps": (C.c_int32, [C.POINTER(C.c_uint64), C.c_int32]),
     "ft_test_sample": (C.c_int32, [_P, _P, C.c_int32, C.POINTER(ft_sampling), _P, _P, _P]),
 }
 

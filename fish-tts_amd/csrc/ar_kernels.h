@@ -23,6 +23,9 @@ enum { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2 };
 // One wave owns R consecutive rows; lanes stride K in 16-byte pieces (1 KiB per wave
 // instruction, fully coalesced); all row loads are issued before anything is consumed.
 // ------------------------------------------------------------------------------------------
+// Octet-major activation form of the lock-step batch GEMMs (wide_kernels.h): element (row m, column k) of Xo[k / 8][ldm][8]
+__device__ __host__ __forceinline__ size_t xo_index(int m, int k, int ldm) { return ((size_t)(k >> 3) * ldm + m) * 8 + (k & 7); }
+
 struct GemvP {
     const void* W;
     const void* bias;
@@ -307,6 +310,8 @@ struct EmbedP {
     float* x;
     int ldx, D, ncb, cbsize, vocab, sem_begin, sem_end, scale;
     float inv_div;  // (float)sqrt(ncb+1), used as a divisor
+    bf16_t* xo;     // optional octet-major bf16 copy of x (lock-step batches: the residual stream of wide_kernels.h)
+    int xo_ldm;
 };
 
 template <typename WT, int ROUND>
@@ -341,6 +346,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedP p) {
         float x = rb<ROUND>(ld_elem(emb, (size_t)t0 * p.D + d) + vq);
         if (p.scale && is_vq) x = rb<ROUND>(x / p.inv_div);
         p.x[(size_t)m * p.ldx + d] = x;
+        if (p.xo) p.xo[xo_index(m, d, p.xo_ldm)] = f32_to_bf16_bits(x);
     }
 }
 
@@ -373,6 +379,7 @@ struct AttnP {
     // for every position (kv_only), pass 2 attends reading every key from the cache (no_append)
     int row_is_pos, kv_only, no_append;
     bf16_t* y_bf;    // optional bf16 copy of y
+    int y_xo_ldm;    // > 0: y_bf is octet-major Xo[H * hd / 8][y_xo_ldm][8] (wide_kernels.h), and y may be null
     bf16_t* q_out;   // kv_only pass: the normalised, rotated queries [row][H*hd] for the MFMA prompt attention
 };
 
@@ -535,8 +542,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
         const int head = kvh * G + g;
         if (p.nsplit == 1) {
             const float yo = rb<ROUND>(O / L);
-            p.y[(size_t)m * p.ldy + head * hd + e] = yo;
-            if (p.y_bf) p.y_bf[(size_t)m * p.ldy + head * hd + e] = f32_to_bf16_bits(yo);
+            if (p.y) p.y[(size_t)m * p.ldy + head * hd + e] = yo;
+            if (p.y_bf) p.y_bf[p.y_xo_ldm ? xo_index(m, head * hd + e, p.y_xo_ldm) : (size_t)m * p.ldy + head * hd + e] = f32_to_bf16_bits(yo);
         } else {
             const size_t pi = ((size_t)m * p.H + head) * p.nsplit + split;
             p.part_o[pi * hd + e] = O;
@@ -622,10 +629,12 @@ __global__ __launch_bounds__(256) void attn_combine_rows_kernel(AttnP a) {
         float yv[4];
         merge_splits4(a, base, e, yv);
         const float y0 = rb<ROUND>(yv[0]), y1 = rb<ROUND>(yv[1]), y2 = rb<ROUND>(yv[2]), y3 = rb<ROUND>(yv[3]);
-        float* y = a.y + (size_t)m * a.ldy + k;
-        y[0] = y0; y[1] = y1; y[2] = y2; y[3] = y3;
+        if (a.y) {
+            float* y = a.y + (size_t)m * a.ldy + k;
+            y[0] = y0; y[1] = y1; y[2] = y2; y[3] = y3;
+        }
         if (a.y_bf) {
-            bf16_t* yb = a.y_bf + (size_t)m * a.ldy + k;
+            bf16_t* yb = a.y_bf + (a.y_xo_ldm ? xo_index(m, k, a.y_xo_ldm) : (size_t)m * a.ldy + k);   // k % 4 == 0: inside one octet
             yb[0] = f32_to_bf16_bits(y0); yb[1] = f32_to_bf16_bits(y1); yb[2] = f32_to_bf16_bits(y2); yb[3] = f32_to_bf16_bits(y3);
         }
     }
@@ -650,6 +659,7 @@ struct FastAttnP {
     int H, Hkv, hd, ncb;
     float eps, scale;
     bf16_t* y_bf;       // optional bf16 copy of y (operand of the MFMA Wo GEMM in wide batches)
+    int y_xo_ldm;       // > 0: y_bf is octet-major Xo[H * hd / 8][y_xo_ldm][8] (wide_kernels.h), and y may be null
 };
 
 constexpr int FAST_MAXCB = 16;
@@ -753,8 +763,8 @@ __global__ __launch_bounds__(64) void fast_attn_kernel(FastAttnP a, float* y, in
         const int d = lane + 64 * e;
         if (d < hd) {
             const float yo = rb<ROUND>(o[e]);
-            y[(size_t)m * ldy + (size_t)h * hd + d] = yo;
-            if (a.y_bf) a.y_bf[(size_t)m * ldy + (size_t)h * hd + d] = f32_to_bf16_bits(yo);
+            if (y) y[(size_t)m * ldy + (size_t)h * hd + d] = yo;
+            if (a.y_bf) a.y_bf[a.y_xo_ldm ? xo_index(m, h * hd + d, a.y_xo_ldm) : (size_t)m * ldy + (size_t)h * hd + d] = f32_to_bf16_bits(yo);
         }
     }
 }
@@ -795,6 +805,8 @@ struct SampP {
     int* tok;         // [M][ncb+1] input column of the next slow step
     int* pos;
     int* done;
+    bf16_t* femb_xo;  // optional octet-major bf16 copy of femb (lock-step batches, wide_kernels.h)
+    int femb_ldm;
 };
 
 __device__ __forceinline__ uint32_t order_key(float f) {
@@ -883,7 +895,11 @@ __device__ __forceinline__ void finish_draw(const SampP& p, const int m, const i
         tokn[p.cb + 1] = code;
     }
     const WT* fe = reinterpret_cast<const WT*>(p.fast_emb);
-    for (int d = tid; d < p.Df; d += T) p.femb[(size_t)m * p.Df + d] = ld_elem(fe, (size_t)code * p.Df + d);
+    for (int d = tid; d < p.Df; d += T) {
+        const float v = ld_elem(fe, (size_t)code * p.Df + d);
+        p.femb[(size_t)m * p.Df + d] = v;
+        if (p.femb_xo) p.femb_xo[xo_index(m, d, p.femb_ldm)] = f32_to_bf16_bits(v);
+    }
     if (p.last) {
         // a slot that has emitted <|im_end|> (or is parked) stays frozen while the rest of the lock-step batch
         // goes on: its position, frame count and frame store no longer move

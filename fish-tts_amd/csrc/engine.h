@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/fishtts_hip.h"
+#include "../../include/fishtts_hip_test.h"
 #include "common.h"
 
 namespace ft {
@@ -66,13 +67,11 @@ struct ft_ctx {
     // MFMA prefill workspace (bf16 precision): S = max_seq_len rows
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_y = nullptr;
     ft::bf16_t *pf_xn = nullptr, *pf_ybf = nullptr, *pf_g = nullptr, *pf_qbf = nullptr;
-    // lock-step batches of >= wide_min utterances run every Linear on the MFMA skinny kernel (bf16 operand copies)
-    ft::bf16_t *mb_xn = nullptr, *mb_ybf = nullptr, *mb_g = nullptr;
-    // fused RMSNorm of the wide path: exact bf16 copy of the residual stream + per-block partial sums of squares
-    ft::bf16_t* mb_xb = nullptr;
-    float* mb_ss = nullptr;   // [max(dim, fast_dim) / 16][max_batch]
-    bool wide_fuse = false;
-    int wide_fuse_max = 16;   // largest lock-step batch that takes the fused-norm GEMMs
+    // lock-step batches of >= wide_min utterances run every Linear as one MFMA launch with the row operations folded in
+    // (wide_kernels.h); their activations are octet-major bf16 Xo[width / 8][xo_ldm][8]: residual streams of the slow and
+    // the fast stack, the drawn codes' embeddings, the attention output, the SwiGLU vector
+    ft::bf16_t *xo_x = nullptr, *xo_xf = nullptr, *xo_femb = nullptr, *xo_y = nullptr, *xo_g = nullptr;
+    int xo_ldm = 0;     // max_batch rounded up to the 16-row MFMA tile
     int wide_min = 5;   // measured: the MFMA path wins from 5 rows (B=5: 2.79 vs 3.33 ms per frame), B <= 4 keeps the bit-exact multi-row GEMV
     bool wide_ok = false;
     bool prefill_v0 = false;
@@ -112,10 +111,6 @@ struct ft_ctx {
     // A hand-off that timed out (ENG_CTL_ABORT) is survivable: the host clears the control words and the hand-off pools,
     // redoes the affected frames on the launch path (eng_suspended) and turns the engine off for this context after
     // ENG_MAX_STRIKES such events.  eng_why says, in words, which frame path this context takes and why.
-    // batch form of the codebook loop (batch_engine.h): 2..32 lock-step rows, opt-in (FT_BATCH_ENGINE)
-    bool engb_on = false;
-    unsigned* engb_g = nullptr;
-    size_t engb_words = 0, engb_bytes = 0, engb_lds = 0;
     bool eng_suspended = false;
     int eng_strikes = 0, eng_last_where = 0;
     bool eng_owner = false;         // this context holds its device's engine slot (one engine context per device and process)

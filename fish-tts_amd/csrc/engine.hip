@@ -3,7 +3,7 @@
 #include "engine.h"
 #include "ar_kernels.h"
 #include "frame_engine.h"
-#include "batch_engine.h"
+#include "wide_kernels.h"
 #include "codec_kernels.h"
 
 #include <math.h>
@@ -201,22 +201,21 @@ static ft_status ar_alloc(ft_ctx* ctx) {
         FT_TRY(dmalloc(ctx, &ctx->pf_ybf, S * c.n_head * c.head_dim));
         FT_TRY(dmalloc(ctx, &ctx->pf_g, S * c.intermediate_size));
         FT_TRY(dmalloc(ctx, &ctx->pf_qbf, S * c.n_head * c.head_dim));
-        // wide lock-step batches: no fast-layer f32 bias copies exist, and the fast widths must fit the MFMA tiles
-        ctx->wide_ok = !getenv("FT_NO_WIDE") && !c.fast_attention_qkv_bias && !c.fast_attention_o_bias &&
-                       c.fast_dim % 32 == 0 && (c.fast_n_head * c.fast_head_dim) % 32 == 0 && c.fast_intermediate_size % 32 == 0;
+        // wide lock-step batches (wide_kernels.h): no fast-layer f32 bias copies exist; every contraction width must be one
+        // the kernel is instantiated for, every output width a whole number of its tiles
+        const int HD = c.n_head * c.head_dim, HDf = c.fast_n_head * c.fast_head_dim;
+        ctx->wide_ok = !getenv("FT_NO_WIDE") && !c.fast_attention_qkv_bias && !c.fast_attention_o_bias && c.fast_dim == c.dim &&
+                       wide_k_ok(c.dim) && wide_k_ok(HD) && wide_k_ok(c.intermediate_size) && wide_k_ok(HDf) && wide_k_ok(c.fast_intermediate_size) &&
+                       qkvN % 32 == 0 && fqkvN % 32 == 0 && c.intermediate_size % 16 == 0 && c.fast_intermediate_size % 16 == 0 &&
+                       c.dim % 16 == 0 && c.vocab_size % 32 == 0 && ctx->fastV % 16 == 0;
         if (ctx->wide_ok) {
-            FT_TRY(dmalloc(ctx, &ctx->mb_xn, M * (size_t)std::max(c.dim, c.fast_dim)));
-            FT_TRY(dmalloc(ctx, &ctx->mb_ybf, M * (size_t)std::max(c.n_head * c.head_dim, c.fast_n_head * c.fast_head_dim)));
-            FT_TRY(dmalloc(ctx, &ctx->mb_g, M * (size_t)std::max(c.intermediate_size, c.fast_intermediate_size)));
-            FT_TRY(dmalloc(ctx, &ctx->mb_xb, M * (size_t)std::max(c.dim, c.fast_dim)));
-            FT_TRY(dmalloc(ctx, &ctx->mb_ss, M * (size_t)(std::max(c.dim, c.fast_dim) / 16 + 1)));
-            // the norm rides inside the consumer GEMM only where every Linear of a layer takes the skinny kernel, and only up
-            // to 16 rows: measured +8 % at B=8, +5 % at B=16, -4 % at B=32 (the in-register normalisation of two row tiles
-            // costs more VALU time than the removed launches)
-            auto sk = [](int k) { return k % 128 == 0; };
-            ctx->wide_fuse = sk(c.dim) && sk(c.n_head * c.head_dim) && sk(c.intermediate_size) &&
-                             sk(c.fast_dim) && sk(c.fast_n_head * c.fast_head_dim) && sk(c.fast_intermediate_size) &&
-                             c.dim % 16 == 0 && c.fast_dim % 16 == 0 && c.max_batch <= 128;
+            ctx->xo_ldm = (int)((M + 15) / 16 * 16);
+            const size_t P = ctx->xo_ldm;
+            FT_TRY(dmalloc(ctx, &ctx->xo_x, P * c.dim));
+            FT_TRY(dmalloc(ctx, &ctx->xo_xf, P * c.fast_dim));
+            FT_TRY(dmalloc(ctx, &ctx->xo_femb, P * c.fast_dim));
+            FT_TRY(dmalloc(ctx, &ctx->xo_y, P * (size_t)std::max(HD, HDf)));
+            FT_TRY(dmalloc(ctx, &ctx->xo_g, P * (size_t)std::max(c.intermediate_size, c.fast_intermediate_size)));
         }
     }
     const size_t nchunk = ((size_t)c.vocab_size + 1023) / 1024;
@@ -280,7 +279,7 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     int* ibufs[] = {ctx->d_pos, ctx->d_tok, ctx->d_tokn, ctx->d_seq, ctx->d_nf, ctx->d_done, ctx->d_prompt};
     for (int* b : ibufs) if (b) hipFree(b);
     if (ctx->d_ctl) hipFree(ctx->d_ctl);
-    { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g, ctx->mb_xn, ctx->mb_ybf, ctx->mb_g, ctx->mb_xb, ctx->mb_ss, ctx->pf_qbf}; for (void* q : pf) if (q) hipFree(q); }
+    { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g, ctx->xo_x, ctx->xo_xf, ctx->xo_femb, ctx->xo_y, ctx->xo_g, ctx->pf_qbf}; for (void* q : pf) if (q) hipFree(q); }
     for (auto& l : ctx->layers) { if (l.bqkv_f32) hipFree(l.bqkv_f32); if (l.bo_f32) hipFree(l.bo_f32); }
     if (ctx->samp_cut) hipFree(ctx->samp_cut);
     if (ctx->samp_chunk_cnt) hipFree(ctx->samp_chunk_cnt);
@@ -423,22 +422,19 @@ static ft_status ar_finalize(ft_ctx* ctx) {
 // widths at any depth); every other configuration keeps the launch path.  It needs every workgroup resident at once:
 // one per CU, sized by the device's CU count - so only ONE context per device and process may run it (two would each
 // hold part of the CUs and time each other out), and nothing in here is fatal: whatever fails leaves the launch path.
-constexpr int EB_STAMP_WORDS = 3 * 10 * 8 * 16;
-static unsigned long long* g_eb_stamps = nullptr;      // diagnostics of the batch codebook loop (FT_EB_STAMPS)
 constexpr int ENG_MAX_STRIKES = 2;      // hand-off time-outs after which a context stops using the engine
 static std::mutex g_eng_mu;
 static std::map<int, ft_ctx*> g_eng_owner;      // device -> the context whose engine runs there
 
 static void eng_release(ft_ctx* ctx) {
     void* eb[] = {ctx->eng_layers, ctx->eng_flayers, ctx->eng_gx /* pool: gxb, gg, gy, gqkv live in it */,
-                  ctx->eng_gpart, ctx->eng_fast_g, ctx->eng_ctl, ctx->eng_qkv0_tab, ctx->engb_g};
+                  ctx->eng_gpart, ctx->eng_fast_g, ctx->eng_ctl, ctx->eng_qkv0_tab};
     for (void* q : eb) if (q) hipFree(q);
     ctx->eng_layers = ctx->eng_flayers = nullptr;
     ctx->eng_gx = ctx->eng_gqkv = ctx->eng_gy = ctx->eng_gxb = ctx->eng_gg = ctx->eng_fast_g = ctx->eng_ctl = nullptr;
     ctx->eng_gpart = nullptr;
     ctx->eng_qkv0_tab = nullptr;
-    ctx->engb_g = nullptr;
-    ctx->eng_on = ctx->eng_fast_on = ctx->engb_on = false;
+    ctx->eng_on = ctx->eng_fast_on = false;
     if (ctx->eng_owner) {
         std::lock_guard<std::mutex> lk(g_eng_mu);
         auto it = g_eng_owner.find(ctx->device);
@@ -613,29 +609,7 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
         }
     }
     ctx->eng_fast_on = true;
-    // ---- the codebook loop of a lock-step batch (2..32 rows) as one launch: opt-in while it has no recovery of its own
-    if (getenv("FT_BATCH_ENGINE") && ctx->eng_relay && c.max_batch >= 2 && c.num_codebooks <= 10 && c.n_fast_layer <= 8) {
-        const size_t per_par = ((nLf + 1) * (size_t)EB_M * ENG_FD + nLf * (size_t)EB_M * (fqkvN + HDf + ENG_FD + ENG_FF_DIM) + (size_t)EB_M * ENG_FV);
-        ctx->engb_words = 2 * per_par + (size_t)c.num_codebooks * EB_M;
-        ctx->engb_words = (ctx->engb_words + 63) & ~(size_t)63;
-        ctx->engb_bytes = ctx->engb_words * 4 * 9;
-        ctx->engb_lds = engb_fast_lds_bytes((int)nLf, c.num_codebooks);
-        std::string wb;
-        if (ctx->engb_lds <= lds_cap &&
-            hip_ok2(hipMalloc((void**)&ctx->engb_g, ctx->engb_bytes), "hipMalloc(batch hand-off pool)") &&
-            hip_ok2(hipMemset(ctx->engb_g, 0, ctx->engb_bytes), "hipMemset(batch hand-off pool)") &&
-            hip_ok2(hipFuncSetAttribute((const void*)fastb_engine_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->engb_lds),
-                    "hipFuncSetAttribute(fastb_engine_kernel)") &&
-            eng_fits_cu((const void*)fastb_engine_kernel<10>, ctx->engb_lds, lds_cap, "batch codebook-loop", wb))
-        {
-            ctx->engb_on = true;
-            if (getenv("FT_EB_STAMPS") && !g_eb_stamps && hipMalloc((void**)&g_eb_stamps, EB_STAMP_WORDS * 8) == hipSuccess)
-                (void)hipMemset(g_eb_stamps, 0, EB_STAMP_WORDS * 8);
-        }
-        else if (ctx->engb_g) { hipFree(ctx->engb_g); ctx->engb_g = nullptr; }
-    }
     why = ctx->eng_xl ? "slow stack (one kv head per XCD) and codebook loop on the frame engine" : "slow stack and codebook loop on the frame engine";
-    if (ctx->engb_on) why += "; codebook loop of 2..32 lock-step rows as one launch (FT_BATCH_ENGINE, experimental)";
     return true;
 }
 
@@ -674,6 +648,7 @@ struct Launch {
     int pos_off;     // added to the device position (token-by-token prefill)
     hipError_t err = hipSuccess;
     bool gemv_only = false;  // measurement: enqueue only the weight-streaming GEMV launches of the frame
+    bool tail_only = false;  // the frame tail follows a prompt pass: the rows' residual stream is in ctx->x (f32 rows)
     void chk() { hipError_t e = hipGetLastError(); if (e != hipSuccess && err == hipSuccess) err = e; }
 };
 
@@ -686,10 +661,36 @@ struct PfX {   // fused RMSNorm hooks of the skinny kernel (codec_kernels.h TapG
 static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, const float* bias, int N, int K,
                     int act, const float* resid, float* out_f32, bf16_t* out_bf, long ldo, int round_out,
                     const PfX& fx = PfX());
-// A lock-step batch of >= wide_min rows (bf16): every Linear is an M-row GEMM on the MFMA skinny kernel (weights read
-// once for the whole batch), norms run as their own row kernels, attention hands bf16 copies to the Wo GEMM.
+// A lock-step batch of >= wide_min rows (bf16): every Linear is ONE M-row MFMA launch (weights read once for the whole
+// batch) with the RMSNorm / SwiGLU / residual add folded in (wide_kernels.h): five launches per layer.
 static bool wide_batch(const Launch& L) {
-    return L.ctx->wide_ok && L.ctx->c.dtype == FT_BF16 && L.M >= L.ctx->wide_min && !L.gemv_only && !L.ctx->prof;
+    return L.ctx->wide_ok && L.ctx->c.dtype == FT_BF16 && L.M >= L.ctx->wide_min && L.M <= 64 && !L.gemv_only && !L.ctx->prof;
+}
+
+// One Linear of a lock-step batch.  Tile choices per shape class measured with tools/mb_wide.hip (profiles/r04_mb_wide.txt):
+// two 16-row weight tiles per workgroup where the fused norm's arithmetic would otherwise be paid per 16 rows of a long
+// matrix (W13 always, Wqkv from 17 batch rows), both 16-row batch tiles in one workgroup only where the weights
+// dominate (W13, the vocabulary head); everything else splits the batch rows over workgroups.
+static void wide_gemm(Launch& L, const bf16_t* X, const void* W, const float* bias, int N, int K, const void* gain, int epi,
+                      float* out_f32, long ldo, bf16_t* out_xo, const bf16_t* resid_xo) {
+    WideP p{};
+    p.X = X; p.ldm = L.ctx->xo_ldm; p.W = (const bf16_t*)W; p.ldw = K; p.gain = (const bf16_t*)gain; p.eps = L.ctx->c.norm_eps;
+    p.bias = bias; p.M = L.M; p.N = N; p.K = K; p.out_f32 = out_f32; p.ldo = ldo; p.out_xo = out_xo; p.ldm_o = L.ctx->xo_ldm;
+    p.resid_xo = resid_xo;
+    bool ok;
+    if (epi == WEPI_RESID) ok = wide_gemm_launch<1, 1, false, WEPI_RESID>(p, L.s);
+    else if (epi == WEPI_SWIGLU) ok = L.M > 16 ? wide_gemm_launch<2, 2, true, WEPI_SWIGLU>(p, L.s) : wide_gemm_launch<1, 2, true, WEPI_SWIGLU>(p, L.s);
+    else if (N >= 32768) ok = L.M > 16 ? wide_gemm_launch<2, 2, true, WEPI_STORE>(p, L.s) : wide_gemm_launch<1, 2, true, WEPI_STORE>(p, L.s);
+    else if (N >= 4096 && L.M > 16) ok = wide_gemm_launch<1, 2, true, WEPI_STORE>(p, L.s);
+    else ok = wide_gemm_launch<1, 1, true, WEPI_STORE>(p, L.s);
+    if (!ok && L.err == hipSuccess) L.err = hipErrorInvalidValue;
+    L.chk();
+}
+
+// f32 rows -> octet-major bf16 (the values are bf16-exact): the residual stream a prompt pass left in ctx->x
+static __global__ __launch_bounds__(256) void xo_from_rows_kernel(const float* x, int ldx, int D, bf16_t* xo, int ldm) {
+    const int m = blockIdx.y;
+    for (int d = blockIdx.x * 256 + threadIdx.x; d < D; d += gridDim.x * 256) xo[xo_index(m, d, ldm)] = f32_to_bf16_bits(x[(size_t)m * ldx + d]);
 }
 
 static bool eng_slow_ok(const Launch& L) {
@@ -701,55 +702,6 @@ static bool eng_slow_ok(const Launch& L) {
 static bool eng_fast_ok(const Launch& L) {
     const ft_ctx* ctx = L.ctx;
     return ctx->eng_fast_on && !ctx->eng_suspended && L.M == 1 && !L.gemv_only && !ctx->prof;
-}
-static bool engb_ok(const Launch& L) {
-    const ft_ctx* ctx = L.ctx;
-    return ctx->engb_on && !ctx->eng_suspended && L.M >= 2 && L.M <= EB_M && !L.gemv_only && !ctx->prof;
-}
-
-// The codebook loop of one frame of a lock-step batch (rows m0 .. m0 + M) as one launch (batch_engine.h).
-static void enqueue_fastb_engine(Launch& L) {
-    ft_ctx* ctx = L.ctx;
-    const ft_ar_config& c = ctx->c;
-    const int m0 = L.m0, R = c.num_codebooks + 1;
-    const size_t nLf = c.n_fast_layer;
-    const size_t QKVN = (size_t)(c.fast_n_head + 2 * c.fast_n_local_heads) * c.fast_head_dim, HDf = (size_t)c.fast_n_head * c.fast_head_dim;
-    FastBEngP p{};
-    p.layers = ctx->eng_flayers; p.n_layer = c.n_fast_layer; p.ncb = c.num_codebooks; p.M = L.M;
-    p.eps = c.norm_eps; p.scale = (float)(1.0 / sqrt((double)c.fast_head_dim));
-    p.rope = ctx->frope; p.fast_norm = (const bf16_t*)ctx->fast_norm; p.fast_out = (const bf16_t*)ctx->fast_out;
-    p.fast_emb = (const bf16_t*)ctx->fast_emb;
-    p.hid = ctx->hid + (size_t)m0 * c.fast_dim; p.femb = ctx->femb + (size_t)m0 * c.fast_dim;
-    unsigned* g = ctx->engb_g;
-    p.gx = g; g += 2 * (nLf + 1) * (size_t)EB_M * ENG_FD;
-    p.gqkv = g; g += 2 * nLf * (size_t)EB_M * QKVN;
-    p.gy = g; g += 2 * nLf * (size_t)EB_M * HDf;
-    p.gxb = g; g += 2 * nLf * (size_t)EB_M * ENG_FD;
-    p.gg = g; g += 2 * nLf * (size_t)EB_M * ENG_FF_DIM;
-    p.glog = g; g += 2 * (size_t)EB_M * ENG_FV;
-    p.gcode = g;
-    p.ctl = ctx->eng_ctl;
-    p.rep_delta0 = (long)ctx->engb_words; p.rep_stride = (long)ctx->engb_words;
-    SampP s{};
-    s.logits = nullptr; s.ldl = ctx->fastV; s.V = ctx->fastV;
-    s.ctl = ctx->d_ctl + m0; s.tokn = ctx->d_tokn + (size_t)m0 * R; s.seq = ctx->d_seq + (size_t)m0 * R * ctx->cap;
-    s.cap = ctx->cap; s.nf = ctx->d_nf + m0; s.cb = 1; s.ncb = c.num_codebooks; s.sem_begin = c.semantic_begin_id;
-    s.im_end = c.im_end_id; s.cbsize = c.codebook_size; s.fast_emb = ctx->fast_emb;
-    s.femb = ctx->femb + (size_t)m0 * c.fast_dim; s.Df = c.fast_dim; s.noise = ctx->noise;
-    s.noise_row_len = ctx->noise_row_len; s.noise_rows = ctx->noise_rows; s.noise_off = 0; s.last = 0;
-    s.tok = ctx->d_tok + (size_t)m0 * R; s.pos = ctx->d_pos + m0; s.done = ctx->d_done + m0;
-    p.samp = s;
-    p.noise_cb_stride = ctx->fastV; p.noise_off1 = c.vocab_size;
-    p.stamps = g_eb_stamps;
-    fastb_engine_kernel<10><<<ENG_NB, ENG_THREADS, ctx->engb_lds, L.s>>>(p);
-    L.chk();
-}
-// diagnostics: the in-kernel time stamps of the last batch codebook-loop launch (FT_EB_STAMPS set at context creation)
-extern "C" int32_t ft_test_eb_stamps(unsigned long long* out, int32_t n) {
-    if (!g_eb_stamps) return 0;
-    const int m = n < EB_STAMP_WORDS ? n : EB_STAMP_WORDS;
-    if (hipMemcpy(out, g_eb_stamps, (size_t)m * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return m;
 }
 
 // The whole codebook loop of one frame (steps 0 .. num_codebooks-1 with their draws) as one launch; runs after the
@@ -946,32 +898,22 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
     e.cbsize = c.codebook_size; e.vocab = c.vocab_size; e.sem_begin = c.semantic_begin_id;
     e.sem_end = c.semantic_end_id; e.scale = c.scale_codebook_embeddings;
     e.inv_div = (float)sqrt((double)(c.num_codebooks + 1));
+    const bool wide = wide_batch(L);
+    if (wide) { e.xo = ctx->xo_x + (size_t)m0 * 8; e.xo_ldm = ctx->xo_ldm; }
     if (!L.gemv_only) embed_kernel<WT, ROUND><<<dim3((c.dim + 255) / 256, L.M), 256, 0, L.s>>>(e);
     L.chk();
 
-    const bool wide = wide_batch(L);
     for (int li = 0; li < c.n_layer; ++li) {
         const FtLayer& l = ctx->layers[li];
         if (wide) {
             if constexpr (ROUND == RND_BF16) {
-                const int D = c.dim, HD = c.n_head * c.head_dim, F = c.intermediate_size, M = L.M;
-                bf16_t* xn = ctx->mb_xn + (size_t)m0 * D;
-                bf16_t* ybf = ctx->mb_ybf + (size_t)m0 * HD;
-                bf16_t* gbf = ctx->mb_g + (size_t)m0 * F;
-                // fused norm: the Wo / W2 epilogues leave an exact bf16 copy of x and per-block sums of squares,
-                // the next GEMM normalises its operand on the fly (layer 0 reads the embedding kernel's x: row kernel)
-                const bool fuse = ctx->wide_fuse && M <= ctx->wide_fuse_max;
-                bf16_t* xb = ctx->mb_xb + (size_t)m0 * D;
-                float* ss = ctx->mb_ss + (size_t)m0 * (std::max(c.dim, c.fast_dim) / 16 + 1);
-                PfX leave; leave.ss_out = fuse ? ss : nullptr;
-                PfX nrm; nrm.ss_in = ss; nrm.nblk = D / 16;
-                if (fuse && li > 0) {
-                    nrm.gain = l.attn_norm;
-                    pf_gemm(L, xb, D, M, l.wqkv, l.bqkv_f32, (int)qkvN, D, ACT_NONE, nullptr, qkv, nullptr, (long)qkvN, 0, nrm);
-                } else {
-                    rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.attn_norm, c.norm_eps, D, xn);
-                    pf_gemm(L, xn, D, M, l.wqkv, l.bqkv_f32, (int)qkvN, D, ACT_NONE, nullptr, qkv, nullptr, (long)qkvN, 0);
-                }
+                // five launches per layer (wide_kernels.h): the residual stream xo, the attention output and the SwiGLU vector
+                // travel octet-major in bf16; q k v stay f32 rows for the attention kernel
+                const int D = c.dim, HD = c.n_head * c.head_dim, F = c.intermediate_size, M = L.M, ldm = ctx->xo_ldm;
+                bf16_t* xo = ctx->xo_x + (size_t)m0 * 8;
+                bf16_t* yo = ctx->xo_y + (size_t)m0 * 8;
+                bf16_t* go = ctx->xo_g + (size_t)m0 * 8;
+                wide_gemm(L, xo, l.wqkv, l.bqkv_f32, (int)qkvN, D, l.attn_norm, WEPI_STORE, qkv, (long)qkvN, nullptr, nullptr);
                 AttnP a{};
                 a.qkv = qkv; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->rope;
                 a.kc = (char*)l.kc + (size_t)m0 * ctx->cache_m_stride * ctx->esz;
@@ -983,20 +925,14 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
                 while (ns < ctx->nsplit && (long)M * c.n_local_heads * ns < 256) ns *= 2;
                 a.nsplit = ns;
                 a.eps = c.norm_eps; a.scale = 1.0f / sqrtf((float)c.head_dim);
-                a.y = y; a.ldy = HD; a.y_bf = ybf;
+                a.y = nullptr; a.ldy = HD; a.y_bf = yo; a.y_xo_ldm = ldm;
                 a.part_o = ctx->part_o + (size_t)m0 * c.n_head * ctx->nsplit * c.head_dim;
                 a.part_ml = ctx->part_ml + (size_t)m0 * c.n_head * ctx->nsplit * 2;
                 attn_decode<WT, ROUND>(L, a);
                 if (ns > 1) { attn_combine_rows_kernel<ROUND><<<M, 256, 0, L.s>>>(a); L.chk(); }
-                pf_gemm(L, ybf, HD, M, l.wo, l.bo_f32, D, HD, ACT_NONE, x, x, fuse ? xb : nullptr, D, 1, leave);
-                if (fuse) {
-                    nrm.gain = l.ffn_norm;
-                    pf_gemm(L, xb, D, M, l.w13, nullptr, 2 * F, D, ACT_SWIGLU, nullptr, nullptr, gbf, F, 0, nrm);
-                } else {
-                    rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(x, l.ffn_norm, c.norm_eps, D, xn);
-                    pf_gemm(L, xn, D, M, l.w13, nullptr, 2 * F, D, ACT_SWIGLU, nullptr, nullptr, gbf, F, 0);
-                }
-                pf_gemm(L, gbf, F, M, l.w2, nullptr, D, F, ACT_NONE, x, x, fuse ? xb : nullptr, D, 1, leave);
+                wide_gemm(L, yo, l.wo, l.bo_f32, D, HD, nullptr, WEPI_RESID, nullptr, 0, xo, xo);
+                wide_gemm(L, xo, l.w13, nullptr, 2 * F, D, l.ffn_norm, WEPI_SWIGLU, nullptr, 0, go, nullptr);
+                wide_gemm(L, go, l.w2, nullptr, D, F, nullptr, WEPI_RESID, nullptr, 0, xo, xo);
             }
             continue;
         }
@@ -1058,18 +994,14 @@ static void enqueue_head(Launch& L) {
     ft_ctx* ctx = L.ctx;
     const ft_ar_config& c = ctx->c;
     if (wide_batch(L)) {
-        if constexpr (ROUND == RND_BF16) {
-            bf16_t* xn = ctx->mb_xn + (size_t)L.m0 * c.dim;
-            if (ctx->wide_fuse && L.M <= ctx->wide_fuse_max && c.n_layer > 0 && c.vocab_size % 2 == 0) {  // x and its partials: last slow W2
-                PfX nrm; nrm.gain = ctx->norm; nrm.ss_in = ctx->mb_ss + (size_t)L.m0 * (std::max(c.dim, c.fast_dim) / 16 + 1); nrm.nblk = c.dim / 16;
-                pf_gemm(L, ctx->mb_xb + (size_t)L.m0 * c.dim, c.dim, L.M, ctx->head, nullptr, c.vocab_size, c.dim, ACT_NONE, nullptr,
-                        ctx->logits + (size_t)L.m0 * c.vocab_size, nullptr, c.vocab_size, 0, nrm);
-                return;
-            }
-            rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(ctx->x + (size_t)L.m0 * c.dim, ctx->norm, c.norm_eps, c.dim, xn);
-            pf_gemm(L, xn, c.dim, L.M, ctx->head, nullptr, c.vocab_size, c.dim, ACT_NONE, nullptr,
-                    ctx->logits + (size_t)L.m0 * c.vocab_size, nullptr, c.vocab_size, 0);
+        if (L.tail_only) {
+            xo_from_rows_kernel<<<dim3((c.dim + 255) / 256, L.M), 256, 0, L.s>>>(ctx->x + (size_t)L.m0 * c.dim, c.dim, c.dim,
+                                                                             ctx->xo_x + (size_t)L.m0 * 8, ctx->xo_ldm);
+            L.chk();
         }
+        if constexpr (ROUND == RND_BF16)
+            wide_gemm(L, ctx->xo_x + (size_t)L.m0 * 8, ctx->head, nullptr, c.vocab_size, c.dim, ctx->norm, WEPI_STORE,
+                      ctx->logits + (size_t)L.m0 * c.vocab_size, c.vocab_size, nullptr, nullptr);
         return;
     }
     GemvP h{};
@@ -1095,6 +1027,7 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
     s.noise_row_len = ctx->noise_row_len; s.noise_rows = ctx->noise_rows;
     s.noise_off = cb == 0 ? 0 : (long)c.vocab_size + (long)(cb - 1) * ctx->fastV;
     s.last = last ? 1 : 0; s.tok = ctx->d_tok + (size_t)m0 * R; s.pos = ctx->d_pos + m0; s.done = ctx->d_done + m0;
+    if (wide_batch(L)) { s.femb_xo = ctx->xo_femb + (size_t)m0 * 8; s.femb_ldm = ctx->xo_ldm; }
     if (s.V <= 1024) {
         sample_small_kernel<WT, ROUND><<<L.M, 256, 0, L.s>>>(s);
     } else if (ROUND == RND_BF16) {
@@ -1142,43 +1075,26 @@ static void enqueue_fast_step(Launch& L, const int cb) {
             const float* xl = li == 0 ? xin : xf;
             if (wide) {
                 if constexpr (ROUND == RND_BF16) {
-                    const int HDf = Hf * hdf, Ff = c.fast_intermediate_size, M = L.M;
-                    bf16_t* xn = ctx->mb_xn + (size_t)m0 * Df;
-                    bf16_t* ybf = ctx->mb_ybf + (size_t)m0 * HDf;
-                    bf16_t* gbf = ctx->mb_g + (size_t)m0 * Ff;
-                    // fused norm as in the slow layers; layer 0 reads hid / the code embedding (row kernel)
-                    const bool fuse = ctx->wide_fuse && M <= ctx->wide_fuse_max;
-                    bf16_t* xb = ctx->mb_xb + (size_t)m0 * Df;
-                    float* ss = ctx->mb_ss + (size_t)m0 * (std::max(c.dim, c.fast_dim) / 16 + 1);
-                    PfX leave; leave.ss_out = fuse ? ss : nullptr;
-                    PfX nrm; nrm.ss_in = ss; nrm.nblk = Df / 16;
-                    if (fuse && li > 0) {
-                        nrm.gain = l.attn_norm;
-                        pf_gemm(L, xb, Df, M, l.wqkv, nullptr, (int)qkvN, Df, ACT_NONE, nullptr, qkvf, nullptr, (long)qkvN, 0, nrm);
-                    } else {
-                        rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xl, l.attn_norm, c.norm_eps, Df, xn);
-                        pf_gemm(L, xn, Df, M, l.wqkv, nullptr, (int)qkvN, Df, ACT_NONE, nullptr, qkvf, nullptr, (long)qkvN, 0);
-                    }
+                    // as the slow layers; layer 0 reads the slow stack's residual stream (position 0) or the drawn code's embedding
+                    const int HDf = Hf * hdf, Ff = c.fast_intermediate_size, M = L.M, ldm = ctx->xo_ldm;
+                    const bf16_t* xin_o = (cb == 0 ? ctx->xo_x : ctx->xo_femb) + (size_t)m0 * 8;
+                    bf16_t* xfo = ctx->xo_xf + (size_t)m0 * 8;
+                    bf16_t* yo = ctx->xo_y + (size_t)m0 * 8;
+                    bf16_t* go = ctx->xo_g + (size_t)m0 * 8;
+                    const bf16_t* xlo = li == 0 ? xin_o : xfo;
+                    wide_gemm(L, xlo, l.wqkv, nullptr, (int)qkvN, Df, l.attn_norm, WEPI_STORE, qkvf, (long)qkvN, nullptr, nullptr);
                     FastAttnP a{};
                     a.qkv = qkvf; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->frope;
                     a.kc = (char*)l.kc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
                     a.vc = (char*)l.vc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
                     a.cache_m_stride = ctx->fcache_m_stride; a.c = cb; a.H = Hf; a.Hkv = Hkvf; a.hd = hdf;
                     a.ncb = c.num_codebooks; a.eps = c.norm_eps; a.scale = (float)(1.0 / sqrt((double)hdf));
-                    a.y_bf = ybf;
-                    float* yf = ctx->y + (size_t)m0 * ctx->y_ld;
-                    // y (f32) and its bf16 copy share the row stride HDf here
-                    fast_attn_kernel<WT, ROUND><<<dim3(Hf, M), 64, 0, L.s>>>(a, yf, HDf);
+                    a.y_bf = yo; a.y_xo_ldm = ldm;
+                    fast_attn_kernel<WT, ROUND><<<dim3(Hf, M), 64, 0, L.s>>>(a, nullptr, HDf);
                     L.chk();
-                    pf_gemm(L, ybf, HDf, M, l.wo, nullptr, Df, HDf, ACT_NONE, xl, xf, fuse ? xb : nullptr, Df, 1, leave);
-                    if (fuse) {
-                        nrm.gain = l.ffn_norm;
-                        pf_gemm(L, xb, Df, M, l.w13, nullptr, 2 * Ff, Df, ACT_SWIGLU, nullptr, nullptr, gbf, Ff, 0, nrm);
-                    } else {
-                        rmsnorm_llama_rows_kernel<bf16_t, true><<<M, 256, 0, L.s>>>(xf, l.ffn_norm, c.norm_eps, Df, xn);
-                        pf_gemm(L, xn, Df, M, l.w13, nullptr, 2 * Ff, Df, ACT_SWIGLU, nullptr, nullptr, gbf, Ff, 0);
-                    }
-                    pf_gemm(L, gbf, Ff, M, l.w2, nullptr, Df, Ff, ACT_NONE, xf, xf, fuse ? xb : nullptr, Df, 1, leave);
+                    wide_gemm(L, yo, l.wo, nullptr, Df, HDf, nullptr, WEPI_RESID, nullptr, 0, xfo, xlo);
+                    wide_gemm(L, xfo, l.w13, nullptr, 2 * Ff, Df, l.ffn_norm, WEPI_SWIGLU, nullptr, 0, go, nullptr);
+                    wide_gemm(L, go, l.w2, nullptr, Df, Ff, nullptr, WEPI_RESID, nullptr, 0, xfo, xfo);
                 }
                 continue;
             }
@@ -1214,18 +1130,9 @@ static void enqueue_fast_step(Launch& L, const int cb) {
         }
         if (cb == 0) return;  // logits of position 0 are discarded (inference.py:122)
         if (wide) {
-            if constexpr (ROUND == RND_BF16) {
-                bf16_t* xn = ctx->mb_xn + (size_t)m0 * Df;
-                if (ctx->wide_fuse && L.M <= ctx->wide_fuse_max && c.n_fast_layer > 0 && ctx->fastV % 2 == 0) {
-                    PfX nrm; nrm.gain = ctx->fast_norm; nrm.ss_in = ctx->mb_ss + (size_t)m0 * (std::max(c.dim, c.fast_dim) / 16 + 1); nrm.nblk = Df / 16;
-                    pf_gemm(L, ctx->mb_xb + (size_t)m0 * Df, Df, L.M, ctx->fast_out, nullptr, ctx->fastV, Df, ACT_NONE, nullptr,
-                            ctx->flog + (size_t)m0 * ctx->fastV, nullptr, ctx->fastV, 0, nrm);
-                } else {
-                    rmsnorm_llama_rows_kernel<bf16_t, true><<<L.M, 256, 0, L.s>>>(xf, ctx->fast_norm, c.norm_eps, Df, xn);
-                    pf_gemm(L, xn, Df, L.M, ctx->fast_out, nullptr, ctx->fastV, Df, ACT_NONE, nullptr,
-                            ctx->flog + (size_t)m0 * ctx->fastV, nullptr, ctx->fastV, 0);
-                }
-            }
+            if constexpr (ROUND == RND_BF16)
+                wide_gemm(L, (c.n_fast_layer > 0 ? ctx->xo_xf : ctx->xo_femb) + (size_t)m0 * 8, ctx->fast_out, nullptr, ctx->fastV, Df,
+                          ctx->fast_norm, WEPI_STORE, ctx->flog + (size_t)m0 * ctx->fastV, ctx->fastV, nullptr, nullptr);
             enqueue_sample<WT, ROUND>(L, cb, cb == c.num_codebooks - 1);
             return;
         }
@@ -1261,7 +1168,6 @@ static void enqueue_frame_tail(Launch& L) {
     enqueue_head<WT, ROUND>(L);
     enqueue_sample<WT, ROUND>(L, 0, ncb == 1);
     if (ROUND == RND_BF16 && eng_fast_ok(L)) { enqueue_fast_engine(L); return; }
-    if (ROUND == RND_BF16 && engb_ok(L)) { enqueue_fastb_engine(L); return; }
     for (int cb = 0; cb < ncb; ++cb) enqueue_fast_step<WT, ROUND>(L, cb);
 }
 
@@ -1526,6 +1432,7 @@ extern "C" ft_status ft_ar_first_frames(ft_ctx* ctx, int32_t slot0, int32_t n, c
     const int R = c.num_codebooks + 1;
     FT_TRY(upload_ctl(ctx, slot0, n, sp));
     Launch L{ctx, ctx->stream, slot0, n, 0};
+    L.tail_only = true;
     const bool on_engine = n == 1 && eng_in_use(ctx);
     auto tail = [&]() {
         if (c.dtype == FT_BF16) { enqueue_fproj<bf16_t, RND_BF16>(L); enqueue_frame_tail<bf16_t, RND_BF16>(L); }
@@ -1620,7 +1527,7 @@ extern "C" void ft_ar_kv_free(ft_ctx* ctx, ft_kv_snapshot* snap) {
 
 // the captured grids depend on the batch width, on the KV split count and on whether the frame engine serves the frame
 static int graph_key(const ft_ctx* ctx, int M, int frames) {
-    const bool eng = (ctx->eng_on || ctx->eng_fast_on || ctx->engb_on) && !ctx->eng_suspended;
+    const bool eng = M == 1 && (ctx->eng_on || ctx->eng_fast_on) && !ctx->eng_suspended;   // the engine serves one-slot frames only
     return (M * 64 + ctx->nsplit) + (frames > 1 ? frames * (1 << 20) : 0) + (eng ? (1 << 28) : 0);
 }
 
@@ -1793,7 +1700,6 @@ static ft_status eng_recover(ft_ctx* ctx, bool* aborted) {
     if (ctx->eng_gx) FT_HIP(ctx, hipMemsetAsync(ctx->eng_gx, 0, ctx->eng_pool_bytes, ctx->stream));
     if (ctx->eng_gpart) FT_HIP(ctx, hipMemsetAsync(ctx->eng_gpart, 0, ctx->eng_gpart_bytes, ctx->stream));
     if (ctx->eng_fast_g) FT_HIP(ctx, hipMemsetAsync(ctx->eng_fast_g, 0, ctx->eng_fast_bytes, ctx->stream));
-    if (ctx->engb_g) FT_HIP(ctx, hipMemsetAsync(ctx->engb_g, 0, ctx->engb_bytes, ctx->stream));
     FT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // (epoch is a stack word)
     char buf[256];
     if (ctx->eng_strikes >= ENG_MAX_STRIKES) {

@@ -14,7 +14,7 @@
 // compile-time: every load of the launch is issued before the first use = one memory round trip per launch); the NW
 // partial tiles meet in LDS and are summed in wave order (deterministic).  Weight bytes are read once per M split.
 #pragma once
-#include "common.h"
+#include "ar_kernels.h"   // xo_index
 
 namespace ft {
 
@@ -39,23 +39,30 @@ struct WideP {
     const bf16_t* resid_xo; // WEPI_RESID: the residual stream (same form and stride as out_xo; may alias it)
 };
 
-// octet-major element address
-__device__ __host__ __forceinline__ size_t xo_index(int m, int k, int ldm) { return ((size_t)(k >> 3) * ldm + m) * 8 + (k & 7); }
+typedef float wk_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wk_b2 __attribute__((ext_vector_type(2)));
 
-template <int TS, int NW, int KS, bool NORM, int EPI>
+// two packed bf16 -> two f32 lanes of a packed-f32 operand; and back with one v_cvt_pk_bf16_f32 (round to nearest even)
+__device__ __forceinline__ wk_f2 wk_unpack2(uint32_t w) { return wk_f2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+__device__ __forceinline__ uint32_t wk_pack2(wk_f2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, wk_b2)); }
+
+// NT = 16-row weight tiles per workgroup (they share the workgroup's normalised operand registers: the RMSNorm arithmetic,
+// ~5 vector instructions per element, is paid once per NT * 16 weight rows)
+template <int TS, int NT, int NW, int KS, bool NORM, int EPI>
 __global__ __launch_bounds__(NW * 64) void wide_gemm_kernel(WideP p) {
     __shared__ float ssw[NW][TS * 16];
-    __shared__ float Cs[NW][TS * 16][17];
+    __shared__ float Cs[NW][TS * 16][NT * 16 + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (TS * 16);
+    const int n0 = blockIdx.x * (NT * 16), m0 = blockIdx.y * (TS * 16);
     const int kw = wave * (KS * 32);
     // ---- every load of the launch, issued back to back
-    U4 w[KS], x[TS][KS], g[KS];
-    {
-        const bf16_t* wrow = p.W + (size_t)(n0 + fr) * p.ldw + kw + fq * 8;
+    U4 w[NT][KS], x[TS][KS], g[KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) w[s] = *reinterpret_cast<const U4*>(wrow + s * 32);
+    for (int t = 0; t < NT; ++t) {
+        const bf16_t* wrow = p.W + (size_t)(n0 + t * 16 + fr) * p.ldw + kw + fq * 8;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) w[t][s] = *reinterpret_cast<const U4*>(wrow + s * 32);
     }
 #pragma unroll
     for (int j = 0; j < TS; ++j) {
@@ -69,20 +76,17 @@ __global__ __launch_bounds__(NW * 64) void wide_gemm_kernel(WideP p) {
     if constexpr (NORM) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) g[s] = *reinterpret_cast<const U4*>(p.gain + kw + s * 32 + fq * 8);
-    }
-    float inv[TS];
-    if constexpr (NORM) {
         // sum of squares of this wave's K slice, per row: lanes fr, fr + 16, fr + 32, fr + 48 hold the four octets of a step
 #pragma unroll
         for (int j = 0; j < TS; ++j) {
-            float ss = 0.f;
+            wk_f2 ss2 = wk_f2{0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                float v[8];
-                Vec<bf16_t>::unpack(x[j][s], v);
+                const uint32_t* xw = reinterpret_cast<const uint32_t*>(&x[j][s]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ss = fmaf(v[e], v[e], ss);
+                for (int e = 0; e < 4; ++e) { const wk_f2 v = wk_unpack2(xw[e]); ss2 = __builtin_elementwise_fma(v, v, ss2); }
             }
+            float ss = ss2.x + ss2.y;
             ss += __shfl_xor(ss, 16);
             ss += __shfl_xor(ss, 32);
             if (fq == 0) ssw[wave][j * 16 + fr] = ss;
@@ -93,47 +97,48 @@ __global__ __launch_bounds__(NW * 64) void wide_gemm_kernel(WideP p) {
             float ss = ssw[0][j * 16 + fr];
 #pragma unroll
             for (int q = 1; q < NW; ++q) ss += ssw[q][j * 16 + fr];
-            inv[j] = rsqrt_exact(ss / (float)p.K + p.eps);
-        }
-    }
-    wk_f32x4 acc[TS];
+            const float inv = rsqrt_exact(ss / (float)p.K + p.eps);
+            const wk_f2 inv2 = wk_f2{inv, inv};
+            // x -> round(round(x / rms) * gain), the two roundings of llama.py:172-177, in place in the operand registers
 #pragma unroll
-    for (int j = 0; j < TS; ++j) acc[j] = wk_f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s = 0; s < KS; ++s) {
+                uint32_t* xw = reinterpret_cast<uint32_t*>(&x[j][s]);
+                const uint32_t* gw = reinterpret_cast<const uint32_t*>(&g[s]);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        wk_bf16x8 b;
-        __builtin_memcpy(&b, &w[s], 16);
-        float gv[8];
-        if constexpr (NORM) Vec<bf16_t>::unpack(g[s], gv);
-#pragma unroll
-        for (int j = 0; j < TS; ++j) {
-            wk_bf16x8 a;
-            if constexpr (NORM) {   // x -> round(round(x / rms) * gain): the two roundings of llama.py:172-177
-                float xv[8];
-                Vec<bf16_t>::unpack(x[j][s], xv);
-                U4 o;
-                uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    const float y0 = round_bf16(xv[e] * inv[j]) * gv[e];
-                    const float y1 = round_bf16(xv[e + 1] * inv[j]) * gv[e + 1];
-                    ow[e >> 1] = (uint32_t)f32_to_bf16_bits(y0) | ((uint32_t)f32_to_bf16_bits(y1) << 16);
-                }
-                __builtin_memcpy(&a, &o, 16);
-            } else {
-                __builtin_memcpy(&a, &x[j][s], 16);
+                for (int e = 0; e < 4; ++e)
+                    xw[e] = wk_pack2(wk_unpack2(wk_pack2(wk_unpack2(xw[e]) * inv2)) * wk_unpack2(gw[e]));
             }
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
         }
     }
-    // lane holds C[row = j*16 + 4*fq + r][n = fr]
+    wk_f32x4 acc[TS][NT];
 #pragma unroll
     for (int j = 0; j < TS; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cs[wave][j * 16 + fq * 4 + r][fr] = acc[j][r];
+        for (int t = 0; t < NT; ++t) acc[j][t] = wk_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int j = 0; j < TS; ++j) {
+            wk_bf16x8 a;
+            __builtin_memcpy(&a, &x[j][s], 16);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                wk_bf16x8 b;
+                __builtin_memcpy(&b, &w[t][s], 16);
+                acc[j][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j][t], 0, 0, 0);
+            }
+        }
+    }
+    // lane holds C[row = j*16 + 4*fq + r][n = t*16 + fr]
+#pragma unroll
+    for (int j = 0; j < TS; ++j)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[wave][j * 16 + fq * 4 + r][t * 16 + fr] = acc[j][t][r];
     __syncthreads();
-    for (int e = tid; e < TS * 256; e += NW * 64) {
-        const int row = e >> 4, c = e & 15;       // 16 consecutive lanes finish one row's 16 columns
+    for (int e = tid; e < TS * NT * 256; e += NW * 64) {
+        const int row = e / (NT * 16), c = e % (NT * 16);       // consecutive lanes finish one row's columns
         const int m = m0 + row, n = n0 + c;
         float v = Cs[0][row][c];
 #pragma unroll
@@ -145,7 +150,8 @@ __global__ __launch_bounds__(NW * 64) void wide_gemm_kernel(WideP p) {
             const float other = dpp_f<DPP_XOR1>(v);
             if ((c & 1) == 0 && m < p.M) {
                 const float sg = round_bf16(v / (1.0f + expf(-v)));
-                p.out_xo[((size_t)blockIdx.x * p.ldm_o + m) * 8 + (c >> 1)] = f32_to_bf16_bits(sg * other);
+                const int gc = n >> 1;
+                p.out_xo[((size_t)(gc >> 3) * p.ldm_o + m) * 8 + (gc & 7)] = f32_to_bf16_bits(sg * other);
             }
         } else if constexpr (EPI == WEPI_RESID) {
             if (m < p.M) {
@@ -160,18 +166,16 @@ __global__ __launch_bounds__(NW * 64) void wide_gemm_kernel(WideP p) {
 }
 
 // K split: 128..256 contraction elements per wave where the width allows (one memory round trip, registers for every load)
-template <int TS, bool NORM, int EPI>
+template <int TS, int NT, bool NORM, int EPI>
 static inline bool wide_gemm_launch(const WideP& p, hipStream_t st) {
-    if (p.N % 16 != 0 || p.M < 1) return false;
-    const dim3 grid(p.N / 16, (p.M + TS * 16 - 1) / (TS * 16));
-    if (p.K == 1024) wide_gemm_kernel<TS, 8, 4, NORM, EPI><<<grid, 512, 0, st>>>(p);
-    else if (p.K == 2048) wide_gemm_kernel<TS, 8, 8, NORM, EPI><<<grid, 512, 0, st>>>(p);
-    else if (p.K == 3072) wide_gemm_kernel<TS, 12, 8, NORM, EPI><<<grid, 768, 0, st>>>(p);
-    else if (p.K == 512) wide_gemm_kernel<TS, 4, 4, NORM, EPI><<<grid, 256, 0, st>>>(p);
-    else if (p.K == 4096) wide_gemm_kernel<TS, 16, 8, NORM, EPI><<<grid, 1024, 0, st>>>(p);
+    if (p.N % (NT * 16) != 0 || p.M < 1) return false;
+    const dim3 grid(p.N / (NT * 16), (p.M + TS * 16 - 1) / (TS * 16));
+    if (p.K == 1024) wide_gemm_kernel<TS, NT, 8, 4, NORM, EPI><<<grid, 512, 0, st>>>(p);
+    else if (p.K == 2048) wide_gemm_kernel<TS, NT, 8, 8, NORM, EPI><<<grid, 512, 0, st>>>(p);
+    else if (p.K == 3072) wide_gemm_kernel<TS, NT, 12, 8, NORM, EPI><<<grid, 768, 0, st>>>(p);
     else return false;
     return true;
 }
-static inline bool wide_k_ok(int K) { return K == 512 || K == 1024 || K == 2048 || K == 3072 || K == 4096; }
+static inline bool wide_k_ok(int K) { return K == 1024 || K == 2048 || K == 3072; }
 
 }  // namespace ft

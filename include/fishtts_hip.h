@@ -46,7 +46,7 @@ typedef struct ft_ar_config {
 /* Hyper-parameters of the DAC decode path; the reference hard-codes them in
  * fish_tts/synthesizer.py:199-269 (and fish_tts/models/vocoder.py:824-872). */
 typedef struct ft_codec_config {
-    int32_t dtype;                 /* FT_BF16 | FT_F32 arithmetic of the conv/linear contractions */
+    int32_t dtype;                 /* FT_BF16 only: bf16 MFMA contractions, f32 accumulation, f32 transformer residual stream (anything else is FT_ERR_UNSUPPORTED) */
     int32_t n_codebooks;           /* residual codebooks (9); +1 semantic */
     int32_t codebook_size, semantic_codebook_size, codebook_dim, latent_dim; /* 1024, 4096, 8, 1024 */
     int32_t n_tf_layer, tf_n_head, tf_head_dim, tf_ffn, tf_window;           /* 8, 16, 64, 3072, 128 */
@@ -129,11 +129,6 @@ void ft_ar_kv_free(ft_ctx* ctx, ft_kv_snapshot* snap);
  * The step is hipGraph-captured; EOS is polled every `poll` frames (>=1). */
 ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames, const ft_sampling* sp,
                        int32_t poll, int32_t* out_frames, int32_t* out_n);
-/* Test hooks: inject the Exp(1) noise the sampler divides by (inference.py:26), one row of
- * `row_len` floats per generated frame (slow vocab draws first, then (num_codebooks-1) x 1024);
- * q == NULL restores the RNG.  Read back the last slow logits / pre-norm hidden of a slot. */
-ft_status ft_ar_set_noise(ft_ctx* ctx, const float* q, int64_t n_rows, int64_t row_len);
-ft_status ft_ar_get_debug(ft_ctx* ctx, int32_t slot, float* logits /*vocab*/, float* hidden /*fast_dim*/);
 
 /* Codec path = DAC.decode (vocoder.py:906-912) incl. DownsampleResidualVectorQuantize.decode
  * (vocoder.py:800-814) and Decoder (vocoder.py:605-640).  codes: B x (n_codebooks+1) x T int32
@@ -158,24 +153,7 @@ void ft_codec_stream_end(ft_ctx* ctx, ft_codec_stream* st);
  * int32 row-major (host, row stride = T' = ceil(n_samples / ft_codec_enc_frame_len)); *out_frames = T'. */
 ft_status ft_codec_encode(ft_ctx* ctx, const float* audio, int64_t n_samples, int32_t* codes, int32_t* out_frames);
 int32_t ft_codec_enc_frame_len(const ft_ctx* ctx);
-/* Test hook: the residual vector quantiser search alone on given pre-quantiser latents z [T][latent_dim] f32 (host). */
-ft_status ft_codec_rvq_encode(ft_ctx* ctx, const float* z, int32_t T, int32_t* codes);
 
-/* Measurement hook used by bench.py (never by the product path).  The weight-streaming GEMV launches of
- * one decode frame whose weights come from HBM (4 per slow layer + the vocabulary head; the fast stack's
- * 100 MB stay cache-resident and are excluded) are captured into a hipGraph and replayed `frames` times
- * between two HIP events on the engine's own stream.  Returns the elapsed device ms, the number of kernel
- * launches timed and the algorithmic bytes those launches stream. */
-ft_status ft_ar_profile_gemv(ft_ctx* ctx, int32_t frames, const ft_sampling* sp, double* ms,
-                             int64_t* launches, int64_t* bytes);
-/* Measurement hook used by bench.py (never by the product path): `frames` real decode frames of slot 0 (prefilled by
- * the caller, enough frame / cache capacity left) timed with HIP events on the engine's own stream.
- * ms_graph: elapsed ms of `frames` back-to-back replays of the captured frame graph (what ft_ar_decode runs);
- * seg_ms[3]: ms summed over frames-1 further frames launched eagerly with events between the three parts of a frame:
- * the slow stack, the vocabulary head + semantic draw, the fast codebook loop (bf16 only, else zeros);
- * nodes_per_frame: launches in the captured frame.  Reference: one decode_one_token_ar call, inference.py:83-155. */
-ft_status ft_ar_profile_frame(ft_ctx* ctx, int32_t frames, const ft_sampling* sp, double* ms_graph,
-                              double* seg_ms, int32_t* nodes_per_frame);
 ft_status ft_sync(ft_ctx* ctx);
 /* State of the persistent frame engine (csrc/frame_engine.h), the batch-1 form of the decode step
  * (fish_tts/models/inference.py:83-155 as two launches of one workgroup per CU instead of ~325 launches).
@@ -188,19 +166,6 @@ ft_status ft_sync(ft_ctx* ctx);
 ft_status ft_ar_engine_state(ft_ctx* ctx, int32_t* flags, int32_t* aborted, int32_t* where);
 /* One line of text: which path the batch-1 decode frames of this context take and why (for the host's log). */
 const char* ft_ar_frame_path(const ft_ctx* ctx);
-/* Test hook: workgroup `wg` of the next slow-stack (which = 0) or codebook-loop (which = 1) engine launch publishes
- * nothing, so the launch times out (one shot).  Exercises the recovery described above. */
-ft_status ft_test_engine_fault(ft_ctx* ctx, int32_t which, int32_t wg);
-/* Diagnostics, no reference counterpart: the in-kernel time stamps (100 MHz ticks) of the last launch of the experimental
- * batch codebook loop (FT_BATCH_ENGINE and FT_EB_STAMPS set when the context was created; tools/batch_engine_probe.py).
- * Returns the number of words copied, 0 when there are none. */
-int32_t ft_test_eb_stamps(unsigned long long* out, int32_t n);
-/* Test hook: one draw of the sampling kernel (inference.py:30-80) on caller-supplied logits.
- * cb = 0 draws from `vocab_size` logits, cb >= 1 from min(1024, codebook_size); window is the
- * (num_codebooks+1) x 16 penalty window of inference.py:187-191 or NULL (no penalty); q the Exp(1)
- * noise (same length as the logits) or NULL (RNG).  Clobbers slot 0. */
-ft_status ft_test_sample(ft_ctx* ctx, const float* logits, int32_t cb, const ft_sampling* sp,
-                         const int32_t* window, const float* q, int32_t* out_index);
 
 #ifdef __cplusplus
 }

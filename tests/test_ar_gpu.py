@@ -362,17 +362,15 @@ def test_batch32_mixed_lengths_equals_single(monkeypatch, precision):
     eng.close()
 
 
-@pytest.mark.parametrize("B,batch_engine", [(8, False), (19, False), (19, True), (32, True)])
-def test_wide_batch_vs_oracle(monkeypatch, B, batch_engine):
-    """Lock-step batches of >= 8 utterances run every Linear as an M-row MFMA GEMM (skinny split-K kernel), which sums
-    in a different order than the single-utterance GEMV: each utterance must follow the oracle up to a decision whose
-    top-1/top-2 margin is inside the bf16 evaluation-order tolerance."""
+@pytest.mark.parametrize("B", [5, 8, 16, 19, 32, 40])
+def test_wide_batch_vs_oracle(monkeypatch, B):
+    """Lock-step batches of >= 5 utterances run every Linear as ONE M-row MFMA launch with the RMSNorm / SwiGLU /
+    residual add folded in (csrc/wide_kernels.h: octet-major bf16 activations, five launches per layer), which sums in
+    a different order than the single-utterance GEMV: each utterance must follow the ORACLE up to a decision whose
+    top-1/top-2 margin is inside the bf16 evaluation-order tolerance.  The widths cover one 16-row batch tile (5, 8,
+    16), two (19, 32) and the row split over workgroups beyond 32 (40)."""
     shape = medium_shape()
-    if batch_engine:
-        # the codebook loop of the whole batch as ONE persistent launch (batch_engine.h; opt-in): same judgement
-        monkeypatch.setenv("FT_BATCH_ENGINE", "1")
     eng, orc = make_pair(shape, "bf16", std=0.05, max_batch=B)
-    assert ("FT_BATCH_ENGINE" in eng.frame_path()) == batch_engine, eng.frame_path()
     kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
     sp = eng._sampling(0.7, 1e-6, 1.1)
     prompts = [make_prompt(shape, 9 + (3 * i) % 11, seed=300 + i, n_vq=i % 4) for i in range(B)]
@@ -380,8 +378,8 @@ def test_wide_batch_vs_oracle(monkeypatch, B, batch_engine):
     frames, n = eng.decode(5, [sp] * B, poll=5)
     checked = 0
     for i, p in enumerate(prompts):
-        if i % 3 and B > 8:
-            continue                                   # the oracle is slow: every third utterance of the big batch
+        if i % 3 and B > 8 and i != B - 1:
+            continue                                   # the oracle is slow: every third utterance of the big batch, and the last row
         taps = []
         orc.reset()
         want = orc.generate(p.clone(), 6, frame_taps=taps, **kw).numpy()
@@ -392,8 +390,7 @@ def test_wide_batch_vs_oracle(monkeypatch, B, batch_engine):
             col, row = div
             assert _margin_ok(taps, col - p.shape[1], row, 0.03 * scale), f"utterance {i} diverged at {div}\n{got}\n{want}"
         checked += 1
-    assert checked >= 7
-    assert eng.engine_state()[1] == 0, eng.engine_state()          # no hand-off timed out
+    assert checked >= min(B, 6)
     eng.close()
 
 

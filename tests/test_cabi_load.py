@@ -6,9 +6,9 @@ import re
 import pytest
 
 
-def _header_symbols():
+def _header_symbols(name="fishtts_hip.h"):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    text = open(os.path.join(root, "include", "fishtts_hip.h")).read()
+    text = open(os.path.join(root, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(ft_[a-z_0-9]+)\s*\(", text)))
 
@@ -18,8 +18,12 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build()
     lib = _lib.load()
-    declared = _header_symbols()
-    assert declared, "no symbols parsed from the header"
+    product, hooks = _header_symbols(), _header_symbols("fishtts_hip_test.h")
+    assert product and hooks, "no symbols parsed from the headers"
+    assert not set(product) & set(hooks)
+    # the drop-in boundary carries no test / measurement hook
+    assert not [n for n in product if n.startswith("ft_test_") or "profile" in n or n in ("ft_ar_set_noise", "ft_ar_get_debug")]
+    declared = product + hooks
     for name in declared:
         assert hasattr(lib, name), name
     assert set(declared) == set(_lib.SYMBOLS), set(declared) ^ set(_lib.SYMBOLS)
