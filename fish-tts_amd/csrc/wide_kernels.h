@@ -48,15 +48,24 @@ __device__ __forceinline__ uint32_t wk_pack2(wk_f2 v) { return __builtin_bit_cas
 
 // NT = 16-row weight tiles per workgroup (they share the workgroup's normalised operand registers: the RMSNorm arithmetic,
 // ~5 vector instructions per element, is paid once per NT * 16 weight rows)
-template <int TS, int NT, int NW, int KS, bool NORM, int EPI>
-__global__ __launch_bounds__(NW * 64) void wide_gemm_kernel(WideP p) {
-    __shared__ float ssw[NW][TS * 16];
-    __shared__ float Cs[NW][TS * 16][NT * 16 + 1];
+template <int TS, int NT, int NW>
+constexpr int wide_lds_floats() { return NW * TS * 16 + NW * TS * 16 * (NT * 16 + 1); }
+
+// bx, by: the workgroup's tile (16 * NT weight rows, 16 * TS batch rows); lds: wide_lds_floats<TS, NT, NW>() floats
+// SYNC: hooks of an experiment that ran many dependent phases in one launch (tools/mb_chain.hip); WideNoSync in the product
+struct WideNoSync {
+    __device__ __forceinline__ void wait() const {}
+    __device__ __forceinline__ void signal() const {}
+};
+template <int TS, int NT, int NW, int KS, bool NORM, int EPI, typename SYNC = WideNoSync>
+__device__ __forceinline__ void wide_gemm_body(const WideP& p, const int bx, const int by, float* lds, const SYNC& sync = SYNC()) {
+    float (*ssw)[TS * 16] = reinterpret_cast<float (*)[TS * 16]>(lds);
+    float (*Cs)[TS * 16][NT * 16 + 1] = reinterpret_cast<float (*)[TS * 16][NT * 16 + 1]>(lds + NW * TS * 16);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * (NT * 16), m0 = blockIdx.y * (TS * 16);
+    const int n0 = bx * (NT * 16), m0 = by * (TS * 16);
     const int kw = wave * (KS * 32);
-    // ---- every load of the launch, issued back to back
+    // ---- every load of the launch, issued back to back (the weights first: tools/mb_chain.hip puts a wait between the two groups)
     U4 w[NT][KS], x[TS][KS], g[KS];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -64,6 +73,11 @@ __global__ __launch_bounds__(NW * 64) void wide_gemm_kernel(WideP p) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) w[t][s] = *reinterpret_cast<const U4*>(wrow + s * 32);
     }
+    if constexpr (NORM) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) g[s] = *reinterpret_cast<const U4*>(p.gain + kw + s * 32 + fq * 8);
+    }
+    sync.wait();
 #pragma unroll
     for (int j = 0; j < TS; ++j) {
         const int row = m0 + j * 16 + fr;
@@ -74,8 +88,6 @@ __global__ __launch_bounds__(NW * 64) void wide_gemm_kernel(WideP p) {
             x[j][s] = on ? *reinterpret_cast<const U4*>(xr + (size_t)s * 4 * p.ldm * 8) : U4{0u, 0u, 0u, 0u};
     }
     if constexpr (NORM) {
-#pragma unroll
-        for (int s = 0; s < KS; ++s) g[s] = *reinterpret_cast<const U4*>(p.gain + kw + s * 32 + fq * 8);
         // sum of squares of this wave's K slice, per row: lanes fr, fr + 16, fr + 32, fr + 48 hold the four octets of a step
 #pragma unroll
         for (int j = 0; j < TS; ++j) {
@@ -163,6 +175,13 @@ __global__ __launch_bounds__(NW * 64) void wide_gemm_kernel(WideP p) {
             if (m < p.M) p.out_f32[(size_t)m * p.ldo + n] = v;
         }
     }
+    sync.signal();
+}
+
+template <int TS, int NT, int NW, int KS, bool NORM, int EPI>
+__global__ __launch_bounds__(NW * 64) void wide_gemm_kernel(WideP p) {
+    __shared__ float lds[wide_lds_floats<TS, NT, NW>()];
+    wide_gemm_body<TS, NT, NW, KS, NORM, EPI>(p, blockIdx.x, blockIdx.y, lds);
 }
 
 // K split: 128..256 contraction elements per wave where the width allows (one memory round trip, registers for every load)
