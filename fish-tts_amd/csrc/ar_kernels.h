@@ -409,25 +409,22 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     WT* vc = reinterpret_cast<WT*>(p.vc) + crow + (size_t)kvh * p.n_slots * hd;
     const int grp = lane / LPP, gl = lane % LPP;
     const int slot = wave * PPW + grp;
-    auto load_kv = [&](int j, float(&kv)[8], float(&vv)[8]) {
-        if constexpr (sizeof(WT) == 2) {
-            Vec<WT>::load(kc + (size_t)j * hd + gl * 8, kv);
-            Vec<WT>::load(vc + (size_t)j * hd + gl * 8, vv);
-        } else {
-            const float* kf = reinterpret_cast<const float*>(kc) + (size_t)j * hd + gl * 8;
-            const float* vf = reinterpret_cast<const float*>(vc) + (size_t)j * hd + gl * 8;
+    // K/V rows travel in chunks of U block steps: every load of a chunk is issued before the first row is used (one memory
+    // round trip per U * NSLOT positions instead of one per NSLOT), the arithmetic keeps the order of the plain loop.  The
+    // first chunk is requested now, so it travels while q/k/v are built.
+    constexpr int U = sizeof(WT) == 2 ? 8 : 4;
+    typename Vec<WT>::Raw kraw[U], vraw[U];
+    auto load_chunk = [&](int base0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { kv[e] = kf[e]; vv[e] = vf[e]; }
+        for (int u = 0; u < U; ++u) {
+            const int j = base0 + u * NSLOT + grp;
+            const bool on = j < hi && (j != pos || p.no_append);
+            typename Vec<WT>::Raw zr{};
+            kraw[u] = on ? Vec<WT>::load_raw(kc + (size_t)j * hd + gl * 8) : zr;
+            vraw[u] = on ? Vec<WT>::load_raw(vc + (size_t)j * hd + gl * 8) : zr;
         }
     };
-    // the first K/V rows of this lane group are requested now, so they travel while q/k/v are built
-    float kpre[8], vpre[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { kpre[e] = 0.f; vpre[e] = 0.f; }
-    {
-        const int j = lo + wave * PPW + grp;
-        if (j < hi && (j != pos || p.no_append)) load_kv(j, kpre, vpre);
-    }
+    load_chunk(lo + wave * PPW);
 
     // phase 1: q heads of this group, new k, new v
     for (int item = wave; item < G + 2; item += 4) {
@@ -486,37 +483,37 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
     }
-    bool first = true;
-    for (int base = lo + wave * PPW; base < hi; base += NSLOT) {
-        const int j = base + grp;
-        const bool valid = j < hi;
-        float kv[8], vv[8];
+    for (int base0 = lo + wave * PPW; base0 < hi; base0 += NSLOT * U) {
+        if (base0 != lo + wave * PPW) load_chunk(base0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { kv[e] = kpre[e]; vv[e] = vpre[e]; }
-        if (valid) {
-            if (j == pos && !p.no_append) {
+        for (int u = 0; u < U; ++u) {
+            const int base = base0 + u * NSLOT;
+            if (base >= hi) break;
+            const int j = base + grp;
+            const bool valid = j < hi;
+            float kv[8], vv[8];
+            Vec<WT>::unpack_raw(kraw[u], kv);
+            Vec<WT>::unpack_raw(vraw[u], vv);
+            if (valid && j == pos && !p.no_append) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { kv[e] = k_new[gl * 8 + e]; vv[e] = v_new[gl * 8 + e]; }
-            } else if (!first) {
-                load_kv(j, kv, vv);
             }
-        }
-        first = false;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float d = 0.f;
+            for (int g = 0; g < G; ++g) {
+                float d = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) d = fmaf(qr[g][e], kv[e], d);
-            if (LPP > 1) d = group_sum_rt(d, LPP);
-            if (valid) {
-                const float s = d * p.scale;
-                const float mn = fmaxf(mrun[g], s);
-                const float corr = expf(mrun[g] - mn);
-                const float pj = expf(s - mn);
-                lrun[g] = lrun[g] * corr + pj;
+                for (int e = 0; e < 8; ++e) d = fmaf(qr[g][e], kv[e], d);
+                if (LPP > 1) d = group_sum_rt(d, LPP);
+                if (valid) {
+                    const float s = d * p.scale;
+                    const float mn = fmaxf(mrun[g], s);
+                    const float corr = expf(mrun[g] - mn);
+                    const float pj = expf(s - mn);
+                    lrun[g] = lrun[g] * corr + pj;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[g][e] = acc[g][e] * corr + pj * vv[e];
-                mrun[g] = mn;
+                    for (int e = 0; e < 8; ++e) acc[g][e] = acc[g][e] * corr + pj * vv[e];
+                    mrun[g] = mn;
+                }
             }
         }
     }
@@ -1119,8 +1116,6 @@ struct Red4 {
 template <typename WT, int ROUND>
 __global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
     __shared__ float redbuf[8];
-    __shared__ int pen_id[32];
-    __shared__ float pen_val[32];
     __shared__ float amv[4];
     __shared__ int ami[4];
     __shared__ int wcnt[4];
@@ -1137,30 +1132,31 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
     const int* seq = p.seq + (size_t)m * R * p.cap;
     Red4 red{redbuf, 0};
     const int i0 = 4 * tid;
+    // repetition penalty (inference.py:38-46): the window's ids are read by every thread (same addresses: one round trip
+    // beside the logits), the owner of a penalised logit rewrites it from the PRE-penalty value in its registers - what the
+    // reference's gather-then-scatter does (duplicate ids write the same value)
+    constexpr int MAXPEN = 32;
+    int ids[MAXPEN];
+    {
+        const int npen = nfv > 0 ? (p.cb == 0 ? (R < MAXPEN ? R : MAXPEN) : 16) : 0;
+        const int it = nfv - 1;
+        const int ws = it < 16 ? 0 : it - 16;
+#pragma unroll
+        for (int k = 0; k < MAXPEN; ++k)
+            ids[k] = k < npen ? (p.cb == 0 ? seq[(size_t)k * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + k]) : -1;
+    }
     float l[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) l[e] = (i0 + e) < V ? L[i0 + e] : -INFINITY;
-    if (nfv > 0) {  // repetition penalty: lanes fetch the (<= 16) ids and their pre-penalty logits in parallel
-        const int it = nfv - 1;
-        const int ws = it < 16 ? 0 : it - 16;
-        const int npen = p.cb == 0 ? R : 16;
-        if (tid < npen) {
-            const int id = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
-            pen_id[tid] = -1;
-            if (id >= 0 && id < V) {
-                const float sv = L[id];
-                pen_id[tid] = id;
-                pen_val[tid] = sv < 0.f ? rb<ROUND>(sv * ctl.rep) : rb<ROUND>(sv / ctl.rep);
-            }
-        }
-        __syncthreads();
-        for (int k = 0; k < npen; ++k) {
-            const int id = pen_id[k];
-            if (id >= i0 && id < i0 + 4) {
-                const float nv = pen_val[k];
+    {
+        float lp[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (i0 + e == id) l[e] = nv;
-            }
+        for (int e = 0; e < 4; ++e) lp[e] = l[e] < 0.f ? rb<ROUND>(l[e] * ctl.rep) : rb<ROUND>(l[e] / ctl.rep);
+#pragma unroll
+        for (int k = 0; k < MAXPEN; ++k) {
+            const int id = ids[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (id == i0 + e && id < V) l[e] = lp[e];
         }
     }
     if (p.cb == 0 && ctl.ban_eos && p.im_end < V) {

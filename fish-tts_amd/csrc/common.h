@@ -59,8 +59,13 @@ __device__ __forceinline__ void st_elem(float* p, size_t i, float v) { p[i] = v;
 
 // 16-byte vector of weights -> VEC f32 values (VEC = 8 for bf16, 4 for f32)
 template <typename T> struct Vec;
+// Raw / load_raw / unpack_raw: EIGHT consecutive elements kept in their storage form until they are used (K/V rows in flight)
+struct F8Raw { float4 a, b; };
 template <> struct Vec<bf16_t> {
     static constexpr int N = 8;
+    typedef U4 Raw;
+    __device__ static __forceinline__ U4 load_raw(const bf16_t* p) { return *reinterpret_cast<const U4*>(p); }
+    __device__ static __forceinline__ void unpack_raw(const U4& r, float (&v)[8]) { unpack(r, v); }
     __device__ static __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
         const U4 r = *reinterpret_cast<const U4*>(p);
         v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
@@ -81,6 +86,9 @@ template <> struct Vec<bf16_t> {
 };
 template <> struct Vec<f16_t> {
     static constexpr int N = 8;
+    typedef U4 Raw;
+    __device__ static __forceinline__ U4 load_raw(const f16_t* p) { return *reinterpret_cast<const U4*>(p); }
+    __device__ static __forceinline__ void unpack_raw(const U4& r, float (&v)[8]) { unpack(r, v); }
     __device__ static __forceinline__ void unpack(const U4& r, float (&v)[8]) {
         v[0] = f16_bits_to_f32(r.x & 0xffffu); v[1] = f16_bits_to_f32(r.x >> 16);
         v[2] = f16_bits_to_f32(r.y & 0xffffu); v[3] = f16_bits_to_f32(r.y >> 16);
@@ -95,6 +103,13 @@ template <> struct Vec<f16_t> {
 };
 template <> struct Vec<float> {
     static constexpr int N = 4;
+    typedef F8Raw Raw;
+    __device__ static __forceinline__ F8Raw load_raw(const float* p) {
+        return F8Raw{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)};
+    }
+    __device__ static __forceinline__ void unpack_raw(const F8Raw& r, float (&v)[8]) {
+        v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+    }
     __device__ static __forceinline__ void load(const float* p, float (&v)[4]) {
         const float4 r = *reinterpret_cast<const float4*>(p);
         v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;

@@ -52,8 +52,10 @@ template <int TS, int NT, int NW>
 constexpr int wide_lds_floats() { return NW * TS * 16 + NW * TS * 16 * (NT * 16 + 1); }
 
 // bx, by: the workgroup's tile (16 * NT weight rows, 16 * TS batch rows); lds: wide_lds_floats<TS, NT, NW>() floats
-// SYNC: hooks of an experiment that ran many dependent phases in one launch (tools/mb_chain.hip); WideNoSync in the product
+// SYNC: hooks of an experiment that ran many dependent phases in one launch (tools/mb_chain.hip: weights requested, then a
+// wait for the producer phase, then the activations); WideNoSync in the product
 struct WideNoSync {
+    static constexpr bool weights_first = false;
     __device__ __forceinline__ void wait() const {}
     __device__ __forceinline__ void signal() const {}
 };
@@ -65,19 +67,18 @@ __device__ __forceinline__ void wide_gemm_body(const WideP& p, const int bx, con
     const int fr = lane & 15, fq = lane >> 4;
     const int n0 = bx * (NT * 16), m0 = by * (TS * 16);
     const int kw = wave * (KS * 32);
-    // ---- every load of the launch, issued back to back (the weights first: tools/mb_chain.hip puts a wait between the two groups)
+    // ---- every load of the launch, issued back to back, in the order of use: the activations (L2) and the gain first, so
+    // that the fused norm runs while the weights are still on their way from HBM (the counted waits follow issue order)
     U4 w[NT][KS], x[TS][KS], g[KS];
+    auto issue_w = [&] {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const bf16_t* wrow = p.W + (size_t)(n0 + t * 16 + fr) * p.ldw + kw + fq * 8;
+        for (int t = 0; t < NT; ++t) {
+            const bf16_t* wrow = p.W + (size_t)(n0 + t * 16 + fr) * p.ldw + kw + fq * 8;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) w[t][s] = *reinterpret_cast<const U4*>(wrow + s * 32);
-    }
-    if constexpr (NORM) {
-#pragma unroll
-        for (int s = 0; s < KS; ++s) g[s] = *reinterpret_cast<const U4*>(p.gain + kw + s * 32 + fq * 8);
-    }
-    sync.wait();
+            for (int s = 0; s < KS; ++s) w[t][s] = *reinterpret_cast<const U4*>(wrow + s * 32);
+        }
+    };
+    if constexpr (SYNC::weights_first) { issue_w(); sync.wait(); }
 #pragma unroll
     for (int j = 0; j < TS; ++j) {
         const int row = m0 + j * 16 + fr;
@@ -86,6 +87,23 @@ __device__ __forceinline__ void wide_gemm_body(const WideP& p, const int bx, con
 #pragma unroll
         for (int s = 0; s < KS; ++s)
             x[j][s] = on ? *reinterpret_cast<const U4*>(xr + (size_t)s * 4 * p.ldm * 8) : U4{0u, 0u, 0u, 0u};
+    }
+    if constexpr (NORM) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) g[s] = *reinterpret_cast<const U4*>(p.gain + kw + s * 32 + fq * 8);
+    }
+    if constexpr (!SYNC::weights_first) issue_w();
+    // the residual values this thread adds in the epilogue (element e of the tile -> thread e % threads), requested now
+    constexpr int EPT = (TS * NT * 256 + NW * 64 - 1) / (NW * 64);
+    bf16_t rs[EPT];
+    if constexpr (EPI == WEPI_RESID) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = tid + i * NW * 64;
+            const int row = e / (NT * 16), c = e % (NT * 16);
+            const int m = m0 + row, n = n0 + c;
+            rs[i] = (e < TS * NT * 256 && m < p.M) ? p.resid_xo[((size_t)(n >> 3) * p.ldm_o + m) * 8 + (n & 7)] : (bf16_t)0;
+        }
     }
     if constexpr (NORM) {
         // sum of squares of this wave's K slice, per row: lanes fr, fr + 16, fr + 32, fr + 48 hold the four octets of a step
@@ -149,7 +167,10 @@ __device__ __forceinline__ void wide_gemm_body(const WideP& p, const int bx, con
 #pragma unroll
             for (int r = 0; r < 4; ++r) Cs[wave][j * 16 + fq * 4 + r][t * 16 + fr] = acc[j][t][r];
     __syncthreads();
-    for (int e = tid; e < TS * NT * 256; e += NW * 64) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = tid + i * NW * 64;
+        if (e >= TS * NT * 256) break;
         const int row = e / (NT * 16), c = e % (NT * 16);       // consecutive lanes finish one row's columns
         const int m = m0 + row, n = n0 + c;
         float v = Cs[0][row][c];
@@ -168,7 +189,7 @@ __device__ __forceinline__ void wide_gemm_body(const WideP& p, const int bx, con
         } else if constexpr (EPI == WEPI_RESID) {
             if (m < p.M) {
                 const size_t oi = ((size_t)(n >> 3) * p.ldm_o + m) * 8 + (n & 7);
-                v += bf16_bits_to_f32(p.resid_xo[oi]);
+                v += bf16_bits_to_f32(rs[i]);
                 p.out_xo[oi] = f32_to_bf16_bits(v);
             }
         } else {

@@ -33,6 +33,7 @@ struct ChainSync {
     unsigned* wait_rep;   // the producer phase's eight per-XCD "complete" words (32 dwords apart), or null
     int relay;            // this workgroup polls the counter itself and sets its XCD's word
     int mode;             // experiment switches: 2 = no fences, 4 = long sleep
+    static constexpr bool weights_first = true;
     __device__ __forceinline__ void wait() const;
     __device__ __forceinline__ void signal() const;
 };
