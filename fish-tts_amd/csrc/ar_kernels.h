@@ -657,6 +657,11 @@ struct FastAttnP {
     float eps, scale;
     bf16_t* y_bf;       // optional bf16 copy of y (operand of the MFMA Wo GEMM in wide batches)
     int y_xo_ldm;       // > 0: y_bf is octet-major Xo[H * hd / 8][y_xo_ldm][8] (wide_kernels.h), and y may be null
+    // paired pass of a wide batch (pair_M > 0, c == 0): grid.y = 2 pair_M; block y < pair_M is utterance y at position 0 (row y
+    // of qkv / y_bf), block y >= pair_M is utterance y - pair_M at position 1 (row pair_off + y - pair_M).  The position-1
+    // block rebuilds position 0's key from the utterance's position-0 row (the cache row is written by another block of
+    // this launch) with the arithmetic of the block that appends it.
+    int pair_M, pair_off;
 };
 
 constexpr int FAST_MAXCB = 16;
@@ -665,14 +670,17 @@ constexpr int FAST_MAXCB = 16;
 // All K/V rows of the <= num_codebooks cached positions are fetched in one round trip.
 template <typename WT, int ROUND>
 __global__ __launch_bounds__(64) void fast_attn_kernel(FastAttnP a, float* y, int ldy) {
-    const int h = blockIdx.x, m = blockIdx.y, lane = threadIdx.x;
-    const int hd = a.hd, hp = hd >> 1, H = a.H, Hkv = a.Hkv, G = H / Hkv, c = a.c, ncb = a.ncb;
+    const int h = blockIdx.x, lane = threadIdx.x;
+    const bool second = a.pair_M > 0 && (int)blockIdx.y >= a.pair_M;      // position 1 of the paired pass
+    const int u = second ? blockIdx.y - a.pair_M : blockIdx.y;           // utterance (cache row)
+    const int m = second ? a.pair_off + u : u;                           // row of qkv / y
+    const int hd = a.hd, hp = hd >> 1, H = a.H, Hkv = a.Hkv, G = H / Hkv, c = second ? 1 : a.c, ncb = a.ncb;
     const int kvh = h / G;
     const float* qkv = a.qkv + (size_t)m * a.ldq;
     const WT* qn = reinterpret_cast<const WT*>(a.qn);
     const WT* kn = reinterpret_cast<const WT*>(a.kn);
-    WT* kc = reinterpret_cast<WT*>(a.kc) + (size_t)m * a.cache_m_stride + (size_t)kvh * ncb * hd;
-    WT* vc = reinterpret_cast<WT*>(a.vc) + (size_t)m * a.cache_m_stride + (size_t)kvh * ncb * hd;
+    WT* kc = reinterpret_cast<WT*>(a.kc) + (size_t)u * a.cache_m_stride + (size_t)kvh * ncb * hd;
+    WT* vc = reinterpret_cast<WT*>(a.vc) + (size_t)u * a.cache_m_stride + (size_t)kvh * ncb * hd;
     constexpr int EPL = 2;  // dims per lane: d = lane + 64 e, valid while d < hd
     // issue every load first: cached rows, the new q/k/v, the rotation entries, the norm gains
     float kj[FAST_MAXCB][EPL], vj[FAST_MAXCB][EPL];
@@ -681,7 +689,7 @@ __global__ __launch_bounds__(64) void fast_attn_kernel(FastAttnP a, float* y, in
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int d = lane + 64 * e;
-            const bool on = j < c && d < hd;
+            const bool on = j < c && d < hd && !second;
             kj[j][e] = on ? ld_elem(kc, (size_t)j * hd + d) : 0.f;
             vj[j][e] = on ? ld_elem(vc, (size_t)j * hd + d) : 0.f;
         }
@@ -697,6 +705,30 @@ __global__ __launch_bounds__(64) void fast_attn_kernel(FastAttnP a, float* y, in
         sn[e] = on ? a.rope[((size_t)c * hp + (d >> 1)) * 2 + 1] : 0.f;
         gq[e] = (on && qn) ? ld_elem(qn, d) : 1.f;
         gk[e] = (on && kn) ? ld_elem(kn, d) : 1.f;
+    }
+    if (second) {   // position 0's key and value of this utterance, from its position-0 row
+        const float* qkv0 = a.qkv + (size_t)u * a.ldq;
+        float k0[EPL], c0[EPL], s0[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int d = lane + 64 * e;
+            const bool on = d < hd;
+            k0[e] = on ? qkv0[(size_t)(H + kvh) * hd + d] : 0.f;
+            vj[0][e] = on ? qkv0[(size_t)(H + Hkv + kvh) * hd + d] : 0.f;
+            c0[e] = on ? a.rope[(size_t)(d >> 1) * 2] : 1.f;
+            s0[e] = on ? a.rope[(size_t)(d >> 1) * 2 + 1] : 0.f;
+        }
+        if (kn) {
+            const float ss = wave_sum(k0[0] * k0[0] + k0[1] * k0[1]);
+            const float inv = rsqrt_exact(ss / (float)hd + a.eps);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) k0[e] = rb<ROUND>((k0[e] * inv) * gk[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const float ko = dpp_f<DPP_XOR1>(k0[e]);
+            kj[0][e] = rb<ROUND>((lane & 1) == 0 ? k0[e] * c0[e] - ko * s0[e] : k0[e] * c0[e] + ko * s0[e]);
+        }
     }
     if (qn) {  // per-head nn.RMSNorm, one rounding (llama.py:207-209)
         const float ss = wave_sum(q[0] * q[0] + q[1] * q[1]);

@@ -163,7 +163,7 @@ static ft_status ar_alloc(ft_ctx* ctx) {
     else ctx->hid = ctx->x;
     FT_TRY(dmalloc(ctx, &ctx->femb, M * c.fast_dim));
     FT_TRY(dmalloc(ctx, &ctx->xf, M * c.fast_dim));
-    FT_TRY(dmalloc(ctx, &ctx->qkvf, M * fqkvN));
+    FT_TRY(dmalloc(ctx, &ctx->qkvf, 2 * ((M + 15) / 16 * 16) * fqkvN));   // 2 x: the paired codebook pass of wide batches (positions 0 and 1 as 2 M rows)
     FT_TRY(dmalloc(ctx, &ctx->gf, M * c.fast_intermediate_size));
     FT_TRY(dmalloc(ctx, &ctx->flog, M * ctx->fastV));
     FT_TRY(dmalloc(ctx, &ctx->part_o, M * c.n_head * ctx->nsplit_max * c.head_dim));
@@ -209,7 +209,11 @@ static ft_status ar_alloc(ft_ctx* ctx) {
                        qkvN % 32 == 0 && fqkvN % 32 == 0 && c.intermediate_size % 16 == 0 && c.fast_intermediate_size % 16 == 0 &&
                        c.dim % 16 == 0 && c.vocab_size % 32 == 0 && ctx->fastV % 16 == 0;
         if (ctx->wide_ok) {
-            ctx->xo_ldm = (int)((M + 15) / 16 * 16);
+            // rows [0, xo_pair) = the batch, rows [xo_pair, 2 xo_pair) = the same utterances at codebook position 1 in the
+            // paired first pass of the codebook loop
+            ctx->xo_pair = (int)((M + 15) / 16 * 16);
+            ctx->no_pair = getenv("FT_NO_PAIR") != nullptr;
+            ctx->xo_ldm = 2 * ctx->xo_pair;
             const size_t P = ctx->xo_ldm;
             FT_TRY(dmalloc(ctx, &ctx->xo_x, P * c.dim));
             FT_TRY(dmalloc(ctx, &ctx->xo_xf, P * c.fast_dim));
@@ -667,21 +671,29 @@ static bool wide_batch(const Launch& L) {
     return L.ctx->wide_ok && L.ctx->c.dtype == FT_BF16 && L.M >= L.ctx->wide_min && L.M <= 64 && !L.gemv_only && !L.ctx->prof;
 }
 
+// Codebook positions 0 and 1 of a wide batch in ONE pass of 2 M rows (both inputs are known once the semantic token is drawn:
+// the slow stack's hidden state and the drawn code's embedding, inference.py:116-131): rows xo_pair + m hold position 1.
+static bool wide_pair(const Launch& L) {
+    const ft_ctx* ctx = L.ctx;
+    return wide_batch(L) && !ctx->no_pair && ctx->c.num_codebooks >= 2 && ctx->c.n_fast_layer > 0 && ctx->xo_pair + L.M <= 64;
+}
+
 // One Linear of a lock-step batch.  Tile choices per shape class measured with tools/mb_wide.hip (profiles/r04_mb_wide.txt):
 // two 16-row weight tiles per workgroup where the fused norm's arithmetic would otherwise be paid per 16 rows of a long
 // matrix (W13 always, Wqkv from 17 batch rows), both 16-row batch tiles in one workgroup only where the weights
 // dominate (W13, the vocabulary head); everything else splits the batch rows over workgroups.
 static void wide_gemm(Launch& L, const bf16_t* X, const void* W, const float* bias, int N, int K, const void* gain, int epi,
-                      float* out_f32, long ldo, bf16_t* out_xo, const bf16_t* resid_xo) {
+                      float* out_f32, long ldo, bf16_t* out_xo, const bf16_t* resid_xo, int rows = 0) {
+    const int M = rows > 0 ? rows : L.M;
     WideP p{};
     p.X = X; p.ldm = L.ctx->xo_ldm; p.W = (const bf16_t*)W; p.ldw = K; p.gain = (const bf16_t*)gain; p.eps = L.ctx->c.norm_eps;
-    p.bias = bias; p.M = L.M; p.N = N; p.K = K; p.out_f32 = out_f32; p.ldo = ldo; p.out_xo = out_xo; p.ldm_o = L.ctx->xo_ldm;
+    p.bias = bias; p.M = M; p.N = N; p.K = K; p.out_f32 = out_f32; p.ldo = ldo; p.out_xo = out_xo; p.ldm_o = L.ctx->xo_ldm;
     p.resid_xo = resid_xo;
     bool ok;
     if (epi == WEPI_RESID) ok = wide_gemm_launch<1, 1, false, WEPI_RESID>(p, L.s);
-    else if (epi == WEPI_SWIGLU) ok = L.M > 16 ? wide_gemm_launch<2, 2, true, WEPI_SWIGLU>(p, L.s) : wide_gemm_launch<1, 2, true, WEPI_SWIGLU>(p, L.s);
-    else if (N >= 32768) ok = L.M > 16 ? wide_gemm_launch<2, 2, true, WEPI_STORE>(p, L.s) : wide_gemm_launch<1, 2, true, WEPI_STORE>(p, L.s);
-    else if (N >= 4096 && L.M > 16) ok = wide_gemm_launch<1, 2, true, WEPI_STORE>(p, L.s);
+    else if (epi == WEPI_SWIGLU) ok = M > 16 ? wide_gemm_launch<2, 2, true, WEPI_SWIGLU>(p, L.s) : wide_gemm_launch<1, 2, true, WEPI_SWIGLU>(p, L.s);
+    else if (N >= 32768) ok = M > 16 ? wide_gemm_launch<2, 2, true, WEPI_STORE>(p, L.s) : wide_gemm_launch<1, 2, true, WEPI_STORE>(p, L.s);
+    else if (N >= 4096 && M > 16) ok = wide_gemm_launch<1, 2, true, WEPI_STORE>(p, L.s);
     else ok = wide_gemm_launch<1, 1, true, WEPI_STORE>(p, L.s);
     if (!ok && L.err == hipSuccess) L.err = hipErrorInvalidValue;
     L.chk();
@@ -1027,7 +1039,11 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
     s.noise_row_len = ctx->noise_row_len; s.noise_rows = ctx->noise_rows;
     s.noise_off = cb == 0 ? 0 : (long)c.vocab_size + (long)(cb - 1) * ctx->fastV;
     s.last = last ? 1 : 0; s.tok = ctx->d_tok + (size_t)m0 * R; s.pos = ctx->d_pos + m0; s.done = ctx->d_done + m0;
-    if (wide_batch(L)) { s.femb_xo = ctx->xo_femb + (size_t)m0 * 8; s.femb_ldm = ctx->xo_ldm; }
+    if (wide_batch(L)) {
+        // the semantic code's embedding is position 1 of the paired pass: it joins the slow stack's residual stream
+        s.femb_xo = (cb == 0 && wide_pair(L) ? ctx->xo_x + (size_t)ctx->xo_pair * 8 : ctx->xo_femb) + (size_t)m0 * 8;
+        s.femb_ldm = ctx->xo_ldm;
+    }
     if (s.V <= 1024) {
         sample_small_kernel<WT, ROUND><<<L.M, 256, 0, L.s>>>(s);
     } else if (ROUND == RND_BF16) {
@@ -1058,7 +1074,7 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
 
 // The fast transformer over codebook positions 0..ncb-1 with its sampling (inference.py:115-149).
 template <typename WT, int ROUND>
-static void enqueue_fast_step(Launch& L, const int cb) {
+static void enqueue_fast_step(Launch& L, const int cb, const bool pair = false) {
     ft_ctx* ctx = L.ctx;
     const ft_ar_config& c = ctx->c;
     const int m0 = L.m0;
@@ -1076,25 +1092,28 @@ static void enqueue_fast_step(Launch& L, const int cb) {
             if (wide) {
                 if constexpr (ROUND == RND_BF16) {
                     // as the slow layers; layer 0 reads the slow stack's residual stream (position 0) or the drawn code's embedding
+                    // pair: rows [0, M) at position 0 and rows [xo_pair, xo_pair + M) at position 1 (cb == 1) in one pass
                     const int HDf = Hf * hdf, Ff = c.fast_intermediate_size, M = L.M, ldm = ctx->xo_ldm;
-                    const bf16_t* xin_o = (cb == 0 ? ctx->xo_x : ctx->xo_femb) + (size_t)m0 * 8;
+                    const int rows = pair ? ctx->xo_pair + M : M;
+                    const bf16_t* xin_o = ((cb == 0 || pair) ? ctx->xo_x : ctx->xo_femb) + (size_t)m0 * 8;
                     bf16_t* xfo = ctx->xo_xf + (size_t)m0 * 8;
                     bf16_t* yo = ctx->xo_y + (size_t)m0 * 8;
                     bf16_t* go = ctx->xo_g + (size_t)m0 * 8;
                     const bf16_t* xlo = li == 0 ? xin_o : xfo;
-                    wide_gemm(L, xlo, l.wqkv, nullptr, (int)qkvN, Df, l.attn_norm, WEPI_STORE, qkvf, (long)qkvN, nullptr, nullptr);
+                    wide_gemm(L, xlo, l.wqkv, nullptr, (int)qkvN, Df, l.attn_norm, WEPI_STORE, qkvf, (long)qkvN, nullptr, nullptr, rows);
                     FastAttnP a{};
                     a.qkv = qkvf; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->frope;
                     a.kc = (char*)l.kc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
                     a.vc = (char*)l.vc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
-                    a.cache_m_stride = ctx->fcache_m_stride; a.c = cb; a.H = Hf; a.Hkv = Hkvf; a.hd = hdf;
+                    a.cache_m_stride = ctx->fcache_m_stride; a.c = pair ? 0 : cb; a.H = Hf; a.Hkv = Hkvf; a.hd = hdf;
                     a.ncb = c.num_codebooks; a.eps = c.norm_eps; a.scale = (float)(1.0 / sqrt((double)hdf));
                     a.y_bf = yo; a.y_xo_ldm = ldm;
-                    fast_attn_kernel<WT, ROUND><<<dim3(Hf, M), 64, 0, L.s>>>(a, nullptr, HDf);
+                    a.pair_M = pair ? M : 0; a.pair_off = ctx->xo_pair;
+                    fast_attn_kernel<WT, ROUND><<<dim3(Hf, pair ? 2 * M : M), 64, 0, L.s>>>(a, nullptr, HDf);
                     L.chk();
-                    wide_gemm(L, yo, l.wo, nullptr, Df, HDf, nullptr, WEPI_RESID, nullptr, 0, xfo, xlo);
-                    wide_gemm(L, xfo, l.w13, nullptr, 2 * Ff, Df, l.ffn_norm, WEPI_SWIGLU, nullptr, 0, go, nullptr);
-                    wide_gemm(L, go, l.w2, nullptr, Df, Ff, nullptr, WEPI_RESID, nullptr, 0, xfo, xfo);
+                    wide_gemm(L, yo, l.wo, nullptr, Df, HDf, nullptr, WEPI_RESID, nullptr, 0, xfo, xlo, rows);
+                    wide_gemm(L, xfo, l.w13, nullptr, 2 * Ff, Df, l.ffn_norm, WEPI_SWIGLU, nullptr, 0, go, nullptr, rows);
+                    wide_gemm(L, go, l.w2, nullptr, Df, Ff, nullptr, WEPI_RESID, nullptr, 0, xfo, xfo, rows);
                 }
                 continue;
             }
@@ -1131,8 +1150,8 @@ static void enqueue_fast_step(Launch& L, const int cb) {
         if (cb == 0) return;  // logits of position 0 are discarded (inference.py:122)
         if (wide) {
             if constexpr (ROUND == RND_BF16)
-                wide_gemm(L, (c.n_fast_layer > 0 ? ctx->xo_xf : ctx->xo_femb) + (size_t)m0 * 8, ctx->fast_out, nullptr, ctx->fastV, Df,
-                          ctx->fast_norm, WEPI_STORE, ctx->flog + (size_t)m0 * ctx->fastV, ctx->fastV, nullptr, nullptr);
+                wide_gemm(L, (c.n_fast_layer > 0 ? ctx->xo_xf : ctx->xo_femb) + (size_t)(m0 + (pair ? ctx->xo_pair : 0)) * 8, ctx->fast_out, nullptr,
+                          ctx->fastV, Df, ctx->fast_norm, WEPI_STORE, ctx->flog + (size_t)m0 * ctx->fastV, ctx->fastV, nullptr, nullptr);
             enqueue_sample<WT, ROUND>(L, cb, cb == c.num_codebooks - 1);
             return;
         }
@@ -1168,7 +1187,9 @@ static void enqueue_frame_tail(Launch& L) {
     enqueue_head<WT, ROUND>(L);
     enqueue_sample<WT, ROUND>(L, 0, ncb == 1);
     if (ROUND == RND_BF16 && eng_fast_ok(L)) { enqueue_fast_engine(L); return; }
-    for (int cb = 0; cb < ncb; ++cb) enqueue_fast_step<WT, ROUND>(L, cb);
+    int cb0 = 0;
+    if (wide_pair(L)) { enqueue_fast_step<WT, ROUND>(L, 1, true); cb0 = 2; }
+    for (int cb = cb0; cb < ncb; ++cb) enqueue_fast_step<WT, ROUND>(L, cb);
 }
 
 static void enqueue_frame(Launch& L, const int* toks, long trs, long tms, int col) {

@@ -394,6 +394,28 @@ def test_wide_batch_vs_oracle(monkeypatch, B):
     eng.close()
 
 
+@pytest.mark.parametrize("B", [7, 19, 32])
+def test_wide_batch_paired_codebook_pass_equals_two_passes(monkeypatch, B):
+    """Wide batches run codebook positions 0 and 1 as ONE pass of 2 M rows (both inputs are known once the semantic
+    token is drawn, inference.py:116-131; the position-1 rows rebuild position 0's key themselves).  Every row keeps its
+    own arithmetic, so the frames equal those of two separate passes (FT_NO_PAIR) bit for bit - sampled draws included."""
+    shape = medium_shape()
+    prompts = [make_prompt(shape, 9 + (3 * i) % 11, seed=300 + i, n_vq=i % 4).numpy() for i in range(B)]
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("FT_NO_PAIR", "1")
+        eng, _ = make_pair(shape, "bf16", std=0.05, max_batch=B)
+        sps = [eng._sampling(0.7, 0.8 if i % 2 else 1e-6, 1.1, seed=7 + i) for i in range(B)]
+        firsts = [eng.prefill(p, sps[i], slot=i) for i, p in enumerate(prompts)]
+        frames, n = eng.decode(6, sps, poll=3)
+        outs.append((np.stack(firsts), frames.copy(), n.copy()))
+        eng.close()
+    assert np.array_equal(outs[0][2], outs[1][2])
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_continuous_batching_equals_single_runs():
     """fish_tts_amd.batch.run_batch: 11 utterances (mixed prompt lengths, frame budgets, greedy and seeded top-p,
     one with a saved K/V prefix) through 4 slots with refill; each equals its single-slot run."""
