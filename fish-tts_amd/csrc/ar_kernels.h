@@ -549,6 +549,185 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Slow-layer decode attention of WIDE lock-step batches (bf16, wide_kernels.h): one block per (kv head, row) walks the row's
+// whole context.  Same inputs, rounding points and cache append as attn_decode_kernel (q/k nn.RMSNorm, interleaved RoPE,
+// f32 scores and probabilities, one rounding of y), but the softmax is taken in two passes - all scores to LDS, the
+// exact maximum, then the weighted sum - instead of an online softmax per lane group: no exponentials or rescaling on
+// the per-position chain, every K row of up to 128 positions (and the first V rows) in flight from the first
+// instruction.  Sums run in another order than the single-utterance kernel; wide batches are judged against the oracle
+// with the bf16 margin (tests/test_ar_gpu.py: test_wide_batch_vs_oracle), not bit for bit.
+// LDS: (G + 2) HD + 16 G + NSLOT G HD + G n_sc floats, n_sc >= the longest context + 1.
+// ------------------------------------------------------------------------------------------
+template <int G, int HD>
+__global__ __launch_bounds__(256) void attn_wide_kernel(AttnP p, int n_sc) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LPP = HD / 8, PPW = 64 / LPP, NSLOT = 4 * PPW, U = 8, HP = HD / 2;
+    const int kvh = blockIdx.x, m = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane / LPP, gl = lane % LPP, slot = wave * PPW + grp;
+    float* q_s = smem;                      // [G][HD]
+    float* k_new = q_s + G * HD;            // [HD]
+    float* v_new = k_new + HD;              // [HD]
+    float* red = v_new + HD;                // [2][4][G]
+    float* acc_s = red + 8 * G;             // [NSLOT][G][HD]
+    float* sc = acc_s + NSLOT * G * HD;     // [G][n_sc]
+    const int pos = p.pos[m] + p.pos_off;   // cached positions 0 .. pos-1, the new one is pos
+    const int n = pos + 1;
+    bf16_t* kc = reinterpret_cast<bf16_t*>(p.kc) + (size_t)m * p.cache_m_stride + (size_t)kvh * p.n_slots * HD;
+    bf16_t* vc = reinterpret_cast<bf16_t*>(p.vc) + (size_t)m * p.cache_m_stride + (size_t)kvh * p.n_slots * HD;
+    U4 kraw[U], vraw[U];
+    auto load_rows = [&](const bf16_t* base, U4 (&r)[U], int base0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = base0 + u * NSLOT + slot;
+            r[u] = j < pos ? *reinterpret_cast<const U4*>(base + (size_t)j * HD + gl * 8) : U4{0u, 0u, 0u, 0u};
+        }
+    };
+    load_rows(kc, kraw, 0);
+    load_rows(vc, vraw, 0);
+    // ---- q heads of this group, new k, new v (attn_decode_kernel phase 1; the rotation entries are requested with the inputs)
+    const float* qkv = p.qkv + (size_t)m * p.ldq;
+    const bf16_t* qn = reinterpret_cast<const bf16_t*>(p.qn);
+    const bf16_t* kn = reinterpret_cast<const bf16_t*>(p.kn);
+    for (int item = wave; item < G + 2; item += 4) {
+        const float* src;
+        const bf16_t* gain = nullptr;
+        float* dst;
+        if (item < G) { src = qkv + (size_t)(kvh * G + item) * HD; gain = qn; dst = q_s + item * HD; }
+        else if (item == G) { src = qkv + (size_t)(p.H + kvh) * HD; gain = kn; dst = k_new; }
+        else { src = qkv + (size_t)(p.H + p.Hkv + kvh) * HD; dst = v_new; }
+        if (item == G + 1) {
+            for (int e = lane; e < HD; e += 64) dst[e] = src[e];
+        } else {
+            float x0 = 0.f, x1 = 0.f, c = 1.f, sn = 0.f, g0 = 1.f, g1 = 1.f;
+            if (lane < HP) {
+                x0 = src[2 * lane]; x1 = src[2 * lane + 1];
+                c = p.rope[((size_t)pos * HP + lane) * 2]; sn = p.rope[((size_t)pos * HP + lane) * 2 + 1];
+                if (gain) { g0 = ld_elem(gain, 2 * lane); g1 = ld_elem(gain, 2 * lane + 1); }
+            }
+            if (gain) {
+                const float ss = wave_sum(x0 * x0 + x1 * x1);
+                const float inv = rsqrt_exact(ss / (float)HD + p.eps);
+                x0 = round_bf16((x0 * inv) * g0);
+                x1 = round_bf16((x1 * inv) * g1);
+            }
+            if (lane < HP) {
+                dst[2 * lane] = round_bf16(x0 * c - x1 * sn);
+                dst[2 * lane + 1] = round_bf16(x1 * c + x0 * sn);
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < HD; e += 256) {      // llama.py:142-149
+        kc[(size_t)pos * HD + e] = f32_to_bf16_bits(k_new[e]);
+        vc[(size_t)pos * HD + e] = f32_to_bf16_bits(v_new[e]);
+    }
+    // ---- pass 1: scores of every position, the maximum per head
+    float qr[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qr[g][e] = q_s[g * HD + gl * 8 + e];
+    float mx[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) mx[g] = -INFINITY;
+    for (int base0 = 0; base0 < n; base0 += NSLOT * U) {
+        if (base0) load_rows(kc, kraw, base0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base0 + u * NSLOT >= n) break;
+            const int j = base0 + u * NSLOT + slot;
+            float kv[8];
+            Vec<bf16_t>::unpack(kraw[u], kv);
+            if (j == pos) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kv[e] = k_new[gl * 8 + e];
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = fmaf(qr[g][e], kv[e], d);
+                if (LPP > 1) d = group_sum_rt(d, LPP);
+                const float sv = d * p.scale;
+                if (j < n) {
+                    mx[g] = fmaxf(mx[g], sv);
+                    if (gl == 0) sc[g * n_sc + j] = sv;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float w = wave_max(mx[g]);
+        if (lane == 0) red[wave * G + g] = w;
+    }
+    __syncthreads();
+    float Mx[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) Mx[g] = fmaxf(fmaxf(red[g], red[G + g]), fmaxf(red[2 * G + g], red[3 * G + g]));
+    // ---- pass 2: probabilities (one exponential per head and position over the whole block), their sum
+    float ls[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float a = 0.f;
+        for (int j = tid; j < n; j += 256) {
+            const float e = expf(sc[g * n_sc + j] - Mx[g]);
+            sc[g * n_sc + j] = e;
+            a += e;
+        }
+        ls[g] = wave_sum(a);
+        if (lane == 0) red[4 * G + wave * G + g] = ls[g];
+    }
+    __syncthreads();
+    // ---- pass 3: the weighted sum of the V rows
+    float acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+    for (int base0 = 0; base0 < n; base0 += NSLOT * U) {
+        if (base0) load_rows(vc, vraw, base0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base0 + u * NSLOT >= n) break;
+            const int j = base0 + u * NSLOT + slot;
+            if (j < n) {
+                float vv[8];
+                Vec<bf16_t>::unpack(vraw[u], vv);
+                if (j == pos) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vv[e] = v_new[gl * 8 + e];
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float pj = sc[g * n_sc + j];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(pj, vv[e], acc[g][e]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc_s[(size_t)(slot * G + g) * HD + gl * 8 + e] = acc[g][e];
+    __syncthreads();
+    for (int idx = tid; idx < G * HD; idx += 256) {
+        const int g = idx / HD, e = idx % HD;
+        float O = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; ++sl) O += acc_s[(size_t)(sl * G + g) * HD + e];
+        const float L = ((red[4 * G + g] + red[5 * G + g]) + red[6 * G + g]) + red[7 * G + g];
+        const float yo = round_bf16(O / L);
+        const int head = kvh * G + g;
+        if (p.y) p.y[(size_t)m * p.ldy + head * HD + e] = yo;
+        if (p.y_bf) p.y_bf[p.y_xo_ldm ? xo_index(m, head * HD + e, p.y_xo_ldm) : (size_t)m * p.ldy + head * HD + e] = f32_to_bf16_bits(yo);
+    }
+}
+constexpr int attn_wide_lds_floats(int G, int HD, int n_sc) { return (G + 2) * HD + 8 * G + 4 * (64 / (HD / 8)) * G * HD + G * n_sc; }
+
 // Merge of the split-KV partials of one head at 4 consecutive elements e..e+3: y = sum_s O_s w_s / sum_s l_s w_s,
 // w_s = exp(m_s - max m).  Splits are taken 8 at a time (all loads of a chunk issued before use); up to 8 splits this
 // is a single pass, beyond that the running (max, sum, acc) are rescaled per chunk.
@@ -1148,6 +1327,7 @@ struct Red4 {
 template <typename WT, int ROUND>
 __global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
     __shared__ float redbuf[8];
+    __shared__ int pen_id[32];
     __shared__ float amv[4];
     __shared__ int ami[4];
     __shared__ int wcnt[4];
@@ -1164,31 +1344,29 @@ __global__ __launch_bounds__(256) void sample_small_kernel(SampP p) {
     const int* seq = p.seq + (size_t)m * R * p.cap;
     Red4 red{redbuf, 0};
     const int i0 = 4 * tid;
-    // repetition penalty (inference.py:38-46): the window's ids are read by every thread (same addresses: one round trip
-    // beside the logits), the owner of a penalised logit rewrites it from the PRE-penalty value in its registers - what the
-    // reference's gather-then-scatter does (duplicate ids write the same value)
-    constexpr int MAXPEN = 32;
-    int ids[MAXPEN];
-    {
-        const int npen = nfv > 0 ? (p.cb == 0 ? (R < MAXPEN ? R : MAXPEN) : 16) : 0;
+    // repetition penalty (inference.py:38-46): the window's ids are fetched beside the logits (one round trip), the owner of
+    // a penalised logit rewrites it from the PRE-penalty value in its registers - what the reference's gather-then-scatter
+    // does (duplicate ids write the same value)
+    const int npen = nfv > 0 ? (p.cb == 0 ? (R < 32 ? R : 32) : 16) : 0;
+    if (tid < npen) {
         const int it = nfv - 1;
         const int ws = it < 16 ? 0 : it - 16;
-#pragma unroll
-        for (int k = 0; k < MAXPEN; ++k)
-            ids[k] = k < npen ? (p.cb == 0 ? seq[(size_t)k * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + k]) : -1;
+        pen_id[tid] = p.cb == 0 ? seq[(size_t)tid * p.cap + ws + 1] : seq[(size_t)(p.cb + 1) * p.cap + ws + 1 + tid];
     }
     float l[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) l[e] = (i0 + e) < V ? L[i0 + e] : -INFINITY;
-    {
+    if (npen > 0) {
+        __syncthreads();
         float lp[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) lp[e] = l[e] < 0.f ? rb<ROUND>(l[e] * ctl.rep) : rb<ROUND>(l[e] / ctl.rep);
+        for (int k = 0; k < npen; ++k) {
+            const int id = pen_id[k];
+            if (id >= i0 && id < i0 + 4 && id < V) {
 #pragma unroll
-        for (int k = 0; k < MAXPEN; ++k) {
-            const int id = ids[k];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (id == i0 + e && id < V) l[e] = lp[e];
+                for (int e = 0; e < 4; ++e) if (id == i0 + e) l[e] = lp[e];
+            }
         }
     }
     if (p.cb == 0 && ctl.ban_eos && p.im_end < V) {

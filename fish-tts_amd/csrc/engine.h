@@ -73,6 +73,7 @@ struct ft_ctx {
     ft::bf16_t *xo_x = nullptr, *xo_xf = nullptr, *xo_femb = nullptr, *xo_y = nullptr, *xo_g = nullptr;
     int xo_ldm = 0;     // rows of an octet: 2 x xo_pair
     int xo_pair = 0;    // max_batch rounded up to the 16-row MFMA tile; rows from here on hold codebook position 1 of the paired pass
+    bool no_attn_wide = false;   // FT_NO_ATTN_WIDE: wide batches keep the online-softmax attention kernel of the single rows
     bool no_pair = false;   // FT_NO_PAIR: codebook positions 0 and 1 as two passes (the comparison a parity test makes)
     int wide_min = 5;   // measured: the MFMA path wins from 5 rows (B=5: 2.79 vs 3.33 ms per frame), B <= 4 keeps the bit-exact multi-row GEMV
     bool wide_ok = false;

@@ -213,6 +213,7 @@ static ft_status ar_alloc(ft_ctx* ctx) {
             // paired first pass of the codebook loop
             ctx->xo_pair = (int)((M + 15) / 16 * 16);
             ctx->no_pair = getenv("FT_NO_PAIR") != nullptr;
+            ctx->no_attn_wide = getenv("FT_NO_ATTN_WIDE") != nullptr;
             ctx->xo_ldm = 2 * ctx->xo_pair;
             const size_t P = ctx->xo_ldm;
             FT_TRY(dmalloc(ctx, &ctx->xo_x, P * c.dim));
@@ -932,16 +933,28 @@ static void enqueue_slow(Launch& L, const int* toks, long tok_row_stride, long t
                 a.vc = (char*)l.vc + (size_t)m0 * ctx->cache_m_stride * ctx->esz;
                 a.cache_m_stride = ctx->cache_m_stride; a.pos = ctx->d_pos + m0; a.pos_off = L.pos_off;
                 a.H = c.n_head; a.Hkv = c.n_local_heads; a.hd = c.head_dim; a.n_slots = ctx->n_slots;
-                // split the cache walk until M x Hkv x nsplit blocks cover the chip (long contexts: voice prompts)
-                int ns = 1;
-                while (ns < ctx->nsplit && (long)M * c.n_local_heads * ns < 256) ns *= 2;
-                a.nsplit = ns;
                 a.eps = c.norm_eps; a.scale = 1.0f / sqrtf((float)c.head_dim);
                 a.y = nullptr; a.ldy = HD; a.y_bf = yo; a.y_xo_ldm = ldm;
-                a.part_o = ctx->part_o + (size_t)m0 * c.n_head * ctx->nsplit * c.head_dim;
-                a.part_ml = ctx->part_ml + (size_t)m0 * c.n_head * ctx->nsplit * 2;
-                attn_decode<WT, ROUND>(L, a);
-                if (ns > 1) { attn_combine_rows_kernel<ROUND><<<M, 256, 0, L.s>>>(a); L.chk(); }
+                // >= 128 (row, kv head) blocks: each walks its row's whole context with the two-pass kernel; fewer rows split
+                // the cache walk until M x Hkv x nsplit blocks cover the chip (long contexts of few rows: voice prompts)
+                const int Gq = c.n_head / c.n_local_heads;
+                const size_t wlds = (size_t)attn_wide_lds_floats(Gq, c.head_dim, ctx->n_slots) * sizeof(float);
+                if (!ctx->no_attn_wide && (long)M * c.n_local_heads >= 128 && c.head_dim == 128 && (Gq == 1 || Gq == 2 || Gq == 4) && wlds <= 65536) {
+                    a.nsplit = 1;
+                    const dim3 grid(c.n_local_heads, 1, M);
+                    if (Gq == 1) attn_wide_kernel<1, 128><<<grid, 256, wlds, L.s>>>(a, ctx->n_slots);
+                    else if (Gq == 2) attn_wide_kernel<2, 128><<<grid, 256, wlds, L.s>>>(a, ctx->n_slots);
+                    else attn_wide_kernel<4, 128><<<grid, 256, wlds, L.s>>>(a, ctx->n_slots);
+                    L.chk();
+                } else {
+                    int ns = 1;
+                    while (ns < ctx->nsplit && (long)M * c.n_local_heads * ns < 256) ns *= 2;
+                    a.nsplit = ns;
+                    a.part_o = ctx->part_o + (size_t)m0 * c.n_head * ctx->nsplit * c.head_dim;
+                    a.part_ml = ctx->part_ml + (size_t)m0 * c.n_head * ctx->nsplit * 2;
+                    attn_decode<WT, ROUND>(L, a);
+                    if (ns > 1) { attn_combine_rows_kernel<ROUND><<<M, 256, 0, L.s>>>(a); L.chk(); }
+                }
                 wide_gemm(L, yo, l.wo, l.bo_f32, D, HD, nullptr, WEPI_RESID, nullptr, 0, xo, xo);
                 wide_gemm(L, xo, l.w13, nullptr, 2 * F, D, l.ffn_norm, WEPI_SWIGLU, nullptr, 0, go, nullptr);
                 wide_gemm(L, go, l.w2, nullptr, D, F, nullptr, WEPI_RESID, nullptr, 0, xo, xo);

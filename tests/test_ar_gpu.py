@@ -416,6 +416,33 @@ def test_wide_batch_paired_codebook_pass_equals_two_passes(monkeypatch, B):
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_wide_batch_long_contexts_vs_oracle():
+    """Wide batches at contexts of 140-420 positions: the two-pass decode attention of wide batches (attn_wide_kernel:
+    one block per row and kv head, K rows of 128 positions per round trip, several chunks here) against the ORACLE,
+    with the bf16 evaluation-order margin."""
+    B = 16
+    shape = medium_shape(max_seq_len=512)
+    eng, orc = make_pair(shape, "bf16", std=0.05, max_batch=B, max_new_tokens=16)
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    sp = eng._sampling(0.7, 1e-6, 1.1)
+    lens = [140 + (37 * i) % 281 for i in range(B)]
+    prompts = [make_prompt(shape, lens[i], seed=700 + i, n_vq=lens[i] - 30) for i in range(B)]
+    firsts = [eng.prefill(p.numpy(), sp, slot=i) for i, p in enumerate(prompts)]
+    frames, n = eng.decode(4, [sp] * B, poll=4)
+    eng.close()
+    for i in (0, 5, 11, 15):
+        p = prompts[i]
+        taps = []
+        orc.reset()
+        want = orc.generate(p.clone(), 5, frame_taps=taps, **kw).numpy()
+        got = np.concatenate([p.numpy(), firsts[i][:, None], frames[i, : n[i]].T], axis=1)
+        scale = max(1.0, float(taps[0][0].float().abs().max()))
+        div = first_divergence(got, want)
+        if div is not None:
+            col, row = div
+            assert _margin_ok(taps, col - p.shape[1], row, 0.03 * scale), f"utterance {i} ({lens[i]} positions) diverged at {div}"
+
+
 def test_continuous_batching_equals_single_runs():
     """fish_tts_amd.batch.run_batch: 11 utterances (mixed prompt lengths, frame budgets, greedy and seeded top-p,
     one with a saved K/V prefix) through 4 slots with refill; each equals its single-slot run."""
