@@ -81,7 +81,7 @@ SYMBOLS = {
     "ft_sync": (C.c_int32, [_P]),
     "ft_ar_engine_state": (C.c_int32, [_P, _P, _P, _P]),
     "ft_ar_frame_path": (C.c_char_p, [_P]),
-    "ft_test_engine_fault": (C.c_int32, [_P, C.c_int32, C.c_int32]),
+    "ft_test_engine_fault": (C.c_int32, [_P, C.c_int32, C.c_int32, C.c_int32]),
     "ft_test_sample": (C.c_int32, [_P, _P, C.c_int32, C.POINTER(ft_sampling), _P, _P, _P]),
 }
 

@@ -147,9 +147,10 @@ class ARHipEngine:
         """Which path the batch-1 frames take (persistent frame engine or launches) and why."""
         return self.lib.ft_ar_frame_path(self._h).decode()
 
-    def inject_engine_fault(self, which: int = 0, workgroup: int = 0) -> None:
-        """Test hook: the next slow-stack (0) / codebook-loop (1) engine launch loses one workgroup's rows and times out."""
-        self._check(self.lib.ft_test_engine_fault(self._h, which, workgroup), "ft_test_engine_fault")
+    def inject_engine_fault(self, which: int = 0, workgroup: int = 0, skip: int = 0) -> None:
+        """Test hook: a coming slow-stack (0) / codebook-loop (1) engine launch loses one workgroup's rows and times out;
+        `skip` launches of that kind pass first."""
+        self._check(self.lib.ft_test_engine_fault(self._h, which, workgroup, skip), "ft_test_engine_fault")
 
     # ------------------------------------------------------------------ primitives
     @staticmethod

@@ -43,6 +43,7 @@ class CodecHipEngine:
         a = self.args
         self.with_encoder = bool(with_encoder and a.encoder_dim > 0)
         self.lib = L.load()
+        self._streams = set()          # open CodecStreams (ended before the native context goes)
         c = L.ft_codec_config()
         c.dtype = L.FT_BF16
         c.n_codebooks, c.codebook_size, c.semantic_codebook_size = a.n_codebooks, a.codebook_size, a.semantic_codebook_size
@@ -74,6 +75,8 @@ class CodecHipEngine:
         self.enc_frame_len = self.lib.ft_codec_enc_frame_len(self._h)
 
     def close(self):
+        for st in list(getattr(self, "_streams", ())):
+            st.close()
         if getattr(self, "_h", None) is not None and self._h:
             self.lib.ft_destroy(self._h)
             self._h = C.c_void_p()
@@ -177,6 +180,7 @@ class CodecStream:
         self._h = C.c_void_p()
         engine._check(engine.lib.ft_codec_stream_begin(engine._h, C.byref(self._h)), "ft_codec_stream_begin")
         self.frames = 0
+        engine._streams.add(self)      # the engine ends its open streams before it destroys the native context
 
     def decode(self, codes: np.ndarray) -> np.ndarray:
         """codes (n_codebooks+1, T) integer -> float32 (T * frame_len,): the next T frames of the stream."""
@@ -192,8 +196,9 @@ class CodecStream:
 
     def close(self) -> None:
         if self._h:
-            self.engine.lib.ft_codec_stream_end(self.engine._h, self._h)
+            self.engine.lib.ft_codec_stream_end(self.engine._h, self._h)   # the stream knows its context: a closed engine is fine
             self._h = C.c_void_p()
+        self.engine._streams.discard(self)
 
     def __del__(self):
         try:

@@ -24,9 +24,11 @@ struct UpStage { ConvW ct; float *dw_w, *dw_b, *ln_w, *ln_b, *gamma; ConvW pw1, 
 struct ResUnitW { float *a0, *a2; ConvW c7, c1; };
 struct DecBlock { float* a0; ConvW ct; ResUnitW u[3]; int s, cin, cout; };
 
+struct ft_codec_stream;
 struct CodecState {
     hipStream_t stream = nullptr;
     std::mutex mu;
+    std::vector<ft_codec_stream*> streams;   // live streamed decodes of this context (their device state is freed with it)
     float* tables = nullptr;  // RVQ tables
     float* rope = nullptr;
     std::vector<TfLayer> tf;
@@ -256,10 +258,15 @@ ft_status codec_create(ft_ctx* ctx) {
     return FT_OK;
 }
 
+static void stream_orphan(ft_codec_stream* sc);
 void codec_destroy(ft_ctx* ctx) {
     CodecState* s = ctx->codec;
     if (!s) return;
     if (s->stream) { hipStreamSynchronize(s->stream); hipStreamDestroy(s->stream); }
+    // streams the caller has not ended yet: their device state goes with the context, the host handle stays valid for
+    // ft_codec_stream_end (which then only deletes it) and is refused by ft_codec_stream_decode
+    for (ft_codec_stream* sc : s->streams) stream_orphan(sc);
+    s->streams.clear();
     for (void* p : s->owned) hipFree(p);
     delete s;
     ctx->codec = nullptr;
@@ -600,6 +607,7 @@ static void gemm(hipStream_t st, const ConvW& w, const GemmIO& io) {
 // (vocoder.py:411-420, 449-455); with those carried, a chunk's samples are the whole decode's samples, bit for bit.
 constexpr int STREAM_NOMINAL_FRAMES = 215;      // kernel variants are those of a 10 s utterance whatever the chunk length
 struct ft_codec_stream {
+    ft_ctx* owner = nullptr;   // the context whose codec the state belongs to; null once that context is gone (buffers freed)
     int t0 = 0;           // frames decoded so far (rope position of the next chunk's first frame)
     int par = 0;          // which copy is current
     std::vector<bf16_t*> kv[2];                    // per transformer layer: [window - 1][2 * H * hd], newest rows last
@@ -607,6 +615,12 @@ struct ft_codec_stream {
     std::vector<Tail> tails;                       // in the order decode_one consumes them
     std::vector<void*> owned;
 };
+
+static void stream_orphan(ft_codec_stream* sc) {
+    for (void* v : sc->owned) hipFree(v);
+    sc->owned.clear();
+    sc->owner = nullptr;
+}
 
 static int halo_of(const ConvW& w) {
     int h = 0;
@@ -749,6 +763,11 @@ extern "C" ft_status ft_codec_stream_begin(ft_ctx* ctx, ft_codec_stream** out) {
         (void)hipGetLastError();
         return ft_fail(ctx, FT_ERR_NOMEM, "ft_codec_stream_begin: could not set up the carried state");
     }
+    sc->owner = ctx;
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        s->streams.push_back(sc);
+    }
     *out = sc;
     return FT_OK;
 }
@@ -757,6 +776,7 @@ extern "C" ft_status ft_codec_stream_decode(ft_ctx* ctx, ft_codec_stream* sc, co
     if (!ctx || !sc) return FT_ERR_ARG;
     if (!ctx->has_codec || !ctx->codec) return ft_fail(ctx, FT_ERR_STATE, "Vocoder not loaded");
     if (!codes || !audio || T < 1) return ft_fail(ctx, FT_ERR_ARG, "ft_codec_stream_decode: bad argument");
+    if (sc->owner != ctx) return ft_fail(ctx, FT_ERR_STATE, "ft_codec_stream_decode: the stream belongs to another (or a destroyed) context");
     const ft_codec_config& c = ctx->cc;
     if (T > c.max_frames) return ft_fail(ctx, FT_ERR_TOO_LONG, "ft_codec_stream_decode: chunk longer than max_frames");
     if (sc->t0 + T > c.max_frames) return ft_fail(ctx, FT_ERR_TOO_LONG, "ft_codec_stream_decode: stream longer than max_frames (rope table)");
@@ -766,13 +786,21 @@ extern "C" ft_status ft_codec_stream_decode(ft_ctx* ctx, ft_codec_stream* sc, co
     return decode_one(ctx, codes, T, T, audio, sc);
 }
 
+// `ctx` may be null or stale: the stream knows its context, and a stream whose context was destroyed first has no device
+// state left (codec_destroy freed it) - only the host handle is deleted then.
 extern "C" void ft_codec_stream_end(ft_ctx* ctx, ft_codec_stream* sc) {
+    (void)ctx;
     if (!sc) return;
-    if (ctx && ctx->codec) {
-        std::lock_guard<std::mutex> lock(ctx->codec->mu);
-        hipSetDevice(ctx->device);
-        hipStreamSynchronize(ctx->codec->stream);
+    ft_ctx* own = sc->owner;
+    if (own && own->codec) {
+        CodecState* s = own->codec;
+        std::lock_guard<std::mutex> lock(s->mu);
+        hipSetDevice(own->device);
+        hipStreamSynchronize(s->stream);
         for (void* v : sc->owned) hipFree(v);
+        sc->owned.clear();
+        for (size_t i = 0; i < s->streams.size(); ++i)
+            if (s->streams[i] == sc) { s->streams.erase(s->streams.begin() + (long)i); break; }
     }
     delete sc;
 }

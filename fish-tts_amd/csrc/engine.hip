@@ -1672,6 +1672,12 @@ extern "C" ft_status ft_ar_decode(ft_ctx* ctx, int32_t nslots, int32_t n_frames,
                 FT_HIP(ctx, hipMemcpyAsync(ctx->d_done, hp + 2, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
                 FT_HIP(ctx, hipMemcpy2DAsync(ctx->d_tok, sizeof(int), ctx->d_seq + (hp[1] - 1), (size_t)ctx->cap * sizeof(int),
                                              sizeof(int), R, hipMemcpyDeviceToDevice, ctx->stream));
+                // the frame store beyond the rewound frame count goes back to zero: early in an utterance the repetition
+                // penalty's window reaches past the current frame (inference.py:187-191 reads a 16-column window of a
+                // zero-initialised store), and the aborted burst left its frames there
+                if (!done0 && hp[1] < ctx->cap)
+                    FT_HIP(ctx, hipMemset2DAsync(ctx->d_seq + hp[1], (size_t)ctx->cap * sizeof(int), 0,
+                                                 (size_t)std::min(burst, ctx->cap - hp[1]) * sizeof(int), R, ctx->stream));
                 ctx->eng_suspended = true;
                 const ft_status st = run_burst(burst);
                 ctx->eng_suspended = false;
@@ -1737,7 +1743,12 @@ static ft_status eng_recover(ft_ctx* ctx, bool* aborted) {
     FT_HIP(ctx, hipStreamSynchronize(ctx->stream));     // (epoch is a stack word)
     char buf[256];
     if (ctx->eng_strikes >= ENG_MAX_STRIKES) {
-        ctx->eng_on = ctx->eng_fast_on = false;
+        // the engine is given up for good: its graphs go, its buffers and the device's engine seat are released (another
+        // context of the process may take it), the reason stays readable through ft_ar_frame_path
+        for (auto it = ctx->graphs.begin(); it != ctx->graphs.end();) {
+            if (it->first & (1 << 28)) { hipGraphExecDestroy(it->second); it = ctx->graphs.erase(it); } else ++it;
+        }
+        eng_release(ctx);
         snprintf(buf, sizeof buf, "launch path: the frame engine was turned off after %d hand-off time-outs (last in phase %u)",
                  ctx->eng_strikes, w[ENG_CTL_WHERE]);
         ctx->eng_why = buf;
@@ -1759,15 +1770,17 @@ extern "C" ft_status ft_ar_engine_state(ft_ctx* ctx, int32_t* flags, int32_t* ab
 
 extern "C" const char* ft_ar_frame_path(const ft_ctx* ctx) { return ctx ? ctx->eng_why.c_str() : ""; }
 
-// Test hook: workgroup `wg` of the NEXT slow-stack (which = 0) or codebook-loop (which = 1) engine launch plays dead - it
-// publishes nothing, every workgroup that waits for its rows times out (one shot: that workgroup clears the word).
-extern "C" ft_status ft_test_engine_fault(ft_ctx* ctx, int32_t which, int32_t wg) {
+// Test hook: workgroup `wg` of a coming slow-stack (which = 0) or codebook-loop (which = 1) engine launch plays dead - it
+// publishes nothing, every workgroup that waits for its rows times out (one shot: that workgroup clears the word).  `skip`
+// launches of that kind pass first, so the time-out can be placed in a later burst of a call or inside a multi-frame graph.
+extern "C" ft_status ft_test_engine_fault(ft_ctx* ctx, int32_t which, int32_t wg, int32_t skip) {
     FT_TRY(ar_ready(ctx));
     if (!ctx->eng_ctl || !(which == 0 ? ctx->eng_on : ctx->eng_fast_on)) return ft_fail(ctx, FT_ERR_STATE, "ft_test_engine_fault: the frame engine is off");
-    if (wg < 0 || wg >= ctx->eng_nb) return ft_fail(ctx, FT_ERR_ARG, "ft_test_engine_fault: bad workgroup");
-    const unsigned v = (which == 0 ? 0u : ENG_FAULT_FAST) + 1u + (unsigned)wg;
+    if (wg < 0 || wg >= ctx->eng_nb || skip < 0) return ft_fail(ctx, FT_ERR_ARG, "ft_test_engine_fault: bad workgroup or skip count");
+    const unsigned v[2] = {(which == 0 ? 0u : ENG_FAULT_FAST) + 1u + (unsigned)wg, (unsigned)skip};
+    static_assert(ENG_CTL_FAULT_SKIP == ENG_CTL_FAULT + 1, "the two words are written by one copy");
     FT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    FT_HIP(ctx, hipMemcpy(ctx->eng_ctl + ENG_CTL_FAULT, &v, sizeof v, hipMemcpyHostToDevice));
+    FT_HIP(ctx, hipMemcpy(ctx->eng_ctl + ENG_CTL_FAULT, v, sizeof v, hipMemcpyHostToDevice));
     return FT_OK;
 }
 

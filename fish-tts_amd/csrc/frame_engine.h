@@ -44,14 +44,21 @@ typedef __attribute__((address_space(1))) unsigned long long eng_gu64;
 #define ENG_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 // control words (device memory, zeroed at creation)
-enum { ENG_CTL_EPOCH = 0, ENG_CTL_ABORT = 1, ENG_CTL_EXIT = 2, ENG_CTL_WHERE = 3, ENG_CTL_ARRIVED = 4, ENG_CTL_FAULT = 5, ENG_CTL_XCD = 16, ENG_CTL_WORDS = 32 };
+enum { ENG_CTL_EPOCH = 0, ENG_CTL_ABORT = 1, ENG_CTL_EXIT = 2, ENG_CTL_WHERE = 3, ENG_CTL_ARRIVED = 4, ENG_CTL_FAULT = 5, ENG_CTL_FAULT_SKIP = 6,
+       ENG_CTL_XCD = 16, ENG_CTL_WORDS = 32 };
 // ENG_CTL_FAULT (test hook, ft_test_engine_fault): 1 + b = workgroup b of the next slow-stack launch, ENG_FAULT_FAST + 1 + b =
 // of the next codebook-loop launch, starts with its `dead` word set and clears the fault word: it publishes nothing.
+// ENG_CTL_FAULT_SKIP launches of that kind pass first (only the named workgroup reads and counts the word down).
 constexpr unsigned ENG_FAULT_FAST = 0x10000u;
 // true when this workgroup is the one told to play dead (thread 0 only; the word is cleared)
 __device__ __forceinline__ bool eng_fault_here(unsigned* ctl, unsigned base, int b) {
     const unsigned f = __hip_atomic_load((__attribute__((address_space(1))) unsigned*)(ctl + ENG_CTL_FAULT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (f != base + 1u + (unsigned)b) return false;
+    const unsigned skip = __hip_atomic_load((__attribute__((address_space(1))) unsigned*)(ctl + ENG_CTL_FAULT_SKIP), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (skip > 0u) {
+        __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(ctl + ENG_CTL_FAULT_SKIP), skip - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
     __hip_atomic_store((__attribute__((address_space(1))) unsigned*)(ctl + ENG_CTL_FAULT), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }

@@ -33,9 +33,10 @@ ft_status ft_ar_profile_gemv(ft_ctx* ctx, int32_t frames, const ft_sampling* sp,
 ft_status ft_ar_profile_frame(ft_ctx* ctx, int32_t frames, const ft_sampling* sp, double* ms_graph,
                               double* seg_ms, int32_t* nodes_per_frame);
 
-/* Test hook: workgroup `wg` of the next slow-stack (which = 0) or codebook-loop (which = 1) engine launch publishes
- * nothing, so the launch times out (one shot).  Exercises the recovery described above. */
-ft_status ft_test_engine_fault(ft_ctx* ctx, int32_t which, int32_t wg);
+/* Test hook: workgroup `wg` of a coming slow-stack (which = 0) or codebook-loop (which = 1) engine launch publishes
+ * nothing, so the launch times out (one shot); `skip` launches of that kind pass first (a later burst of a call, a
+ * launch inside a multi-frame graph).  Exercises the recovery described above. */
+ft_status ft_test_engine_fault(ft_ctx* ctx, int32_t which, int32_t wg, int32_t skip);
 
 /* Test hook: one draw of the sampling kernel (inference.py:30-80) on caller-supplied logits.
  * cb = 0 draws from `vocab_size` logits, cb >= 1 from min(1024, codebook_size); window is the

@@ -169,16 +169,12 @@ def test_synthesize_batch_equals_synthesize(tts):
     assert synth.synthesize_batch([], max_tokens=10, **kw) == []
 
 
-@pytest.mark.parametrize("precision", ["fp32", "fp16"])
-def test_model_directory_in_reference_layout(tmp_path, precision):
-    """SURVEY §8-f F2 end to end: FishTTS(model_dir) on a directory laid out like the reference's checkpoint
-    (config.json, model.pth with a "state_dict" wrapper, "model." prefixes, separate wq/wk/wv, an audio_* tensor;
-    tokenizer.tiktoken + special_tokens.json; no codec.pth -> vocoder not loaded, as the reference warns)."""
+def _write_ar_directory(tmp_path):
+    """A directory laid out like the reference's checkpoint (synthesizer.py:158-197, llama.py:466-500): config.json,
+    model.pth with a "state_dict" wrapper, "model." prefixes, separate wq / wk / wv, an audio_* tensor;
+    tokenizer.tiktoken + special_tokens.json."""
     import base64
     import json
-    import fish_tts_amd as ft
-    from fish_tts_amd.generation import generate_long
-    from fish_tts_amd.prompt import build_prompt
     from fish_tts_amd.tokenizer import NAMED_SPECIAL_TOKENS
     shape = dataclasses.replace(tiny_shape(), max_seq_len=2304)
     w = OA.random_weights(shape, seed=3)
@@ -200,6 +196,18 @@ def test_model_directory_in_reference_layout(tmp_path, precision):
     ranks = {bytes([i]): i for i in range(256)}
     (tmp_path / "tokenizer.tiktoken").write_text("\n".join(f"{base64.b64encode(t).decode()} {r}" for t, r in ranks.items()))
     (tmp_path / "special_tokens.json").write_text(json.dumps(NAMED_SPECIAL_TOKENS + [f"<|semantic:{i}|>" for i in range(2048)]))
+    return shape, w
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_model_directory_in_reference_layout(tmp_path, precision):
+    """SURVEY §8-f F2 end to end: FishTTS(model_dir) on a directory laid out like the reference's checkpoint
+    (config.json, model.pth with a "state_dict" wrapper, "model." prefixes, separate wq/wk/wv, an audio_* tensor;
+    tokenizer.tiktoken + special_tokens.json; no codec.pth -> vocoder not loaded, as the reference warns)."""
+    import fish_tts_amd as ft
+    from fish_tts_amd.generation import generate_long
+    from fish_tts_amd.prompt import build_prompt
+    shape, w = _write_ar_directory(tmp_path)
     synth = ft.FishTTS(model_dir=tmp_path, precision=precision, warmup=True)     # "fp16": synthesizer.py:125-126
     try:
         assert synth._vocoder is None and synth._is_warmed_up and synth.precision == precision
@@ -230,6 +238,65 @@ def test_model_directory_in_reference_layout(tmp_path, precision):
             synth.synthesize("Hi there", max_tokens=4)
     finally:
         synth._engine.close()
+
+
+def test_model_directory_with_codec_pth(tmp_path):
+    """The same directory WITH codec.pth as the reference stores it (synthesizer.py:271-286, vocoder.py:423-429, 457-463): a
+    "state_dict" wrapper, every generator tensor under "generator.", the decoder's weight-normed convolutions as
+    parametrizations.weight.original0 (g) / original1 (v) with g != |v|, and a discriminator tensor that must be
+    dropped - at the codec widths the reference hard-codes (synthesizer.py:199-269).  FishTTS(model_dir).synthesize must
+    give the PCM of the same codes decoded by an engine loaded with the plain weights, which in turn follows the f32
+    oracle within the codec's bf16 tolerance."""
+    import fish_tts_amd as ft
+    from fish_tts_amd.codec_engine import CodecHipEngine
+    from fish_tts_amd.generation import generate_long
+    shape, w = _write_ar_directory(tmp_path)
+    cshape = OC.CodecShape()
+    cw = OC.random_weights(cshape, seed=1)
+    g = torch.Generator().manual_seed(5)
+    sd, n_wn = {}, 0
+    for k, v in cw.items():
+        if k.startswith("decoder.") and k.endswith("conv.weight") and v.dim() == 3:
+            base = "generator." + k[: -len("weight")]
+            stretch = 0.5 + torch.rand(v.shape[0], 1, 1, generator=g)          # v is NOT unit-norm and g is not |v|
+            sd[base + "parametrizations.weight.original0"] = v.flatten(1).norm(dim=1).view(-1, 1, 1)
+            sd[base + "parametrizations.weight.original1"] = v * stretch
+            n_wn += 1
+        else:
+            sd["generator." + k] = v
+    assert n_wn > 20
+    sd["discriminator.convs.0.weight"] = torch.zeros(3, 3)
+    torch.save({"state_dict": sd}, tmp_path / "codec.pth")
+    del sd
+    synth = ft.FishTTS(model_dir=tmp_path, precision="fp32", warmup=False)
+    plain = None
+    try:
+        assert synth._vocoder is not None
+        kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+        wav = synth.synthesize("Hi there", max_tokens=6, **kw)
+        codes = [r.codes for r in generate_long(engine=synth._engine, tokenizer=synth._tokenizer, text="Hi there", max_new_tokens=6, **kw)
+                 if r.action == "sample"][0]
+        with wave.open(io.BytesIO(wav), "rb") as wf:
+            pcm = np.frombuffer(wf.readframes(wf.getnframes()), dtype=np.int16)
+        assert pcm.shape == (codes.shape[1] * cshape.frame_len,)
+        plain = CodecHipEngine(device=0, max_frames=64)
+        plain.load_state_dict(cw)
+        audio = plain.decode(codes[None].astype(np.int64))[0]
+        # the fold g * v / |v| is f32 arithmetic on the host: the folded weights equal the plain ones to f32 rounding, the
+        # bf16 operand copies then agree except where that rounding crosses a bf16 tie
+        ref_pcm = (np.clip(audio, -1, 1) * 32767).astype(np.int16).astype(np.float32)
+        fold_err = np.sqrt(np.mean((pcm.astype(np.float32) - ref_pcm) ** 2)) / np.sqrt(np.mean(ref_pcm ** 2))
+        assert fold_err <= 1e-2, fold_err
+        want, _ = OC.CodecOracle(cshape, cw).decode(torch.from_numpy(codes.astype(np.int64))[None], torch.tensor([codes.shape[1]]))
+        want = want[0, 0].numpy()
+        err = np.sqrt(np.mean((audio - want) ** 2)) / np.sqrt(np.mean(want ** 2))
+        assert err <= 3e-2, err
+    finally:
+        synth._engine.close()
+        if synth._vocoder is not None:
+            synth._vocoder.close()
+        if plain is not None:
+            plain.close()
 
 
 def test_seamless_stream_equals_the_full_decode(tts):

@@ -177,6 +177,40 @@ def test_streamed_decode_with_carried_state_equals_the_whole_decode():
     eng.close()
 
 
+def test_stream_belongs_to_its_context_and_survives_its_closing():
+    """A streamed decode's carried state lives in the context that began it: another context refuses the handle
+    (FT_ERR_STATE, nothing is read from it); closing the engine ends its open streams first; a native context destroyed
+    under a live stream frees the stream's device state, after which ft_codec_stream_end only deletes the handle and
+    ft_codec_stream_decode refuses it."""
+    import ctypes as CT
+    from fish_tts_amd import _lib as L
+    shape = tiny_codec_shape()
+    a, _ = make_codec(shape)
+    b, _ = make_codec(shape, seed=1)
+    g = torch.Generator().manual_seed(3)
+    codes = np.zeros((shape.n_codebooks + 1, 6), dtype=np.int32)
+    codes[0] = torch.randint(0, shape.semantic_codebook_size, (6,), generator=g).numpy()
+    codes[1:] = torch.randint(0, shape.codebook_size, (shape.n_codebooks, 6), generator=g).numpy()
+    sa = a.stream()
+    first = sa.decode(codes)
+    audio = np.empty(6 * a.frame_len, dtype=np.float32)
+    rc = b.lib.ft_codec_stream_decode(b._h, sa._h, codes.ctypes.data_as(CT.c_void_p), 6, audio.ctypes.data_as(CT.c_void_p))
+    assert rc == L.FT_ERR_STATE and b"another" in b.lib.ft_last_error(b._h)
+    again = a.stream()
+    assert np.array_equal(again.decode(codes), first)          # the refused call touched nothing
+    a.close()                                                  # ends sa and `again` first
+    assert not sa._h and not again._h
+    sa.close()
+    # natively: the context goes while a stream is live
+    sb = b.stream()
+    sb.decode(codes)
+    handle, ctx = sb._h, b._h
+    b._streams.discard(sb)
+    b.close()
+    sb._h = CT.c_void_p()
+    L.load().ft_codec_stream_end(None, handle)                 # no device state left: deletes the handle only
+
+
 def test_streamed_decode_other_lengths_and_shapes():
     """Lengths at which the one-shot decode picks other kernel variants than the stream's nominal ones (the summation
     order inside a multi-tap convolution then differs): the chunked stream still equals the ONE-CHUNK stream bit for bit,

@@ -170,6 +170,47 @@ def test_hand_off_time_out_is_recovered_in_process(monkeypatch):
     eng.close()
 
 
+def test_time_out_in_a_later_burst_and_in_first_frames(monkeypatch):
+    """The recovery's other entrances: (1) a slow-stack time-out placed after ten passing launches - frame 11 of
+    decode(24, poll=8), i.e. the SECOND burst, inside a four-frame graph: the slot is rewound to the burst's first frame
+    (position, frame count, input column from the frame store) and the burst redone on the launch path; (2) a codebook-loop
+    time-out in ft_ar_first_frames(n = 1) after ft_ar_prefill_slow (prefill_many).  Frames equal the launch path's bit for
+    bit throughout; the second strike releases the engine, and another context of the process may then take it."""
+    shape = dataclasses.replace(medium_shape(), max_seq_len=1024)
+    prompt = make_prompt(shape, 26, seed=13, n_vq=2).numpy()
+    prompt2 = make_prompt(shape, 17, seed=18, n_vq=1).numpy()
+    kw = dict(temperature=0.7, top_p=0.8, repetition_penalty=1.1)
+
+    monkeypatch.setenv("FT_NO_ENGINE", "1")
+    ref, _ = make_pair(shape, "bf16", max_new_tokens=64, std=0.05)
+    sp = ref._sampling(seed=21, ban_eos=True, **kw)
+    want_first = ref.prefill(prompt, sp, slot=0)
+    want, wn = ref.decode(24, [sp], poll=8)
+    want2_first = ref.prefill_many([prompt2], [sp])[0]
+    want2, wn2 = ref.decode(8, [sp], poll=8)
+    ref.close()
+
+    monkeypatch.delenv("FT_NO_ENGINE", raising=False)
+    eng, _ = make_pair(shape, "bf16", max_new_tokens=64, std=0.05)
+    assert eng.engine_state()[0] == 3
+    assert np.array_equal(eng.prefill(prompt, sp, slot=0), want_first)
+    eng.inject_engine_fault(which=0, workgroup=77, skip=10)
+    got, gn = eng.decode(24, [sp], poll=8)
+    assert eng.engine_state()[:2] == (3, 1), (eng.engine_state(), eng.frame_path())
+    assert gn[0] == wn[0] and np.array_equal(got[0, : gn[0]], want[0, : wn[0]]), int(np.argmax((got[0] != want[0]).any(axis=1)))
+    eng.inject_engine_fault(which=1, workgroup=3)
+    first2 = eng.prefill_many([prompt2], [sp])[0]
+    assert np.array_equal(first2, want2_first)
+    flags, strikes, _ = eng.engine_state()
+    assert (flags, strikes) == (0, 2) and "turned off" in eng.frame_path()
+    d, nd = eng.decode(8, [sp], poll=8)
+    assert np.array_equal(d[0, : nd[0]], want2[0, : wn2[0]])
+    other, _ = make_pair(shape, "bf16", max_new_tokens=16, std=0.05)      # the seat was released at the second strike
+    assert other.engine_state()[0] == 3, other.frame_path()
+    other.close()
+    eng.close()
+
+
 def test_second_context_on_the_device_keeps_the_launch_path(monkeypatch):
     """One engine context per device and process: a second AR context takes the launch path (and says why); when the first
     is closed, a new one gets the engine."""
