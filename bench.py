@@ -331,6 +331,7 @@ def main():
                 "rtf": round(elapsed / audio_s, 5) if audio_s > 0 else None,
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                             "traffic_source": "none: no counter pass exists for the batch workload",
                              "kernel": "lock-step decode frames (one pass over the weights per frame step for all slots + each slot's K/V), per GPU",
                              "frame_steps": int(steps_run), "ms_per_frame_step": round(elapsed * world / max(steps_run, 1) * 1e3, 4)},
                 "cpu_baseline": None}))
@@ -424,12 +425,15 @@ def main():
     per_frame_bytes = fb["total"] + KV_BYTES_PER_POS * pos_mid
     frame_ms = ms_graph / NPF
     achieved = per_frame_bytes / (frame_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if os.path.exists(tpath):  # HBM bytes per frame from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on this bench (eager frames)
-        traffic = json.load(open(tpath)).get("hbm_bytes_per_frame")
+    # HBM-side bytes per frame: NOT measured by this run - the newest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    # over this bench with eager frames (FT_NO_GRAPH; counters and stream capture do not go together), profiles/README.md
+    traffic, traffic_source = None, None
+    for rr in ("r04", "r03", "r02"):
+        tpath = os.path.join(ROOT, "profiles", rr + "_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_frame")
+            traffic_source = f"profiles/{rr}_traffic.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, eager frames; not this run)"
+            break
     parts = {}
     for name, ms_k, nbytes in (("slow_stack", seg[0], fb["slow"] + KV_BYTES_PER_POS * pos_mid), ("head_and_draw", seg[1], fb["head"]),
                                ("fast_loop", seg[2], fb["fast"])):
@@ -437,7 +441,7 @@ def main():
         parts[name] = {"ms": round(per, 4), "algorithmic_GB": round(nbytes / 1e9, 4),
                        "GBps": round(nbytes / (per * 1e-3) / 1e9, 1) if per > 0 else None}
     roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "kernel": ("one decode frame = ft::slow_engine_kernel + vocabulary head gemv + semantic draw + ft::fast_engine_kernel"
                        if flags == 3 else "one decode frame (launch path: gemv / attention / sampler kernels)"),
             "launches_per_frame": nodes, "bytes_per_frame": int(per_frame_bytes), "frame_us": round(frame_ms * 1e3, 2),
