@@ -550,6 +550,57 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Prompt pass (bf16, MFMA attention): q/k nn.RMSNorm, interleaved RoPE and the K/V append of EVERY prompt position in one
+// launch - one block per position, a wave per head, the arithmetic of attn_decode_kernel's first phase (llama.py:207-209,
+// 246-248, 594-618, 142-149).  Leaves the finished queries [row][H * hd] in bf16 for flash_prefill_kernel.
+// (Before: the decode attention kernel in its kv_only mode, one block per position AND kv head: 35 us per layer at 780
+// positions.)
+// ------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(256) void prefill_rope_append_kernel(AttnP p) {
+    constexpr int HP = HD / 2;
+    static_assert(HP <= 64, "one lane per rotated pair");
+    const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pos = p.pos_off + row;
+    const float* qkv = p.qkv + (size_t)row * p.ldq;
+    const bf16_t* qn = reinterpret_cast<const bf16_t*>(p.qn);
+    const bf16_t* kn = reinterpret_cast<const bf16_t*>(p.kn);
+    bf16_t* kc = reinterpret_cast<bf16_t*>(p.kc);
+    bf16_t* vc = reinterpret_cast<bf16_t*>(p.vc);
+    float c = 1.f, sn = 0.f;
+    if (lane < HP) { c = p.rope[((size_t)pos * HP + lane) * 2]; sn = p.rope[((size_t)pos * HP + lane) * 2 + 1]; }
+    const int items = p.H + 2 * p.Hkv;
+    for (int item = wave; item < items; item += 4) {
+        const float* src = qkv + (size_t)item * HD;
+        float x0 = 0.f, x1 = 0.f;
+        if (lane < HP) { x0 = src[2 * lane]; x1 = src[2 * lane + 1]; }
+        if (item >= p.H + p.Hkv) {           // a value head: stored as it is
+            const int kvh = item - p.H - p.Hkv;
+            if (lane < HP) {
+                bf16_t* dst = vc + ((size_t)kvh * p.n_slots + pos) * HD;
+                dst[2 * lane] = f32_to_bf16_bits(x0); dst[2 * lane + 1] = f32_to_bf16_bits(x1);
+            }
+            continue;
+        }
+        const bf16_t* gain = item < p.H ? qn : kn;
+        if (gain) {
+            const float ss = wave_sum(x0 * x0 + x1 * x1);
+            const float inv = rsqrt_exact(ss / (float)HD + p.eps);
+            if (lane < HP) {
+                x0 = round_bf16((x0 * inv) * ld_elem(gain, 2 * lane));
+                x1 = round_bf16((x1 * inv) * ld_elem(gain, 2 * lane + 1));
+            }
+        }
+        if (lane < HP) {
+            const float r0 = round_bf16(x0 * c - x1 * sn), r1 = round_bf16(x1 * c + x0 * sn);
+            bf16_t* dst = item < p.H ? p.q_out + (size_t)row * p.H * HD + (size_t)item * HD
+                                     : kc + ((size_t)(item - p.H) * p.n_slots + pos) * HD;
+            dst[2 * lane] = f32_to_bf16_bits(r0); dst[2 * lane + 1] = f32_to_bf16_bits(r1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Slow-layer decode attention of WIDE lock-step batches (bf16, wide_kernels.h): one block per (kv head, row) walks the row's
 // whole context.  Same inputs, rounding points and cache append as attn_decode_kernel (q/k nn.RMSNorm, interleaved RoPE,
 // f32 scores and probabilities, one rounding of y), but the softmax is taken in two passes - all scores to LDS, the

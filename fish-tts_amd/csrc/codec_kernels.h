@@ -8,6 +8,8 @@
 //   * Linear / 1x1 conv: one tap
 // Snake (x + sin^2(ax)/a) is applied once per element in the producer's epilogue, never per tap.
 #pragma once
+#include <algorithm>
+
 #include "common.h"
 
 namespace ft {
@@ -390,6 +392,97 @@ __global__ __launch_bounds__(64 * NWM * NWN) void tapgemm64_kernel(TapGemmP p) {
     }
 }
 
+// Plain Linear (one tap, no halo) on the same tiles, for the prompt pass: A and B tiles of DEPTH K-steps travel in registers
+// at any time (the pipelined kernel above has its A stripe one step ahead only - enough behind seven taps, not for a
+// linear: at 780 prompt rows every step waited ~2 us for its rows, 38 us per product).  Two LDS buffers, one barrier per
+// step: step k's tiles are written to buffer k % 2 while buffer (k + 1) % 2 may still be read by waves one barrier behind.
+template <int BM, int BN, int NWM, int NWN, int DEPTH>
+__global__ __launch_bounds__(64 * NWM * NWN) void lingemm_kernel(TapGemmP p) {
+    constexpr int BK = 64, NTHR = 64 * NWM * NWN, LD = BK + 8, QPR = BK / 8;
+    constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
+    static_assert(WM % 16 == 0 && WN % 16 == 0 && DEPTH % 2 == 0, "whole MFMA tiles per wave; buffer parity follows the unrolled step");
+    static_assert((BM * QPR) % NTHR == 0 && (BN * QPR) % NTHR == 0, "every thread moves whole 16-byte pieces of both tiles");
+    constexpr int ACH = (BM * QPR) / NTHR, BCH = (BN * QPR) / NTHR;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    bf16_t* const A0 = lds;
+    bf16_t* const B0 = lds + 2 * BM * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    U4 ar[DEPTH][ACH], br[DEPTH][BCH];
+    auto load = [&](U4 (&a)[ACH], U4 (&b)[BCH], int step) {
+        const int k0 = step * BK;
+#pragma unroll
+        for (int u = 0; u < ACH; ++u) {
+            const int c = tid + NTHR * u, r = c / QPR, q = c % QPR;
+            // rows past the end re-read the last row (their products are never stored): every load is unconditional, so the
+            // counted waits of the pipeline stay exact (a predicated load costs a branch and a full drain per step)
+            a[u] = *reinterpret_cast<const U4*>(p.X + (size_t)min(m0 + r, p.T_in - 1) * p.ldx + k0 + q * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < BCH; ++u) {
+            const int c = tid + NTHR * u, r = c / QPR, q = c % QPR;
+            b[u] = *reinterpret_cast<const U4*>(p.W + (size_t)min(n0 + r, p.N - 1) * p.K + k0 + q * 8);
+        }
+    };
+    auto stage = [&](const U4 (&a)[ACH], const U4 (&b)[BCH], bf16_t* As, bf16_t* Bs) {
+#pragma unroll
+        for (int u = 0; u < ACH; ++u) {
+            const int c = tid + NTHR * u, r = c / QPR, q = c % QPR;
+            *reinterpret_cast<U4*>(&As[r * LD + q * 8]) = a[u];
+        }
+#pragma unroll
+        for (int u = 0; u < BCH; ++u) {
+            const int c = tid + NTHR * u, r = c / QPR, q = c % QPR;
+            *reinterpret_cast<U4*>(&Bs[r * LD + q * 8]) = b[u];
+        }
+    };
+    // K / 64 is a multiple of DEPTH (the host checks): no branch sits between a load and its use, and the loads past the end
+    // re-read the last step's tiles, so the compiler's counted waits (vmcnt) never have to drain the pipeline
+    const int nsteps = p.K / BK;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) load(ar[d], br[d], d);
+    for (int base = 0; base < nsteps; base += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int step = base + d;
+            bf16_t* As = A0 + (d & 1) * BM * LD;
+            bf16_t* Bs = B0 + (d & 1) * BN * LD;
+            stage(ar[d], br[d], As, Bs);
+            __syncthreads();
+            load(ar[d], br[d], min(step + DEPTH, nsteps - 1));
+#pragma unroll
+            for (int kk = 0; kk < BK / 32; ++kk) {
+                bf16x8 af[TM], bfr[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * WM + i * 16 + fr) * LD + kk * 32 + fq * 8]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * WN + j * 16 + fr) * LD + kk * 32 + fq * 8]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    const bool vec_ok = p.act != ACT_SWIGLU && (p.N % 8) == 0 && (p.n_mod % 8) == 0 && (p.ldo % 8) == 0 && (p.ldr % 8) == 0;
+    if (vec_ok) tapgemm_epilogue_lds<BM, BN, TM, TN, NWM, NWN>(p, acc, reinterpret_cast<float*>(lds), m0, n0, 0, wm, wn, fr, fq);
+    else { __syncthreads(); tapgemm_epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, 0, fr, fq); }
+}
+template <int BM, int BN, int NWM>
+constexpr size_t lingemm_lds_bytes() {
+    return std::max((size_t)2 * (BM + BN) * (64 + 8) * 2, (size_t)(BM / NWM) * (BN + 4) * 4);
+}
+
 // ---- prompt-pass attention on the matrix cores (llama.py:229-283 with the causal mask of 437) -----------------------
 // One block = 64 query positions of one query head (4 waves x 16 rows); K and V^T tiles of 32 cached positions are staged
 // in LDS once per block and shared by the waves.  S = Q K^T and O += P V run on v_mfma_f32_16x16x32_bf16; the softmax is
@@ -434,25 +527,26 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashP p) {
     for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.f; }
     const int last_row = min(q0 + 63, p.S - 1);
     const int kmax = p.pos0 + last_row;                    // last visible key of the block
-    // K/V rows of a tile travel in registers one tile ahead of their use (global loads overlap the MFMAs of the
-    // previous tile); each thread owns CPT 16-byte pieces of the [KT][HD] tile
+    // K/V rows of a tile travel in registers TWO tiles ahead of their use, in two named register sets; every load is
+    // unconditional (rows past the last visible key re-read that key's row: they are masked below), so no branch sits between
+    // a load and its use and the counted waits never drain the pipeline.  Each thread owns CPT 16-byte pieces of a tile.
     constexpr int CPT = KT * (HD / 8) / 256;
-    U4 kreg[CPT], vreg[CPT];
-    auto fetch = [&](int kt) {
+    U4 kregA[CPT], vregA[CPT], kregB[CPT], vregB[CPT];
+    auto fetch = [&](U4 (&kreg)[CPT], U4 (&vreg)[CPT], int kt) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int c = tid + i * 256;
             const int kr = c / (HD / 8), d8 = (c % (HD / 8)) * 8;
-            const int j = kt + kr;
-            kreg[i] = U4{0u, 0u, 0u, 0u}; vreg[i] = U4{0u, 0u, 0u, 0u};
-            if (j <= kmax) {
-                kreg[i] = *reinterpret_cast<const U4*>(kc + (size_t)j * HD + d8);
-                vreg[i] = *reinterpret_cast<const U4*>(vc + (size_t)j * HD + d8);
-            }
+            const int j = min(kt + kr, kmax);
+            kreg[i] = *reinterpret_cast<const U4*>(kc + (size_t)j * HD + d8);
+            vreg[i] = *reinterpret_cast<const U4*>(vc + (size_t)j * HD + d8);
         }
     };
-    fetch(0);
-    for (int kt = 0; kt <= kmax; kt += KT) {
+    fetch(kregA, vregA, 0);
+    fetch(kregB, vregB, KT);
+    // V^T in LDS: the 8-key group g of row d sits at group g ^ ((d / 8) & 3) - the 16 lanes that write one key of 16 different
+    // 8-row bands then spread over four banks instead of one (their rows are 8 x LDV halfs = a multiple of 32 dwords apart)
+    auto tile = [&](U4 (&kreg)[CPT], U4 (&vreg)[CPT], const int kt) {
         __syncthreads();                                    // previous tile fully consumed
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
@@ -460,11 +554,12 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashP p) {
             const int kr = c / (HD / 8), d8 = (c % (HD / 8)) * 8;
             *reinterpret_cast<U4*>(&Ks[kr * LDK + d8]) = kreg[i];
             const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vreg[i]);
+            const int col = (((kr >> 3) ^ ((d8 >> 3) & 3)) << 3) + (kr & 7);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) Vt[(d8 + e) * LDV + kr] = ve[e];
+            for (int e = 0; e < 8; ++e) Vt[(d8 + e) * LDV + col] = ve[e];
         }
         __syncthreads();
-        if (kt + KT <= kmax) fetch(kt + KT);
+        fetch(kreg, vreg, kt + 2 * KT);
         // S = Q K^T for two 16-key sub-tiles: lane holds S[q = 4 fq + r][key = sub * 16 + fr]
         f32x4 sc[2];
 #pragma unroll
@@ -519,10 +614,16 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashP p) {
         const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Pl[fr * LDP + fq * 8]);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[(t * 16 + fr) * LDV + fq * 8]);
+            const int d = t * 16 + fr;
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[d * LDV + ((fq ^ ((d >> 3) & 3)) << 3)]);
             O[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, vf, O[t], 0, 0, 0);
             O[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, vf, O[t], 0, 0, 0);
         }
+    };
+    // tiles in pairs (one per register set); a tile wholly past the last visible key adds nothing (every score masked)
+    for (int kt = 0; kt <= kmax; kt += 2 * KT) {
+        tile(kregA, vregA, kt);
+        tile(kregB, vregB, kt + KT);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1110,7 +1211,7 @@ struct RvqEncP {
 };
 static __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqEncP p) {
     extern __shared__ float res[];           // [D]
-    __shared__ float part[4][16];
+    __shared__ double part[4][16];
     __shared__ float e_s[16];
     __shared__ float bestv[4];
     __shared__ int besti[4];
@@ -1121,14 +1222,17 @@ static __global__ __launch_bounds__(256) void rvq_encode_kernel(RvqEncP p) {
     __syncthreads();
     for (int q = 0; q < p.R; ++q) {
         const float* W = p.inw + (size_t)q * cd * D;
+        // the projection is accumulated in f64 (f32 operands): its f32 result is then the correctly rounded one at any width
+        // (1024 at the real shapes), so an index can differ from an f32 evaluation only where that evaluation's own
+        // accumulation error decides
         for (int c = 0; c < cd; ++c) {
-            float a = 0.f;
-            for (int d = tid; d < D; d += 256) a = fmaf(W[(size_t)c * D + d], res[d], a);
-            a = wave_sum(a);
+            double a = 0.0;
+            for (int d = tid; d < D; d += 256) a = fma((double)W[(size_t)c * D + d], (double)res[d], a);
+            for (int sft = 32; sft >= 1; sft >>= 1) a += __shfl_xor(a, sft);
             if (lane == 0) part[wave][c] = a;
         }
         __syncthreads();
-        if (tid < cd) e_s[tid] = (((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]) + p.inb[q * cd + tid];
+        if (tid < cd) e_s[tid] = (float)((((part[0][tid] + part[1][tid]) + part[2][tid]) + part[3][tid]) + (double)p.inb[q * cd + tid]);
         __syncthreads();
         float nn = 0.f;
         for (int c = 0; c < cd; ++c) nn += e_s[c] * e_s[c];

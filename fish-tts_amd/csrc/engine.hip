@@ -1280,11 +1280,19 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
     } else if (fused) {
         L.err = hipErrorInvalidValue;   // the fused norm exists on the skinny kernel only (callers check the shapes)
     } else if (mode >= 1 && K % 64 == 0 && N % 128 == 0) {
-        // long prompts (reference audio): the pipelined tile kernel of the codec
-        // 64 x 64 x 64 tiles on 4 waves up to 511 rows (the 4-wave 128 x 128 tile spills: 25.8 vs 12.8 ms at Lp = 1500);
-        // from 512 rows 128 x 128 on 8 waves (the 64 x 64 tile is bound by the L2 bandwidth of its weight re-reads)
+        // long prompts (reference audio): MFMA tiles with four K-steps of both operands in flight (lingemm_kernel) - 128 x 128
+        // on 8 waves for the wide products from 512 rows, 64 x 64 on 4 waves otherwise (the N = 1024 products would leave
+        // 200 CUs idle on the large tile: 56 workgroups at 780 rows).  Measured at 780 rows (tools/prefill_probe.py): 7.05 ms
+        // with the codec's one-step-ahead tile kernel, 5.51 ms with these (3.56 against 5.61 ms at 256 rows).
+        auto lg = [&](auto kern, dim3 grid, int threads, size_t lds) {
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            kern<<<grid, threads, lds, L.s>>>(p);
+        };
         constexpr int tile8_s = 512;
-        if (S >= tile8_s) {
+        if (K % 256 == 0) {
+            if (S >= tile8_s && N > 1024) lg(lingemm_kernel<128, 128, 2, 4, 4>, dim3((S + 127) / 128, N / 128), 512, lingemm_lds_bytes<128, 128, 2>());
+            else lg(lingemm_kernel<64, 64, 2, 2, 4>, dim3((S + 63) / 64, N / 64), 256, lingemm_lds_bytes<64, 64, 2>());
+        } else if (S >= tile8_s) {
             constexpr size_t lds8 = std::max((size_t)((128 + 56) + 2 * 128) * (64 + 8) * 2, (size_t)(128 / 2) * (128 + 4) * 4);
             static DevOnce once8;
             once8.run([] { hipFuncSetAttribute((const void*)tapgemm64_kernel<128, 128, 64, 2, 4>,
@@ -1336,6 +1344,12 @@ static void prefill_gemm(Launch& L, int slot, int Lp, int pos0, bool with_tail =
         a.q_out = flash ? ctx->pf_qbf : nullptr;
         for (int pass = 0; pass < 2; ++pass) {
             a.kv_only = pass == 0; a.no_append = pass == 1;
+            if (pass == 0 && flash) {       // every position's q k v in one launch of Lp blocks
+                if (c.head_dim == 128) prefill_rope_append_kernel<128><<<Lp, 256, 0, L.s>>>(a);
+                else prefill_rope_append_kernel<64><<<Lp, 256, 0, L.s>>>(a);
+                L.chk();
+                continue;
+            }
             if (pass == 1 && flash) {
                 FlashP fp{ctx->pf_qbf, (const bf16_t*)a.kc, (const bf16_t*)a.vc, ctx->pf_ybf, Lp, c.n_head, c.n_local_heads,
                           c.head_dim, ctx->n_slots, pos0, a.scale};

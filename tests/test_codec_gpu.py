@@ -357,6 +357,68 @@ def test_encode_vs_bf16_oracle_like_for_like():
     eng.close()
 
 
+def test_s1_mini_codec_encode_three_way_at_real_widths():
+    """Encode side at the REAL widths (synthesizer.py:199-269: encoder 64..1024 channels, strides 2,4,8,8, the window-512
+    4-layer transformer, 1024-wide pre-module, 4096 + 9 x 1024 codebooks) on 121 frames of audio, three code sets: GPU
+    (bf16 operands and activations, f32 accumulation), the oracle in bfloat16 - the precision the reference encodes in
+    (synthesizer.py:289-291, 345-353) - and the oracle in f32.  Indices are argmaxes over near neighbours in an 8-dim
+    space, so any two bf16 evaluations flip some against each other; asserted: the GPU agrees with the bf16 oracle on the
+    semantic index no worse than the two ORACLE precisions agree with each other minus 5 points (measured here: f32~bf16
+    oracle 0.885 at 61 frames), its rebuilt latents sit no farther from the bf16 oracle's than 1.25 x the distance
+    between the oracle precisions, and an absolute floor of 75 % semantic agreement."""
+    shape = C.CodecShape()
+    eng, orc = make_codec_with_encoder(shape, max_frames=128)
+    w = C.random_weights(shape, seed=0)
+    w.update(C.random_encoder_weights(shape, seed=1))
+    orb = C.CodecOracle(shape, w, dtype=torch.bfloat16)
+    n = 121 * shape.enc_frame_len - 5
+    audio = _test_audio(n, seed=12)
+    a = torch.from_numpy(audio)[None, None]
+    want32, _ = orc.encode(a)
+    want16, _ = orb.encode(a)
+    got = eng.encode(audio)
+    assert got.shape == tuple(want16[0].shape) == (10, 121)
+
+    def latents(codes):
+        orc.quantizer_decode(codes)
+        return orc.taps["rvq"].clone()
+    z32, z16, zg = latents(want32), latents(want16), latents(torch.from_numpy(got)[None])
+
+    def rel(x, y):
+        return float((x - y).pow(2).mean().sqrt() / y.pow(2).mean().sqrt())
+    agree_g16 = float(np.mean(got[0] == want16[0, 0].numpy()))
+    agree_g32 = float(np.mean(got[0] == want32[0, 0].numpy()))
+    agree_3216 = float((want32[0, 0] == want16[0, 0]).float().mean())
+    d_g16, d_3216 = rel(zg, z16), rel(z32, z16)
+    print(f"real widths, 121 frames: semantic agreement GPU~bf16 oracle {agree_g16:.3f}, GPU~f32 oracle {agree_g32:.3f} "
+          f"(f32~bf16 oracle {agree_3216:.3f}); latent rel rms {d_g16:.3f} ({d_3216:.3f})")
+    assert agree_g16 >= 0.75 and agree_g16 >= agree_3216 - 0.05, (agree_g16, agree_3216)
+    assert d_g16 <= 1.25 * d_3216 + 0.02, (d_g16, d_3216)
+    eng.close()
+
+
+def test_rvq_search_on_given_latents_at_real_widths():
+    """test_rvq_search_is_exact_on_given_latents at the real quantiser widths (1024-wide latents, 4096 + 9 x 1024 rows of
+    8): the search accumulates its projections in f64, so where it differs from the f32 oracle the ORACLE's own
+    top-1/top-2 gap must be inside the accumulation error of a 1024-term f32 sum (5e-5 on scores of O(1))."""
+    shape = C.CodecShape()
+    eng, orc = make_codec_with_encoder(shape, max_frames=128)
+    audio = _test_audio(100 * shape.enc_frame_len - 7, seed=21)
+    want, _ = orc.encode(torch.from_numpy(audio)[None, None])
+    z = orc.taps["pre"][0].transpose(0, 1).contiguous().numpy()
+    got = eng.rvq_encode(z)
+    assert got.shape == want[0].shape == (10, 100)
+    diff = np.argwhere(got != want[0].numpy())
+    first = {}
+    for q, t in diff:
+        first[t] = min(first.get(t, 99), q)
+    gaps = orc.taps["vq_gap"]
+    for t, q in first.items():
+        assert float(gaps[q][0, t]) < 5e-5, (t, q, float(gaps[q][0, t]))
+    assert len(first) <= 10, len(first)          # and they are rare
+    eng.close()
+
+
 def test_encode_reference_api():
     """FishTTS.encode_reference (synthesizer.py:325-357): WAV bytes -> VoiceProfile; 16-bit PCM scaling, resampling of
     a non-44.1 kHz file, int64 codes of the codec's frame count."""
