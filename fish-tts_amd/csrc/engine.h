@@ -110,6 +110,8 @@ struct ft_ctx {
     bool eng_pair = false;          // fast loop: positions 0 and 1 as two rows of the first pass
     bool xl_shape = false;          // 8 kv heads x (2 x 128) on 8 XCDs x 32 CUs: 32 KV splits always (engine.hip: ar_alloc)
     bool eng_xl = false;            // the slow stack's engine runs its XCD-local form (one kv head per XCD)
+    const void* eng_slow_fn = nullptr;   // the instantiations of the two engine kernels this model's widths match (engine.hip: eng_shapes)
+    const void* eng_fast_fn = nullptr;
     size_t eng_pool_bytes = 0, eng_gpart_bytes = 0, eng_fast_bytes = 0;   // hand-off allocations (zeroed again after an abort)
     // A hand-off that timed out (ENG_CTL_ABORT) is survivable: the host clears the control words and the hand-off pools,
     // redoes the affected frames on the launch path (eng_suspended) and turns the engine off for this context after

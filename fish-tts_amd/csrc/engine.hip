@@ -471,6 +471,39 @@ static bool eng_fits_cu(const void* fn, size_t lds, size_t lds_cap, const char* 
     return fits;
 }
 
+// The shape classes the engine kernels are instantiated for (frame_engine.h: EngSlowShape / EngFastShape; any depth).  The
+// first entries are openaudio-s1-mini's widths (config.json: llama.py:74-86); the others cover the two fields SURVEY.md could
+// not verify against a real config.json - the feed-forward width and the number of kv heads (four kv heads lose the
+// one-kv-head-per-XCD form of the attention and take the general split form).
+typedef void (*eng_slow_fn_t)(SlowEngP);
+typedef void (*eng_fast_fn_t)(FastEngP);
+typedef void (*eng_qkv0_fn_t)(const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, int, int, int, float);
+struct EngSlowEntry { int D, H, HKV, HDIM, F, SQ, SF, SO; eng_slow_fn_t xl, plain; };
+struct EngFastEntry { int D, H, HKV, HDIM, F, V, SQ, SF, SO; eng_fast_fn_t loop; eng_qkv0_fn_t qkv0; };
+template <typename S, bool WITH_XL>
+static EngSlowEntry eng_slow_entry() {
+    eng_slow_fn_t xl = nullptr;
+    if constexpr (WITH_XL) xl = slow_engine_kernel<S, true>;
+    return EngSlowEntry{S::D, S::H, S::HKV, S::HDIM, S::F, S::SQ, S::SF, S::SO, xl, slow_engine_kernel<S, false>};
+}
+template <typename S>
+static EngFastEntry eng_fast_entry() {
+    return EngFastEntry{S::D, S::H, S::HKV, S::HDIM, S::F, S::V, S::SQ, S::SF, S::SO, fast_engine_kernel<S, 10>, eng_qkv0_table_kernel<S>};
+}
+static const EngSlowEntry* eng_slow_shapes(int* n) {
+    static const EngSlowEntry tab[] = {eng_slow_entry<EngSlowS1, true>(), eng_slow_entry<EngSlowShape<1024, 16, 8, 128, 4096>, true>(),
+                                       eng_slow_entry<EngSlowShape<1024, 16, 4, 128, 3072>, false>()};
+    *n = (int)(sizeof tab / sizeof tab[0]);
+    return tab;
+}
+static const EngFastEntry* eng_fast_shapes(int* n) {
+    // (four fast kv heads of 64 would leave a workgroup 6 rows of Wqkv: not a whole number of 4-granule groups - such a model
+    // keeps its codebook loop on launches)
+    static const EngFastEntry tab[] = {eng_fast_entry<EngFastS1>(), eng_fast_entry<EngFastShape<1024, 16, 8, 64, 4096, 1024>>()};
+    *n = (int)(sizeof tab / sizeof tab[0]);
+    return tab;
+}
+
 // false: `why` says what kept the engine off (allocations made so far are released by the caller)
 static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
     const ft_ar_config& c = ctx->c;
@@ -488,17 +521,24 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
     const int HD = c.n_head * c.head_dim;
     const int qkvN = (c.n_head + 2 * c.n_local_heads) * c.head_dim;
     auto per = [&](int units) { return (units + nb - 1) / nb; };
-    // (the kernels carry these widths as compile-time constants: frame_engine.h ENG_D ..)
-    const bool shape_ok = c.dim == ENG_D && c.n_head == ENG_H && c.n_local_heads == ENG_HKV && c.head_dim == ENG_HD &&
-                          c.intermediate_size == ENG_F && HD == 2048 && c.fast_dim == c.dim && c.n_layer >= 1 && c.n_layer < ENG_EPOCH_STEP &&
-                          per(qkvN) <= ENG_SQ * ENG_CW && per(c.dim) <= ENG_SO * ENG_CW && per(c.intermediate_size) <= ENG_SF * ENG_CW &&
+    // (the kernels carry the widths as compile-time constants: one instantiation per shape class)
+    const EngSlowEntry* se = nullptr;
+    {
+        int n = 0;
+        const EngSlowEntry* tab = eng_slow_shapes(&n);
+        for (int i = 0; i < n && !se; ++i)
+            if (c.dim == tab[i].D && c.n_head == tab[i].H && c.n_local_heads == tab[i].HKV && c.head_dim == tab[i].HDIM && c.intermediate_size == tab[i].F)
+                se = &tab[i];
+    }
+    const bool shape_ok = se && c.fast_dim == c.dim && c.n_layer >= 1 && c.n_layer < ENG_EPOCH_STEP &&
+                          per(qkvN) <= se->SQ * ENG_CW && per(c.dim) <= se->SO * ENG_CW && per(c.intermediate_size) <= se->SF * ENG_CW &&
                           qkvN % (4 * nb) == 0 && c.dim % (4 * nb) == 0 && c.intermediate_size % (4 * nb) == 0 && per(qkvN) <= ENG_LINE &&
-                          c.n_local_heads * ctx->nsplit_max <= nb && c.head_dim % (4 * ctx->nsplit_max) == 0 && nb == ENG_NB;
+                          per(c.intermediate_size) <= ENG_LINE && c.n_local_heads * ctx->nsplit_max <= nb && c.head_dim % (4 * ctx->nsplit_max) == 0 && nb == ENG_NB;
     if (!shape_ok) {
-        char buf[256];
-        snprintf(buf, sizeof buf, "widths outside the engine's instantiation (dim %d, heads %d / %d x %d, ffn %d, fast_dim %d on %d CUs; "
-                 "built for 1024, 16 / 8 x 128, 3072, 1024 on 256 CUs)", c.dim, c.n_head, c.n_local_heads, c.head_dim,
-                 c.intermediate_size, c.fast_dim, nb);
+        char buf[320];
+        snprintf(buf, sizeof buf, "widths outside the engine's instantiations (dim %d, heads %d / %d x %d, ffn %d, fast_dim %d on %d CUs; "
+                 "built for dim 1024, 16 heads x 128 with 8 kv heads and ffn 3072 or 4096, or 4 kv heads and ffn 3072, on 256 CUs)", c.dim, c.n_head,
+                 c.n_local_heads, c.head_dim, c.intermediate_size, c.fast_dim, nb);
         why = buf;
         return false;
     }
@@ -547,7 +587,9 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
     const size_t lds_cap = prop.maxSharedMemoryPerMultiProcessor;
     if (ctx->eng_lds_slow > lds_cap) { why = "the slow stack's LDS need exceeds the CU's"; return false; }
     ctx->eng_xl = ctx->xl_shape && nb == 256 && ctx->nsplit_max == 32 && c.n_local_heads * 32 == nb;
-    const void* slow_fn = ctx->eng_xl ? (const void*)slow_engine_kernel<2, 4, 6, 2, true> : (const void*)slow_engine_kernel<2, 4, 6, 2, false>;
+    ctx->eng_xl = ctx->eng_xl && se->xl != nullptr;
+    ctx->eng_slow_fn = (const void*)(ctx->eng_xl ? se->xl : se->plain);
+    const void* slow_fn = ctx->eng_slow_fn;
     if (!hip_ok(hipFuncSetAttribute(slow_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->eng_lds_slow),
                 "hipFuncSetAttribute(slow_engine_kernel)")) return false;
     // every workgroup must be resident at once, one per CU: does one fit a CU at all (registers, LDS, waves)?
@@ -558,13 +600,22 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
     // ---- fast codebook loop
     const int HDf = c.fast_n_head * c.fast_head_dim;
     const int fqkvN = (c.fast_n_head + 2 * c.fast_n_local_heads) * c.fast_head_dim;
-    const bool fast_ok = !getenv("FT_NO_FAST_ENGINE") && c.fast_dim == ENG_FD && c.fast_n_head == ENG_FH && c.fast_n_local_heads == ENG_FHKV &&
-                         c.fast_head_dim == ENG_FHD && c.fast_intermediate_size == ENG_FF_DIM && ctx->fastV == ENG_FV && HDf == 1024 && c.n_fast_layer >= 1 &&
+    const EngFastEntry* fe = nullptr;
+    {
+        int n = 0;
+        const EngFastEntry* tab = eng_fast_shapes(&n);
+        for (int i = 0; i < n && !fe; ++i)
+            if (c.fast_dim == tab[i].D && c.fast_n_head == tab[i].H && c.fast_n_local_heads == tab[i].HKV && c.fast_head_dim == tab[i].HDIM &&
+                c.fast_intermediate_size == tab[i].F && ctx->fastV == tab[i].V)
+                fe = &tab[i];
+    }
+    const bool fast_ok = !getenv("FT_NO_FAST_ENGINE") && fe && HDf == c.fast_dim && c.n_fast_layer >= 1 &&
                          c.num_codebooks >= 2 && c.num_codebooks <= 10 && fqkvN % (4 * nb) == 0 && ctx->fastV % (4 * nb) == 0 &&
-                         per(fqkvN) <= ENG_FQ * ENG_CW && per(c.fast_dim) <= ENG_FO * ENG_CW && per(c.fast_intermediate_size) <= ENG_FF * ENG_CW &&
-                         per(ctx->fastV) <= ENG_FO * ENG_CW && per(fqkvN) <= ENG_LINE && ctx->fastV <= 1024 && c.codebook_size <= 65536 &&
-                         true;
-    if (!fast_ok) { why += "; fast loop on launches (FT_NO_FAST_ENGINE, or fast widths outside 1024 / 16 + 8 heads x 64 / 3072 / 1024 codes used, <= 10 codebooks)"; return true; }
+                         per(fqkvN) <= fe->SQ * ENG_CW && per(c.fast_dim) <= fe->SO * ENG_CW && per(c.fast_intermediate_size) <= fe->SF * ENG_CW &&
+                         per(ctx->fastV) <= fe->SO * ENG_CW && per(fqkvN) <= ENG_LINE && per(c.fast_intermediate_size) <= ENG_LINE && ctx->fastV <= 1024 &&
+                         c.codebook_size <= 65536;
+    if (!fast_ok) { why += "; fast loop on launches (FT_NO_FAST_ENGINE, or fast widths outside the instantiations: 1024 / 16 + 8 heads x 64 / ffn 3072 or 4096 / 1024 codes used, <= 10 codebooks)"; return true; }
+    ctx->eng_fast_fn = (const void*)fe->loop;
     // from here on a failure keeps the slow engine and leaves the fast loop on launches
     auto fast_off = [&](const std::string& w2) { why += "; fast loop on launches (" + w2 + ")"; return true; };
     std::vector<EngLayer> hf(c.n_fast_layer);
@@ -596,16 +647,16 @@ static bool eng_setup_try(ft_ctx* ctx, std::string& why) {
     ctx->eng_lds_fast = eng_fast_lds_bytes(c.fast_dim, fqkvN, HDf, c.fast_intermediate_size, ctx->fastV, (int)nLf, c.num_codebooks, kvw, ctx->eng_pair);
     if (ctx->eng_lds_fast > lds_cap) return fast_off("the codebook loop's LDS need exceeds the CU's");
     ctx->eng_lds_fast = std::max(ctx->eng_lds_fast, (size_t)82 * 1024);
-    if (!hip_ok2(hipFuncSetAttribute((const void*)fast_engine_kernel<2, 2, 6, 10, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (!hip_ok2(hipFuncSetAttribute(ctx->eng_fast_fn, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)ctx->eng_lds_fast), "hipFuncSetAttribute(fast_engine_kernel)")) return fast_off(w2);
-    if (!eng_fits_cu((const void*)fast_engine_kernel<2, 2, 6, 10, 64>, ctx->eng_lds_fast, lds_cap, "codebook-loop", w2)) return fast_off(w2);
+    if (!eng_fits_cu(ctx->eng_fast_fn, ctx->eng_lds_fast, lds_cap, "codebook-loop", w2)) return fast_off(w2);
     // layer 0's q k v of every codebook-embedding row a draw can select (codes < fastV): 4 MB at the s1-mini widths
     if (getenv("FT_NO_QKV0") == nullptr && c.num_codebooks > 2) {
         const size_t tb = (size_t)ctx->fastV * fqkvN * sizeof(bf16_t);
         if (!hip_ok2(hipMalloc((void**)&ctx->eng_qkv0_tab, tb), "hipMalloc(layer-0 q k v table)")) return fast_off(w2);
         const FtLayer& l0 = ctx->flayers[0];
         const size_t lds = ((size_t)c.fast_dim + ENG_MAX_OUT) * sizeof(float);
-        eng_qkv0_table_kernel<2><<<dim3(fqkvN / (ENG_FQ * ENG_CW), 16), ENG_CW * 64, lds, ctx->stream>>>(
+        fe->qkv0<<<dim3(fqkvN / (fe->SQ * ENG_CW), 16), ENG_CW * 64, lds, ctx->stream>>>(
             (const bf16_t*)l0.wqkv, (const bf16_t*)l0.bqkv, (const bf16_t*)l0.attn_norm, (const bf16_t*)ctx->fast_emb,
             (bf16_t*)ctx->eng_qkv0_tab, c.fast_dim, fqkvN, ctx->fastV, c.norm_eps);
         if (!hip_ok2(hipGetLastError(), "eng_qkv0_table_kernel") || !hip_ok2(hipStreamSynchronize(ctx->stream), "eng_qkv0_table_kernel")) {
@@ -753,7 +804,7 @@ static void enqueue_fast_engine(Launch& L) {
     p.samp = s;
     p.noise_cb_stride = ctx->fastV; p.noise_off1 = c.vocab_size;
     p.pair = ctx->eng_pair ? 1 : 0;
-    fast_engine_kernel<2, 2, 6, 10, 64><<<nb, ENG_THREADS, ctx->eng_lds_fast, L.s>>>(p);
+    ((eng_fast_fn_t)ctx->eng_fast_fn)<<<nb, ENG_THREADS, ctx->eng_lds_fast, L.s>>>(p);
     L.chk();
 }
 
@@ -775,8 +826,7 @@ static void enqueue_slow_engine(Launch& L, const int* toks, long tok_row_stride,
     p.gx = ctx->eng_gx; p.gqkv = ctx->eng_gqkv; p.gpart = ctx->eng_gpart; p.gy = ctx->eng_gy; p.gxb = ctx->eng_gxb; p.gg = ctx->eng_gg;
     p.ctl = ctx->eng_ctl; p.x_out = ctx->x + (size_t)m0 * c.dim; p.nt = 1;
     p.rep_delta0 = ctx->eng_relay ? (long)ctx->eng_pool_words : 0; p.rep_stride = ctx->eng_relay ? (long)ctx->eng_pool_words : 0;
-    if (ctx->eng_xl) slow_engine_kernel<2, 4, 6, 2, true><<<ctx->eng_nb, ENG_THREADS, ctx->eng_lds_slow, L.s>>>(p);
-    else slow_engine_kernel<2, 4, 6, 2, false><<<ctx->eng_nb, ENG_THREADS, ctx->eng_lds_slow, L.s>>>(p);
+    ((eng_slow_fn_t)ctx->eng_slow_fn)<<<ctx->eng_nb, ENG_THREADS, ctx->eng_lds_slow, L.s>>>(p);
     L.chk();
 }
 

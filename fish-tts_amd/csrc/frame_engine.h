@@ -26,14 +26,42 @@
 
 namespace ft {
 
-// the one shape class the engine is instantiated for (openaudio-s1-mini's widths, any depth): slow stack / fast stack
-constexpr int ENG_D = 1024, ENG_H = 16, ENG_HKV = 8, ENG_HD = 128, ENG_F = 3072;
-constexpr int ENG_FD = 1024, ENG_FH = 16, ENG_FHKV = 8, ENG_FHD = 64, ENG_FF_DIM = 3072, ENG_FV = 1024;
 constexpr int ENG_NB = 256;              // workgroups of an engine launch = CUs of the chip (8 XCDs x 32)
 constexpr int ENG_WAVES = 8;             // waves per workgroup (one workgroup per CU; 256 VGPRs per wave)
 constexpr int ENG_THREADS = ENG_WAVES * 64;
 constexpr int ENG_CW = 4;                // waves 0..3 own weight rows
 constexpr int ENG_GW = 4;                // waves 4..7 gather the input vector of a phase
+
+// The widths are compile-time constants of the kernels (section "scalar hygiene" of DESIGN.md: run-time widths cost ~300
+// scalar-register spills and the divisions on the hand-off chains); the engine is INSTANTIATED for a short list of shape
+// classes (engine.hip: eng_shapes) and the host's gate picks the one a model's config.json matches - any depth.
+// Slow stack: dim, query heads, kv heads, head_dim, intermediate_size.  Derived: 16-byte weight pieces per lane and row
+// (NT*: 512 contraction elements each), rows / (w1, w3) pairs per compute wave at 256 workgroups (S*), and whether the
+// SwiGLU vector travels three values per 8-byte granule (PK3: whole triples per workgroup, whole 1 KiB pieces).
+template <int D_, int H_, int HKV_, int HDIM_, int F_>
+struct EngSlowShape {
+    static constexpr int D = D_, H = H_, HKV = HKV_, HDIM = HDIM_, F = F_;
+    static constexpr int HD = H * HDIM, QKVN = (H + 2 * HKV) * HDIM, G = H / HKV;
+    static constexpr int NTD = D / 512, NTA = HD / 512, NTF = F / 512;
+    static constexpr int SQ = (QKVN / ENG_NB + ENG_CW - 1) / ENG_CW, SF = (F / ENG_NB + ENG_CW - 1) / ENG_CW, SO = (D / ENG_NB + ENG_CW - 1) / ENG_CW;
+    static constexpr bool PK3 = F % 384 == 0 && (F / ENG_NB) % 3 == 0;
+    static_assert(D % 512 == 0 && HD % 512 == 0 && F % 512 == 0, "weight rows are read as whole 16-byte pieces by 64 lanes");
+    static_assert(QKVN % (4 * ENG_NB) == 0 && D % (4 * ENG_NB) == 0 && F % (4 * ENG_NB) == 0, "whole 16-byte granule groups per workgroup");
+    static_assert(H % HKV == 0 && HDIM % 8 == 0 && HDIM <= 128, "grouped-query attention, 16-byte K/V pieces");
+};
+// Fast stack: fast_dim, heads, kv heads, head_dim, intermediate_size, codes drawn per codebook
+template <int D_, int H_, int HKV_, int HDIM_, int F_, int V_>
+struct EngFastShape {
+    static constexpr int D = D_, H = H_, HKV = HKV_, HDIM = HDIM_, F = F_, V = V_;
+    static constexpr int HD = H * HDIM, QKVN = (H + 2 * HKV) * HDIM, KVW = HKV * HDIM;
+    static constexpr int NTD = D / 512, NTA = HD / 512, NTF = F / 512;
+    static constexpr int SQ = (QKVN / ENG_NB + ENG_CW - 1) / ENG_CW, SF = (F / ENG_NB + ENG_CW - 1) / ENG_CW, SO = (D / ENG_NB + ENG_CW - 1) / ENG_CW;
+    static constexpr bool PK3 = F % 384 == 0 && (F / ENG_NB) % 3 == 0;
+    static_assert(D % 512 == 0 && HD % 512 == 0 && F % 512 == 0 && V == 1024 && HD == D, "fast widths");
+    static_assert(QKVN % (4 * ENG_NB) == 0 && D % (4 * ENG_NB) == 0 && F % (4 * ENG_NB) == 0 && V % (4 * ENG_NB) == 0, "whole granule groups per workgroup");
+};
+typedef EngSlowShape<1024, 16, 8, 128, 3072> EngSlowS1;          // openaudio-s1-mini (the BASELINE shapes)
+typedef EngFastShape<1024, 16, 8, 64, 3072, 1024> EngFastS1;
 // slow stack: the hand-off vectors of layer li live in the buffers of parity li & 1 (tag = epoch + li), so the lines that
 // are polled were written two layers ago and are still in the L2 / memory-side cache instead of cold in HBM
 constexpr int ENG_EPOCH_STEP = 64;       // tags used per launch (>= num_codebooks, >= slow layers)
@@ -279,8 +307,6 @@ __device__ __forceinline__ void eng_gather_x(const EngRelay& rl, const unsigned*
 
 // The packed form (three values per 8-byte granule, eng_gemv<.., PK3>): n values (n % 384 == 0) = n / 384 pieces of 1 KiB;
 // lane l of a piece holds two granules = values 6 l .. 6 l + 5 of the piece.
-static_assert(ENG_F % 384 == 0 && (ENG_F / ENG_NB) % 3 == 0 && ENG_FF_DIM % 384 == 0 && (ENG_FF_DIM / ENG_NB) % 3 == 0,
-              "packed SwiGLU hand-off: whole 1 KiB pieces, whole triples per workgroup");
 __device__ __forceinline__ bool eng_tags3_ok(const U4& v, unsigned tag) { return (v.y >> 16) == tag && (v.w >> 16) == tag; }
 __device__ __forceinline__ void eng_unpack3_to_lds(float* dst, const U4& v) {
     float2 a, b, c;
@@ -715,8 +741,6 @@ struct SlowEngP {
 #define ENG_ASTAMP(wv, k) do { if (p.stamps && gw == (wv) && lane == 0) \
     p.stamps[((size_t)nb * p.n_layer + (size_t)b * p.n_layer + li) * 16 + (k)] = eng_rt(); } while (0)
 
-// units per compute wave and matrix at 256 workgroups: QKV 16 rows -> 4, W13 12 pairs -> 3, Wo / W2 4 rows -> 1
-constexpr int ENG_SQ = 4, ENG_SF = 3, ENG_SO = 1;
 constexpr int ENG_KVST = 6;   // K/V steps of an attention workgroup held in registers (16 positions each at hd = 128)
 
 // which (kv head, split) workgroup b takes in layer li, or -1: the Hkv * nsplit attention workgroups rotate with the layer
@@ -737,9 +761,11 @@ __device__ __forceinline__ int eng_att_role(int b, int nb, int li, int natt) {
 // leaves the XCD.  Needs Hkv XCDs with nb / Hkv workgroups each (checked at run time; a failed census raises the abort
 // word and the host falls back to the launch path).  Per row the arithmetic is that of the launch path at the same split
 // count (attn_decode_kernel + merge_splits4), so the frames stay bit-identical to it.
-template <int NTD, int NTA, int NTF, int G, bool XL = false>
+template <typename S, bool XL = false>
 __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
-    constexpr int SQ = ENG_SQ, SF = ENG_SF, SO = ENG_SO;
+    // units per compute wave and matrix at 256 workgroups (s1-mini: QKV 16 rows -> 4, W13 12 pairs -> 3, Wo / W2 4 rows -> 1)
+    constexpr int NTD = S::NTD, NTA = S::NTA, NTF = S::NTF, G = S::G;
+    constexpr int SQ = S::SQ, SF = S::SF, SO = S::SO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: uniform branches, row offsets in SGPRs)
     const int b = blockIdx.x;
@@ -750,8 +776,8 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
     // The widths are compile-time constants: the host's shape gate (engine.hip: eng_setup_try) admits exactly these.  With
     // run-time widths the kernel spilled ~300 scalar registers into vector lanes and divided by run-time values on its
     // chains (the y layout map alone: six integer divisions per gathered piece).
-    constexpr int D = ENG_D, F = ENG_F, hd = ENG_HD, hp = hd >> 1, H = ENG_H, Hkv = ENG_HKV, HD = H * hd, QKVN = (H + 2 * Hkv) * hd;
-    static_assert(G == H / Hkv, "query heads per kv head");
+    constexpr int D = S::D, F = S::F, hd = S::HDIM, hp = hd >> 1, H = S::H, Hkv = S::HKV, HD = H * hd, QKVN = (H + 2 * Hkv) * hd;
+    static_assert(!XL || (ENG_NB % Hkv == 0 && QKVN % ENG_NB == 0), "XCD-local attention: the workgroups of an XCD share one kv head's rows");
     float* xA = smem;                     // layer input
     float* yS = xA + D;                   // attention output
     float* xB = yS + HD;                  // x' = x + Wo y
@@ -894,7 +920,8 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
             __builtin_amdgcn_sched_barrier(0);
             eng_barrier(); if (*dead) break;                        // B3
             ENG_STAMP(5);
-            eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU, true>(wf, xB, D, p.eps, nullptr, nullptr, p.gg + (size_t)par * VSTR, tag, nullptr, f_lo, f_hi, cw, lane, eo);
+            eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU, S::PK3>(wf, xB, D, p.eps, nullptr, nullptr,
+                                                                   p.gg + (size_t)par * VSTR + (S::PK3 ? 0 : eng_pub(b, f_lo)), tag, nullptr, f_lo, f_hi, cw, lane, eo);
             __builtin_amdgcn_sched_barrier(0);
             ENG_STAMP(6);
             if (more) eng_issue(wf, ln.w13, ln.ffn_norm, D, f_lo, f_hi, cw, lane, p.nt);
@@ -1333,7 +1360,8 @@ __global__ __launch_bounds__(ENG_THREADS) void slow_engine_kernel(SlowEngP p) {
                 unsigned long long* q = p.stamps + ((size_t)b * p.n_layer + li) * 16;
                 q[10] = t_poll0; q[11] = t_poll1; q[12] = eng_rt();
             }
-            eng_gather3_x(rl, p.gg + (size_t)par * VSTR, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 5);
+            if constexpr (S::PK3) eng_gather3_x(rl, p.gg + (size_t)par * VSTR, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 5);
+            else eng_gather_x(rl, p.gg + (size_t)par * VSTR, layF, 0, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, li * 8 + 5);
             eng_barrier(); if (*dead) break;                        // B4
         }
     }
@@ -1394,7 +1422,7 @@ struct FastEngP {
 #define ENG_FSTAMP(k) do { if (p.stamps && tid == 0) p.stamps[(((size_t)b * p.ncb + cb) * nL + li) * 16 + (k)] = eng_rt(); } while (0)
 
 #define ENG_GSTAMP(k) do { if (p.stamps && atid == 0) p.stamps[(((size_t)b * p.ncb + cb) * nL + nL - 1) * 16 + (k)] = eng_rt(); } while (0)
-constexpr int ENG_FQ = 2, ENG_FF = 3, ENG_FO = 1;   // units per compute wave: QKV 8 rows -> 2, W13 12 pairs -> 3, Wo / W2 / head 4 rows -> 1
+constexpr int ENG_FV = 1024;    // codes drawn per codebook (inference.py:134); every fast shape class has this many
 
 // The draw's barriers.  The four gathering waves draw; the compute waves have nothing to do meanwhile, so they FOLLOW: they
 // sit in the workgroup's hardware barrier once per barrier of the draw (eng_draw_follow) and leave when the draw says it
@@ -1919,8 +1947,8 @@ __device__ __forceinline__ int eng_sample_small(const SampP& p, const EngDrawPre
 }
 
 // q k v of fast layer 0 for every row of the codebook-embedding table, with the fast engine's own phase code (same
-// loads, eng_gemv_rows, same rounding): grid (qkvN / (ENG_FQ * ENG_CW), code chunks), 256 threads.
-template <int NTD>
+// loads, eng_gemv_rows, same rounding): grid (qkvN / (S::SQ * ENG_CW), code chunks), 256 threads.
+template <typename S>
 __global__ __launch_bounds__(ENG_CW * 64) void eng_qkv0_table_kernel(const bf16_t* wqkv, const bf16_t* bqkv, const bf16_t* attn_norm,
                                                                       const bf16_t* fast_emb, bf16_t* tab, int D, int qkvN, int ncodes,
                                                                       float eps) {
@@ -1930,7 +1958,8 @@ __global__ __launch_bounds__(ENG_CW * 64) void eng_qkv0_table_kernel(const bf16_
     const int tid = threadIdx.x, lane = tid & 63, cw = tid >> 6;
     int q_lo, q_hi;
     eng_units(qkvN, blockIdx.x, gridDim.x, q_lo, q_hi);
-    EngW<NTD, 1, ENG_FQ> wq;
+    constexpr int NTD = S::NTD;
+    EngW<NTD, 1, S::SQ> wq;
     eng_issue<false>(wq, wqkv, attn_norm, D, q_lo, q_hi, cw, lane, 0);
     const int per = (ncodes + gridDim.y - 1) / gridDim.y;
     const int c_lo = blockIdx.y * per, c_hi = min(c_lo + per, ncodes);
@@ -1942,7 +1971,7 @@ __global__ __launch_bounds__(ENG_CW * 64) void eng_qkv0_table_kernel(const bf16_
             for (int j = 0; j < 8; ++j) xs[d + j] = e8[j];
         }
         __syncthreads();
-        eng_gemv_rows<NTD, 1, ENG_FQ, PRO_RMSNORM, EPI_STORE>(wq, xs, D, eps, bqkv, nullptr, vals, q_lo, q_hi, cw, lane);
+        eng_gemv_rows<NTD, 1, S::SQ, PRO_RMSNORM, EPI_STORE>(wq, xs, D, eps, bqkv, nullptr, vals, q_lo, q_hi, cw, lane);
         __syncthreads();
         if (tid < q_hi - q_lo) tab[(size_t)code * qkvN + q_lo + tid] = f32_to_bf16_bits(vals[tid]);
         __syncthreads();
@@ -1957,16 +1986,18 @@ inline size_t eng_fast_lds_bytes(int D, int qkvN, int HD, int F, int V, int nL, 
     return by;
 }
 
-template <int NTD, int NTA, int NTF, int MAXCB, int HDIM>
+template <typename FS, int MAXCB>
 __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
-    constexpr int SQ = ENG_FQ, SF = ENG_FF, SO = ENG_FO;
+    // units per compute wave (s1-mini: QKV 8 rows -> 2, W13 12 pairs -> 3, Wo / W2 / head 4 rows -> 1)
+    constexpr int NTD = FS::NTD, NTA = FS::NTA, NTF = FS::NTF, HDIM = FS::HDIM;
+    constexpr int SQ = FS::SQ, SF = FS::SF, SO = FS::SO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: uniform branches, row offsets in SGPRs)
     const int b = blockIdx.x;
     constexpr int nb = ENG_NB;            // workgroups = CUs (the host launches exactly this many, one per CU)
     const int cw = wave, gw = wave - ENG_CW, atid = tid - ENG_CW * 64;
     // compile-time widths, as in slow_engine_kernel (the host's gate admits exactly these)
-    constexpr int D = ENG_FD, F = ENG_FF_DIM, hd = HDIM, H = ENG_FH, Hkv = ENG_FHKV, HD = H * hd, KVW = Hkv * hd, QKVN = (H + 2 * Hkv) * hd, V = ENG_FV;
+    constexpr int D = FS::D, F = FS::F, hd = HDIM, H = FS::H, Hkv = FS::HKV, HD = H * hd, KVW = Hkv * hd, QKVN = (H + 2 * Hkv) * hd, V = FS::V;
     float* xA = smem;                          // layer input
     float* qkvS = xA + D;                      // gathered q, k, v of this position
     float* yS = qkvS + QKVN;                 // attention output
@@ -2099,8 +2130,8 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                     eng_gemv2<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU>(wf, xB, xB1, D, p.eps, nullptr, nullptr, nullptr, bg(0, li) + eng_pub(b, f_lo),
                                                                    bg(1, li) + eng_pub(b, f_lo), tag0, tag1, f_lo, f_hi, cw, lane, eo);
                 else
-                    eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU, true>(wf, xB1, D, p.eps, nullptr, nullptr, bg(1, li), tag1, nullptr,
-                                                                  f_lo, f_hi, cw, lane, eo);
+                    eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU, FS::PK3>(wf, xB1, D, p.eps, nullptr, nullptr, bg(1, li) + (FS::PK3 ? 0 : eng_pub(b, f_lo)), tag1, nullptr,
+                                                                    f_lo, f_hi, cw, lane, eo);
                 __builtin_amdgcn_sched_barrier(0);
                 ENG_FSTAMP(6);
                 if (more) eng_issue<false>(wf, ln.w13, ln.ffn_norm, D, f_lo, f_hi, cw, lane, 0);
@@ -2170,8 +2201,8 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 __builtin_amdgcn_sched_barrier(0);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B3: xB
                 ENG_FSTAMP(5);
-                eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU, true>(wf, xB, D, p.eps, nullptr, nullptr, bg(par, li), tag, nullptr,
-                                                              f_lo, f_hi, cw, lane, eo);
+                eng_gemv<NTD, 2, SF, PRO_RMSNORM, EPI_SWIGLU, FS::PK3>(wf, xB, D, p.eps, nullptr, nullptr, bg(par, li) + (FS::PK3 ? 0 : eng_pub(b, f_lo)), tag, nullptr,
+                                                                f_lo, f_hi, cw, lane, eo);
                 __builtin_amdgcn_sched_barrier(0);
                 ENG_FSTAMP(6);
                 if (more) eng_issue<false>(wf, ln.w13, ln.ffn_norm, D, f_lo, f_hi, cw, lane, 0);
@@ -2240,7 +2271,8 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 else eng_gather_x(rl, bxb(1, li), layD, 0, D, tag1, xB1, gw, ENG_GW, lane, p.ctl, dead, wh + 2);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B3
                 if (tail0) eng_gather_x2(rl, EngSrc2{{bg(0, li), bg(1, li)}, {gS, gS1}, {tag0, tag1}}, F, gw, ENG_GW, lane, p.ctl, dead, wh + 3);
-                else eng_gather3_x(rl, bg(1, li), F, tag1, gS1, gw, ENG_GW, lane, p.ctl, dead, wh + 3);
+                else if constexpr (FS::PK3) eng_gather3_x(rl, bg(1, li), F, tag1, gS1, gw, ENG_GW, lane, p.ctl, dead, wh + 3);
+                else eng_gather_x(rl, bg(1, li), layF, 0, F, tag1, gS1, gw, ENG_GW, lane, p.ctl, dead, wh + 3);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B4
             }
         }
@@ -2313,7 +2345,8 @@ __global__ __launch_bounds__(ENG_THREADS) void fast_engine_kernel(FastEngP p) {
                 eng_barrier();                                          // B2
                 eng_gather_x(rl, bxb(par, li), layD, 0, D, tag, xB, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 2);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B3
-                eng_gather3_x(rl, bg(par, li), F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 3);
+                if constexpr (FS::PK3) eng_gather3_x(rl, bg(par, li), F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 3);
+                else eng_gather_x(rl, bg(par, li), layF, 0, F, tag, gS, gw, ENG_GW, lane, p.ctl, dead, 1000 + cb * 64 + li * 8 + 3);
                 eng_barrier(); if (*dead) { alive = false; break; }     // B4
             }
             if (!alive) break;

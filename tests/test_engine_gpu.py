@@ -64,6 +64,30 @@ def test_engine_frames_equal_launch_frames_greedy(monkeypatch, max_seq_len, Lp, 
         assert np.array_equal(ha.view(np.uint32), hb.view(np.uint32)), mode
 
 
+@pytest.mark.parametrize("over,want_flags", [
+    (dict(intermediate_size=4096, fast_intermediate_size=4096), 3),     # the feed-forward width SURVEY could not verify: both engines
+    (dict(intermediate_size=4096), 3),                                   # slow stack 4096, fast stack 3072
+    (dict(n_local_heads=4), 3),                                          # four kv heads: the general split form of the attention
+    (dict(n_local_heads=4, intermediate_size=4096), 0),                  # no instantiation: launch path, and it says why
+])
+@pytest.mark.parametrize("max_seq_len,Lp", [(1024, 40), (1024, 300)])
+def test_engine_shape_classes_equal_launch_frames(monkeypatch, over, want_flags, max_seq_len, Lp):
+    """The engine kernels are instantiated for a short list of shape classes (csrc/engine.hip: eng_slow_shapes /
+    eng_fast_shapes; llama.py:74-86 reads the widths from config.json): every class must give the launch path's frames,
+    vocabulary logits and hidden state bit for bit, greedy and sampled; widths outside the list keep the launch path."""
+    monkeypatch.delenv("FT_NO_XL", raising=False)
+    shape = dataclasses.replace(medium_shape(**over), max_seq_len=max_seq_len)
+    prompt = make_prompt(shape, Lp, seed=14, n_vq=4).numpy()
+    for kw, tape in ((dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1), None),
+                     (dict(temperature=0.7, top_p=0.8, repetition_penalty=1.1), NoiseTape(shape, 24, seed=5))):
+        fa, a, la, ha = _run(monkeypatch, shape, False, prompt, 16, kw, tape)
+        fb, b, lb, hb = _run(monkeypatch, shape, True, prompt, 16, kw, tape)
+        assert fa == 0 and fb == want_flags, (fa, fb)
+        assert np.array_equal(a, b)
+        assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+        assert np.array_equal(ha.view(np.uint32), hb.view(np.uint32))
+
+
 def test_engine_frames_equal_launch_frames_sampled(monkeypatch):
     shape = dataclasses.replace(medium_shape(), max_seq_len=1024)
     prompt = make_prompt(shape, 24, seed=6, n_vq=3).numpy()

@@ -76,8 +76,8 @@ int main(int argc, char** argv) {
     unsigned long long* stamps = (unsigned long long*)zalloc((size_t)nb * n_layer * 16 * 8 * 2);
     const size_t lds = 82 * 1024;
     const bool xl = getenv("XL") != nullptr;     // the XCD-local form (needs nsplit = 32 on 8 x 32 CUs)
-    CK(hipFuncSetAttribute((const void*)slow_engine_kernel<2, 4, 6, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CK(hipFuncSetAttribute((const void*)slow_engine_kernel<2, 4, 6, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)slow_engine_kernel<EngSlowS1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)slow_engine_kernel<EngSlowS1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     printf("XCD-local attention: %d\n", (int)xl);
     CK(hipStreamSynchronize(s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -88,8 +88,8 @@ int main(int argc, char** argv) {
         float best = 1e9f, sum = 0.f; const int reps = 20;
         for (int r = 0; r < reps + 3; ++r) {
             CK(hipEventRecord(e0, s));
-            if (xl) slow_engine_kernel<2, 4, 6, 2, true><<<nb, ENG_THREADS, lds, s>>>(p);
-            else slow_engine_kernel<2, 4, 6, 2, false><<<nb, ENG_THREADS, lds, s>>>(p);
+            if (xl) slow_engine_kernel<EngSlowS1, true><<<nb, ENG_THREADS, lds, s>>>(p);
+            else slow_engine_kernel<EngSlowS1, false><<<nb, ENG_THREADS, lds, s>>>(p);
             CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (r >= 3) { best = std::min(best, ms); sum += ms; }
@@ -217,14 +217,14 @@ static int run_fast(int nb, hipStream_t s) {
     if (!getenv("NO_QKV0")) {
         bf16_t* tab; CK(hipMalloc(&tab, (size_t)V * qkvN * 2));
         const EngLayer l0 = hl[0];
-        eng_qkv0_table_kernel<2><<<dim3(qkvN / (ENG_FQ * ENG_CW), 16), ENG_CW * 64, ((size_t)D + ENG_MAX_OUT) * 4, s>>>(
+        eng_qkv0_table_kernel<EngFastS1><<<dim3(qkvN / (EngFastS1::SQ * ENG_CW), 16), ENG_CW * 64, ((size_t)D + ENG_MAX_OUT) * 4, s>>>(
             l0.wqkv, l0.bqkv, l0.attn_norm, p.fast_emb, tab, D, qkvN, V, p.eps);
         CK(hipGetLastError()); CK(hipStreamSynchronize(s));
         p.qkv0_tab = tab;
     }
     size_t ldsb = eng_fast_lds_bytes(D, qkvN, HD, F, V, nL, ncb, Hkv * hd, p.pair != 0);
     printf("paired first pass: %d, LDS %zu bytes\n", p.pair, ldsb);
-    CK(hipFuncSetAttribute((const void*)fast_engine_kernel<2, 2, 6, 10, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    CK(hipFuncSetAttribute((const void*)fast_engine_kernel<EngFastS1, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     CK(hipStreamSynchronize(s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int mode = 0; mode < 2; ++mode) {
@@ -233,7 +233,7 @@ static int run_fast(int nb, hipStream_t s) {
         for (int r = 0; r < reps + 3; ++r) {
             CK(hipMemcpyAsync(sp.nf, &one, 4, hipMemcpyHostToDevice, s));
             CK(hipEventRecord(e0, s));
-            fast_engine_kernel<2, 2, 6, 10, 64><<<nb, ENG_THREADS, ldsb, s>>>(p);
+            fast_engine_kernel<EngFastS1, 10><<<nb, ENG_THREADS, ldsb, s>>>(p);
             CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (r >= 3) sum += ms;
