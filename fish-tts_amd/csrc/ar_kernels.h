@@ -1066,6 +1066,11 @@ struct SampP {
     int* done;
     bf16_t* femb_xo;  // optional octet-major bf16 copy of femb (lock-step batches, wide_kernels.h)
     int femb_ldm;
+    // wide batches: layer 0's q k v of the NEXT codebook step is a row of a table indexed by the drawn code (its input is
+    // that code's embedding): the draw leaves the row where the step's attention reads it, and the step skips that launch
+    const bf16_t* qkv0_tab;   // [codes][qkv0_n] or null
+    float* qkv0_out;          // [M][qkv0_n]
+    int qkv0_n;
 };
 
 __device__ __forceinline__ uint32_t order_key(float f) {
@@ -1158,6 +1163,10 @@ __device__ __forceinline__ void finish_draw(const SampP& p, const int m, const i
         const float v = ld_elem(fe, (size_t)code * p.Df + d);
         p.femb[(size_t)m * p.Df + d] = v;
         if (p.femb_xo) p.femb_xo[xo_index(m, d, p.femb_ldm)] = f32_to_bf16_bits(v);
+    }
+    if (p.qkv0_tab) {
+        for (int d = tid; d < p.qkv0_n; d += T)
+            p.qkv0_out[(size_t)m * p.qkv0_n + d] = bf16_bits_to_f32(p.qkv0_tab[(size_t)code * p.qkv0_n + d]);
     }
     if (p.last) {
         // a slot that has emitted <|im_end|> (or is parked) stays frozen while the rest of the lock-step batch

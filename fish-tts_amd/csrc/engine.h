@@ -71,9 +71,11 @@ struct ft_ctx {
     // (wide_kernels.h); their activations are octet-major bf16 Xo[width / 8][xo_ldm][8]: residual streams of the slow and
     // the fast stack, the drawn codes' embeddings, the attention output, the SwiGLU vector
     ft::bf16_t *xo_x = nullptr, *xo_xf = nullptr, *xo_femb = nullptr, *xo_y = nullptr, *xo_g = nullptr;
+    ft::bf16_t* wide_qkv0_tab = nullptr;   // [fastV][fast qkv width]: layer 0's q k v of the codebook steps >= 2 by drawn code (wide batches)
     int xo_ldm = 0;     // rows of an octet: 2 x xo_pair
     int xo_pair = 0;    // max_batch rounded up to the 16-row MFMA tile; rows from here on hold codebook position 1 of the paired pass
     bool no_attn_wide = false;   // FT_NO_ATTN_WIDE: wide batches keep the online-softmax attention kernel of the single rows
+    bool no_head_stream = false; // FT_NO_HEAD_STREAM: the vocabulary head of a wide batch on the general wide launch
     bool no_pair = false;   // FT_NO_PAIR: codebook positions 0 and 1 as two passes (the comparison a parity test makes)
     int wide_min = 5;   // measured: the MFMA path wins from 5 rows (B=5: 2.79 vs 3.33 ms per frame), B <= 4 keeps the bit-exact multi-row GEMV
     bool wide_ok = false;
@@ -110,6 +112,7 @@ struct ft_ctx {
     bool eng_pair = false;          // fast loop: positions 0 and 1 as two rows of the first pass
     bool xl_shape = false;          // 8 kv heads x (2 x 128) on 8 XCDs x 32 CUs: 32 KV splits always (engine.hip: ar_alloc)
     bool eng_xl = false;            // the slow stack's engine runs its XCD-local form (one kv head per XCD)
+    std::string path_str;                // what ft_ar_frame_path last returned
     const void* eng_slow_fn = nullptr;   // the instantiations of the two engine kernels this model's widths match (engine.hip: eng_shapes)
     const void* eng_fast_fn = nullptr;
     size_t eng_pool_bytes = 0, eng_gpart_bytes = 0, eng_fast_bytes = 0;   // hand-off allocations (zeroed again after an abort)

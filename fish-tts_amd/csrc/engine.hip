@@ -214,6 +214,7 @@ static ft_status ar_alloc(ft_ctx* ctx) {
             ctx->xo_pair = (int)((M + 15) / 16 * 16);
             ctx->no_pair = getenv("FT_NO_PAIR") != nullptr;
             ctx->no_attn_wide = getenv("FT_NO_ATTN_WIDE") != nullptr;
+            ctx->no_head_stream = getenv("FT_NO_HEAD_STREAM") != nullptr;
             ctx->xo_ldm = 2 * ctx->xo_pair;
             const size_t P = ctx->xo_ldm;
             FT_TRY(dmalloc(ctx, &ctx->xo_x, P * c.dim));
@@ -284,6 +285,7 @@ extern "C" void ft_destroy(ft_ctx* ctx) {
     int* ibufs[] = {ctx->d_pos, ctx->d_tok, ctx->d_tokn, ctx->d_seq, ctx->d_nf, ctx->d_done, ctx->d_prompt};
     for (int* b : ibufs) if (b) hipFree(b);
     if (ctx->d_ctl) hipFree(ctx->d_ctl);
+    if (ctx->wide_qkv0_tab) hipFree(ctx->wide_qkv0_tab);
     { void* pf[] = {ctx->pf_x, ctx->pf_qkv, ctx->pf_y, ctx->pf_xn, ctx->pf_ybf, ctx->pf_g, ctx->xo_x, ctx->xo_xf, ctx->xo_femb, ctx->xo_y, ctx->xo_g, ctx->pf_qbf}; for (void* q : pf) if (q) hipFree(q); }
     for (auto& l : ctx->layers) { if (l.bqkv_f32) hipFree(l.bqkv_f32); if (l.bo_f32) hipFree(l.bo_f32); }
     if (ctx->samp_cut) hipFree(ctx->samp_cut);
@@ -359,6 +361,7 @@ static void* wp(ft_ctx* ctx, const std::string& n) {
 }
 
 static ft_status eng_setup(ft_ctx* ctx);
+static ft_status wide_qkv0_build(ft_ctx* ctx);
 
 static ft_status ar_finalize(ft_ctx* ctx) {
     const ft_ar_config& c = ctx->c;
@@ -419,6 +422,7 @@ static ft_status ar_finalize(ft_ctx* ctx) {
     }
     FT_TRY(fill(ctx->flayers, "fast_layers.", c.fast_intermediate_size, c.fast_dim));
     FT_TRY(eng_setup(ctx));
+    FT_TRY(wide_qkv0_build(ctx));
     return FT_OK;
 }
 
@@ -744,6 +748,13 @@ static void wide_gemm(Launch& L, const bf16_t* X, const void* W, const float* bi
     bool ok;
     if (epi == WEPI_RESID) ok = wide_gemm_launch<1, 1, false, WEPI_RESID>(p, L.s);
     else if (epi == WEPI_SWIGLU) ok = M > 16 ? wide_gemm_launch<2, 2, true, WEPI_SWIGLU>(p, L.s) : wide_gemm_launch<1, 2, true, WEPI_SWIGLU>(p, L.s);
+    else if (N >= 32768 && M <= 32 && K == 1024 && N % 16 == 0 && !L.ctx->no_head_stream) {
+        // the vocabulary head: activations normalised once per workgroup, weights streamed per wave (wide_head_kernel)
+        static DevOnce once;
+        once.run([] { hipFuncSetAttribute((const void*)wide_head_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_head_lds<1024>()); });
+        wide_head_kernel<1024><<<256, 512, wide_head_lds<1024>(), L.s>>>(p);
+        ok = true;
+    }
     else if (N >= 32768) ok = M > 16 ? wide_gemm_launch<2, 2, true, WEPI_STORE>(p, L.s) : wide_gemm_launch<1, 2, true, WEPI_STORE>(p, L.s);
     else if (N >= 4096 && M > 16) ok = wide_gemm_launch<1, 2, true, WEPI_STORE>(p, L.s);
     else ok = wide_gemm_launch<1, 1, true, WEPI_STORE>(p, L.s);
@@ -755,6 +766,51 @@ static void wide_gemm(Launch& L, const bf16_t* X, const void* W, const float* bi
 static __global__ __launch_bounds__(256) void xo_from_rows_kernel(const float* x, int ldx, int D, bf16_t* xo, int ldm) {
     const int m = blockIdx.y;
     for (int d = blockIdx.x * 256 + threadIdx.x; d < D; d += gridDim.x * 256) xo[xo_index(m, d, ldm)] = f32_to_bf16_bits(x[(size_t)m * ldx + d]);
+}
+
+// bf16 rows [row][D] -> octet-major operand rows (table build below)
+static __global__ __launch_bounds__(256) void xo_from_bf16_rows_kernel(const bf16_t* x, int D, bf16_t* xo, int ldm, int rows) {
+    const int m = blockIdx.y;
+    if (m >= rows) return;
+    for (int d = blockIdx.x * 256 + threadIdx.x; d < D; d += gridDim.x * 256) xo[xo_index(m, d, ldm)] = x[(size_t)m * D + d];
+}
+static __global__ void f32_to_bf16_kernel(const float* x, bf16_t* o, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) o[i] = f32_to_bf16_bits(x[i]);
+}
+
+// Wide batches: the table of layer 0's q k v for every code a codebook draw can select (codes < fastV), built at load with
+// the very launch that would compute those rows in a frame (the rows of a lock-step GEMM do not depend on each other, so a
+// table row carries the bits the launch would produce): 4 MB at the s1-mini widths, one launch less per codebook step.
+static ft_status wide_qkv0_build(ft_ctx* ctx) {
+    const ft_ar_config& c = ctx->c;
+    if (!ctx->wide_ok || c.dtype != FT_BF16 || getenv("FT_NO_QKV0") || c.num_codebooks <= 2 || c.n_fast_layer < 1) return FT_OK;
+    const int Df = c.fast_dim, qkvN = (c.fast_n_head + 2 * c.fast_n_local_heads) * c.fast_head_dim, V = ctx->fastV;
+    const FtLayer& l0 = ctx->flayers[0];
+    if (l0.bqkv) return FT_OK;
+    constexpr int CH = 64;
+    bf16_t* xo = nullptr; float* out = nullptr;
+    if (hipMalloc((void**)&xo, (size_t)Df * CH * sizeof(bf16_t)) != hipSuccess || hipMalloc((void**)&out, (size_t)CH * qkvN * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&ctx->wide_qkv0_tab, (size_t)V * qkvN * sizeof(bf16_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (xo) hipFree(xo);
+        if (out) hipFree(out);
+        if (ctx->wide_qkv0_tab) { hipFree(ctx->wide_qkv0_tab); ctx->wide_qkv0_tab = nullptr; }
+        return FT_OK;      // the frames then keep their layer-0 launch
+    }
+    bool ok = true;
+    for (int c0 = 0; c0 < V && ok; c0 += CH) {
+        const int rows = std::min(CH, V - c0);
+        xo_from_bf16_rows_kernel<<<dim3((Df + 255) / 256, rows), 256, 0, ctx->stream>>>((const bf16_t*)ctx->fast_emb + (size_t)c0 * Df, Df, xo, CH, rows);
+        WideP p{};
+        p.X = xo; p.ldm = CH; p.W = (const bf16_t*)l0.wqkv; p.ldw = Df; p.gain = (const bf16_t*)l0.attn_norm; p.eps = c.norm_eps;
+        p.M = rows; p.N = qkvN; p.K = Df; p.out_f32 = out; p.ldo = qkvN;
+        ok = wide_gemm_launch<1, 1, true, WEPI_STORE>(p, ctx->stream);
+        f32_to_bf16_kernel<<<256, 256, 0, ctx->stream>>>(out, ctx->wide_qkv0_tab + (size_t)c0 * qkvN, (long)rows * qkvN);
+    }
+    ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+    hipFree(xo); hipFree(out);
+    if (!ok) { hipFree(ctx->wide_qkv0_tab); ctx->wide_qkv0_tab = nullptr; (void)hipGetLastError(); }
+    return FT_OK;
 }
 
 static bool eng_slow_ok(const Launch& L) {
@@ -1106,6 +1162,10 @@ static void enqueue_sample(Launch& L, int cb, bool last) {
         // the semantic code's embedding is position 1 of the paired pass: it joins the slow stack's residual stream
         s.femb_xo = (cb == 0 && wide_pair(L) ? ctx->xo_x + (size_t)ctx->xo_pair * 8 : ctx->xo_femb) + (size_t)m0 * 8;
         s.femb_ldm = ctx->xo_ldm;
+        if (cb >= 1 && cb + 1 < c.num_codebooks && ctx->wide_qkv0_tab) {     // the next codebook step's layer-0 q k v (its launch is skipped)
+            s.qkv0_tab = ctx->wide_qkv0_tab; s.qkv0_n = (c.fast_n_head + 2 * c.fast_n_local_heads) * c.fast_head_dim;
+            s.qkv0_out = ctx->qkvf + (size_t)m0 * s.qkv0_n;
+        }
     }
     if (s.V <= 1024) {
         sample_small_kernel<WT, ROUND><<<L.M, 256, 0, L.s>>>(s);
@@ -1163,7 +1223,9 @@ static void enqueue_fast_step(Launch& L, const int cb, const bool pair = false) 
                     bf16_t* yo = ctx->xo_y + (size_t)m0 * 8;
                     bf16_t* go = ctx->xo_g + (size_t)m0 * 8;
                     const bf16_t* xlo = li == 0 ? xin_o : xfo;
-                    wide_gemm(L, xlo, l.wqkv, nullptr, (int)qkvN, Df, l.attn_norm, WEPI_STORE, qkvf, (long)qkvN, nullptr, nullptr, rows);
+                    // layer 0 of steps >= 2: the draw of the previous step left this step's q k v (wide_qkv0_build)
+                    if (!(li == 0 && cb >= 2 && !pair && ctx->wide_qkv0_tab))
+                        wide_gemm(L, xlo, l.wqkv, nullptr, (int)qkvN, Df, l.attn_norm, WEPI_STORE, qkvf, (long)qkvN, nullptr, nullptr, rows);
                     FastAttnP a{};
                     a.qkv = qkvf; a.ldq = (int)qkvN; a.qn = l.qn; a.kn = l.kn; a.rope = ctx->frope;
                     a.kc = (char*)l.kc + (size_t)m0 * ctx->fcache_m_stride * ctx->esz;
@@ -1832,7 +1894,15 @@ extern "C" ft_status ft_ar_engine_state(ft_ctx* ctx, int32_t* flags, int32_t* ab
     return FT_OK;
 }
 
-extern "C" const char* ft_ar_frame_path(const ft_ctx* ctx) { return ctx ? ctx->eng_why.c_str() : ""; }
+extern "C" const char* ft_ar_frame_path(const ft_ctx* ctx) {
+    if (!ctx) return "";
+    // batch-1 frames, then what a lock-step batch of >= wide_min rows runs on
+    ft_ctx* c = const_cast<ft_ctx*>(ctx);
+    c->path_str = ctx->eng_why + (ctx->wide_ok && ctx->c.dtype == FT_BF16
+                                      ? "; lock-step batches of >= 5 rows: MFMA launches with fused row operations (five per layer)"
+                                      : "; lock-step batches: multi-row GEMV launches");
+    return c->path_str.c_str();
+}
 
 // Test hook: workgroup `wg` of a coming slow-stack (which = 0) or codebook-loop (which = 1) engine launch plays dead - it
 // publishes nothing, every workgroup that waits for its rows times out (one shot: that workgroup clears the word).  `skip`

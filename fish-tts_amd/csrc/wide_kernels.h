@@ -205,6 +205,112 @@ __global__ __launch_bounds__(NW * 64) void wide_gemm_kernel(WideP p) {
     wide_gemm_body<TS, NT, NW, KS, NORM, EPI>(p, blockIdx.x, blockIdx.y, lds);
 }
 
+// ------------------------------------------------------------------------------------------
+// The vocabulary head of a wide batch (llama.py:446-451: final RMSNorm + tied embedding, 155 776 rows at s1-mini): ONE
+// normalisation of the <= 32 activation rows per workgroup into LDS (octet-major bf16, the A-operand layout), then every
+// wave streams its own 16-row weight tiles over the whole contraction - B fragments straight from HBM, two halves of the
+// K-steps in flight per wave (128 KB per CU), no cross-wave sum.  The general launch (16 NT rows per workgroup, K split
+// over the waves) re-reads the activations once per 32 weight rows: 311 MB of L2 traffic beside 319 MB of weights, 103 us;
+// this form reads them once per workgroup.
+// grid: any (256 = one workgroup per CU), 512 threads; dynamic LDS: (K / 8) * 32 * 16 bytes + 8 * 32 floats.
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(512) void wide_head_kernel(WideP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hl[];
+    constexpr int KS = K / 32, HALF = KS / 2, OCT = K / 8;
+    static_assert(KS % 2 == 0, "two halves of the K-steps per tile");
+    U4* xn = reinterpret_cast<U4*>(hl);                       // [OCT][32] 16-byte pieces
+    float* ssw = reinterpret_cast<float*>(hl + (size_t)OCT * 32 * 16);   // [8][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    // ---- the fused RMSNorm, once per workgroup: thread t owns row t % 32 of octets t / 32, t / 32 + 16, ..
+    {
+        const int row = tid & 31;
+        const bool on = row < p.M;
+        constexpr int PER = OCT / 16;
+        U4 xr[PER];
+        wk_f2 ss2 = wk_f2{0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int o = (tid >> 5) + 16 * i;
+            xr[i] = on ? *reinterpret_cast<const U4*>(p.X + ((size_t)o * p.ldm + row) * 8) : U4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const uint32_t* xw = reinterpret_cast<const uint32_t*>(&xr[i]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const wk_f2 v = wk_unpack2(xw[e]); ss2 = __builtin_elementwise_fma(v, v, ss2); }
+        }
+        float ss = ss2.x + ss2.y;
+        ss += __shfl_xor(ss, 32);
+        if (lane < 32) ssw[wave * 32 + lane] = ss;
+        __syncthreads();
+        float tot = ssw[row];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) tot += ssw[q * 32 + row];
+        const float inv = rsqrt_exact(tot / (float)K + p.eps);
+        const wk_f2 inv2 = wk_f2{inv, inv};
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int o = (tid >> 5) + 16 * i;
+            const U4 g = *reinterpret_cast<const U4*>(p.gain + o * 8);
+            uint32_t* xw = reinterpret_cast<uint32_t*>(&xr[i]);
+            const uint32_t* gw = reinterpret_cast<const uint32_t*>(&g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xw[e] = wk_pack2(wk_unpack2(wk_pack2(wk_unpack2(xw[e]) * inv2)) * wk_unpack2(gw[e]));
+            xn[o * 32 + row] = xr[i];
+        }
+        __syncthreads();
+    }
+    // ---- weight tiles: tile t = weight rows [16 t, 16 t + 16); wave w of workgroup b takes tiles (i * gridDim.x + b) * 8 + w
+    const int ntiles = p.N / 16;
+    U4 wa[HALF], wb[HALF];
+    auto issue = [&](U4 (&w)[HALF], int t, int half) {
+        const bf16_t* wrow = p.W + (size_t)(min(t, ntiles - 1) * 16 + fr) * p.ldw + half * HALF * 32 + fq * 8;
+#pragma unroll
+        for (int s = 0; s < HALF; ++s) w[s] = *reinterpret_cast<const U4*>(wrow + s * 32);
+    };
+    auto mac = [&](const U4 (&w)[HALF], int half, wk_f32x4 (&acc)[2]) {
+#pragma unroll
+        for (int s = 0; s < HALF; ++s) {
+            wk_bf16x8 b;
+            __builtin_memcpy(&b, &w[s], 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                wk_bf16x8 a;
+                const U4 av = xn[((half * HALF + s) * 4 + fq) * 32 + j * 16 + fr];
+                __builtin_memcpy(&a, &av, 16);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
+            }
+        }
+    };
+    int t = (int)blockIdx.x * 8 + wave;
+    const int tstep = (int)gridDim.x * 8;
+    issue(wa, t, 0);
+    issue(wb, t, 1);
+    for (; t < ntiles; t += tstep) {
+        wk_f32x4 acc[2] = {wk_f32x4{0.f, 0.f, 0.f, 0.f}, wk_f32x4{0.f, 0.f, 0.f, 0.f}};
+        mac(wa, 0, acc);
+        issue(wa, t + tstep, 0);            // (past the last tile: re-reads it, never used)
+        mac(wb, 1, acc);
+        issue(wb, t + tstep, 1);
+        // lane holds C[m = j * 16 + 4 fq + r][n = 16 t + fr]
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = j * 16 + fq * 4 + r;
+                if (m < p.M) {
+                    float v = acc[j][r];
+                    if (p.bias) v += p.bias[t * 16 + fr];
+                    p.out_f32[(size_t)m * p.ldo + t * 16 + fr] = round_bf16(v);
+                }
+            }
+    }
+}
+template <int K>
+static inline size_t wide_head_lds() { return (size_t)(K / 8) * 32 * 16 + 8 * 32 * sizeof(float); }
+
 // K split: 128..256 contraction elements per wave where the width allows (one memory round trip, registers for every load)
 template <int TS, int NT, bool NORM, int EPI>
 static inline bool wide_gemm_launch(const WideP& p, hipStream_t st) {

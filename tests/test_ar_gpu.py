@@ -18,10 +18,12 @@ GREEDY = [("greedy_rep1.0", dict(temperature=0.7, top_p=1e-6, repetition_penalty
           ("greedy_rep1.1", dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1))]
 
 
-def medium_shape(**over):
+def medium_shape(n_text=1000, **over):
     """s1-mini widths (dim 1024, ffn 3072, heads 16/8 x 128, fast heads 16/8 x 64) so the specialised
-    kernel instantiations run, but 2+2 layers and a small vocabulary so the oracle takes seconds."""
-    n_text, n_sem = 1000, 4096
+    kernel instantiations run, but 2+2 layers and a small vocabulary so the oracle takes seconds.
+    n_text = 1009 makes the vocabulary a multiple of 32 rows (5120), which the MFMA launches of wide lock-step batches
+    need (s1-mini's 155 776 is one)."""
+    n_sem = 4096
     kw = dict(vocab_size=n_text + 15 + n_sem, n_layer=2, n_head=16, dim=1024, intermediate_size=3072,
               n_local_heads=8, head_dim=128, rope_base=1e6, norm_eps=1e-6, max_seq_len=512,
               tie_word_embeddings=True, attention_qk_norm=True, codebook_size=4096, num_codebooks=10,
@@ -40,8 +42,8 @@ def _margin_ok(orc_taps, col_rel, row, eps):
     return float(top[0] - top[1]) <= eps
 
 
-def _oracle_scores(shape, taps, want, T, col, row, kw, tape):
-    """p/q of the oracle at decision (frame col-T, row): its logits, its window, the shared noise."""
+def _oracle_scores(shape, taps, want, T, col, row, kw, tape, probs_only=False):
+    """p/q of the oracle at decision (frame col-T, row): its logits, its window, the shared noise (probs_only: p alone)."""
     f = col - T
     logits, _, fast = taps[f]
     cb = 0 if row <= 1 else row - 1
@@ -55,6 +57,8 @@ def _oracle_scores(shape, taps, want, T, col, row, kw, tape):
         prev = torch.from_numpy(window[:, 0] if cb == 0 else window[cb + 1]).int()
     probs = O.logits_to_probs(l, torch.tensor(kw["temperature"]), torch.tensor(kw["top_p"]),
                               torch.tensor(kw["repetition_penalty"]), prev)
+    if probs_only:
+        return probs.float().reshape(-1)
     off = 0 if cb == 0 else tape.V + (cb - 1) * tape.fastV
     q = tape.q[f, off: off + probs.shape[-1]].to(probs.dtype)
     return (probs / q).float()
@@ -132,7 +136,16 @@ def test_sampled_with_injected_noise(shape_fn, precision):
             if div is not None and div[0] < min(got.shape[1], want.shape[1]):
                 col, row = div
                 sc = _oracle_scores(shape, taps, want, T, col, row, kw, tape)
-                assert float(sc[int(got[0 if row <= 1 else row, col])]) >= 0.5 * float(sc.max()), (kw, div)
+                tok = int(got[0 if row <= 1 else row, col])
+                if float(sc[tok]) < 0.5 * float(sc.max()):
+                    # the other legitimate way to part: the token sits right at the top-p cut and a few ulp of the logits
+                    # decide on which side (the oracle cut it, the GPU kept it; with a two- or three-token kept set and
+                    # temperature 0.3 the renormalised probabilities then differ a lot, so no score bound is asked for).
+                    # It must be the first or second token below the oracle's kept set in the oracle's own order.
+                    n_kept = int((sc > 0).sum())
+                    pf = _oracle_scores(shape, taps, want, T, col, row, dict(kw, top_p=1.0), tape, probs_only=True)   # uncut probabilities
+                    rank = int((pf > pf[tok]).sum())
+                    assert float(sc[tok]) == 0.0 and rank <= n_kept + 1, (kw, div, rank, n_kept)
     eng.set_noise(None)
     eng.close()
 
@@ -376,8 +389,9 @@ def test_wide_batch_vs_oracle(monkeypatch, B):
     a different order than the single-utterance GEMV: each utterance must follow the ORACLE up to a decision whose
     top-1/top-2 margin is inside the bf16 evaluation-order tolerance.  The widths cover one 16-row batch tile (5, 8,
     16), two (19, 32) and the row split over workgroups beyond 32 (40)."""
-    shape = medium_shape()
+    shape = medium_shape(n_text=1009)
     eng, orc = make_pair(shape, "bf16", std=0.05, max_batch=B)
+    assert "MFMA launches" in eng.frame_path(), eng.frame_path()
     kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
     sp = eng._sampling(0.7, 1e-6, 1.1)
     prompts = [make_prompt(shape, 9 + (3 * i) % 11, seed=300 + i, n_vq=i % 4) for i in range(B)]
@@ -401,18 +415,21 @@ def test_wide_batch_vs_oracle(monkeypatch, B):
     eng.close()
 
 
-@pytest.mark.parametrize("B", [7, 19, 32])
-def test_wide_batch_paired_codebook_pass_equals_two_passes(monkeypatch, B):
+@pytest.mark.parametrize("B,switch", [(7, "FT_NO_PAIR"), (19, "FT_NO_PAIR"), (32, "FT_NO_PAIR"), (19, "FT_NO_QKV0"), (40, "FT_NO_QKV0")])
+def test_wide_batch_paired_codebook_pass_equals_two_passes(monkeypatch, B, switch):
     """Wide batches run codebook positions 0 and 1 as ONE pass of 2 M rows (both inputs are known once the semantic
     token is drawn, inference.py:116-131; the position-1 rows rebuild position 0's key themselves).  Every row keeps its
-    own arithmetic, so the frames equal those of two separate passes (FT_NO_PAIR) bit for bit - sampled draws included."""
-    shape = medium_shape()
+    own arithmetic, so the frames equal those of two separate passes (FT_NO_PAIR) bit for bit - sampled draws included.
+    Likewise layer 0's q k v of the codebook steps >= 2 come from a table indexed by the drawn code, built at load with the
+    launch that would compute them (FT_NO_QKV0: that launch runs in every step): the same bits."""
+    shape = medium_shape(n_text=1009)
     prompts = [make_prompt(shape, 9 + (3 * i) % 11, seed=300 + i, n_vq=i % 4).numpy() for i in range(B)]
     outs = []
     for off in (False, True):
         if off:
-            monkeypatch.setenv("FT_NO_PAIR", "1")
+            monkeypatch.setenv(switch, "1")
         eng, _ = make_pair(shape, "bf16", std=0.05, max_batch=B)
+        assert "MFMA launches" in eng.frame_path(), eng.frame_path()
         sps = [eng._sampling(0.7, 0.8 if i % 2 else 1e-6, 1.1, seed=7 + i) for i in range(B)]
         firsts = [eng.prefill(p, sps[i], slot=i) for i, p in enumerate(prompts)]
         frames, n = eng.decode(6, sps, poll=3)
@@ -428,8 +445,9 @@ def test_wide_batch_long_contexts_vs_oracle():
     one block per row and kv head, K rows of 128 positions per round trip, several chunks here) against the ORACLE,
     with the bf16 evaluation-order margin."""
     B = 16
-    shape = medium_shape(max_seq_len=512)
+    shape = medium_shape(n_text=1009, max_seq_len=512)
     eng, orc = make_pair(shape, "bf16", std=0.05, max_batch=B, max_new_tokens=16)
+    assert "MFMA launches" in eng.frame_path(), eng.frame_path()
     kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
     sp = eng._sampling(0.7, 1e-6, 1.1)
     lens = [140 + (37 * i) % 281 for i in range(B)]
