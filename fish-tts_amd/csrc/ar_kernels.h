@@ -1159,12 +1159,39 @@ __device__ __forceinline__ void finish_draw(const SampP& p, const int m, const i
         tokn[p.cb + 1] = code;
     }
     const WT* fe = reinterpret_cast<const WT*>(p.fast_emb);
+    // the table row of the next step's layer-0 q k v (wide batches) travels with the embedding row: both depend on the drawn
+    // code only, so their loads are issued together (one round trip) before anything is stored; 16-byte pieces
+    constexpr int TQ = 2;
+    U4 tq[TQ];
+    const bool tab16 = p.qkv0_tab && (p.qkv0_n & 7) == 0;
+    if (tab16) {
+#pragma unroll
+        for (int i = 0; i < TQ; ++i) {
+            const int d = (tid + i * T) * 8;
+            tq[i] = d < p.qkv0_n ? *reinterpret_cast<const U4*>(p.qkv0_tab + (size_t)code * p.qkv0_n + d) : U4{0u, 0u, 0u, 0u};
+        }
+    }
     for (int d = tid; d < p.Df; d += T) {
         const float v = ld_elem(fe, (size_t)code * p.Df + d);
         p.femb[(size_t)m * p.Df + d] = v;
         if (p.femb_xo) p.femb_xo[xo_index(m, d, p.femb_ldm)] = f32_to_bf16_bits(v);
     }
-    if (p.qkv0_tab) {
+    if (tab16) {
+        float* qo = p.qkv0_out + (size_t)m * p.qkv0_n;
+        auto put8 = [&](int d, const U4& r) {
+            float v[8];
+            Vec<bf16_t>::unpack(r, v);
+            *reinterpret_cast<float4*>(qo + d) = float4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<float4*>(qo + d + 4) = float4{v[4], v[5], v[6], v[7]};
+        };
+#pragma unroll
+        for (int i = 0; i < TQ; ++i) {
+            const int d = (tid + i * T) * 8;
+            if (d < p.qkv0_n) put8(d, tq[i]);
+        }
+        for (int d = (tid + TQ * T) * 8; d < p.qkv0_n; d += T * 8)
+            put8(d, *reinterpret_cast<const U4*>(p.qkv0_tab + (size_t)code * p.qkv0_n + d));
+    } else if (p.qkv0_tab) {
         for (int d = tid; d < p.qkv0_n; d += T)
             p.qkv0_out[(size_t)m * p.qkv0_n + d] = bf16_bits_to_f32(p.qkv0_tab[(size_t)code * p.qkv0_n + d]);
     }

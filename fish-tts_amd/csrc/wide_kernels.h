@@ -212,15 +212,18 @@ __global__ __launch_bounds__(NW * 64) void wide_gemm_kernel(WideP p) {
 // K-steps in flight per wave (128 KB per CU), no cross-wave sum.  The general launch (16 NT rows per workgroup, K split
 // over the waves) re-reads the activations once per 32 weight rows: 311 MB of L2 traffic beside 319 MB of weights, 103 us;
 // this form reads them once per workgroup.
-// grid: any (256 = one workgroup per CU), 512 threads; dynamic LDS: (K / 8) * 32 * 16 bytes + 8 * 32 floats.
+// grid: any (256 = one workgroup per CU), 512 threads; dynamic LDS: (K / 8) * WH_ROW * 16 bytes + 8 * 32 floats.  An octet row
+// of the LDS image is padded from 32 to 36 pieces: the four octets a wave reads at once (lanes fq = 0..3) then start 576
+// bytes apart and fall into four different bank groups (at 512 bytes they share one: a four-way conflict on every read).
 // ------------------------------------------------------------------------------------------
+constexpr int WH_ROW = 36;
 template <int K>
 __global__ __launch_bounds__(512) void wide_head_kernel(WideP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hl[];
     constexpr int KS = K / 32, HALF = KS / 2, OCT = K / 8;
     static_assert(KS % 2 == 0, "two halves of the K-steps per tile");
-    U4* xn = reinterpret_cast<U4*>(hl);                       // [OCT][32] 16-byte pieces
-    float* ssw = reinterpret_cast<float*>(hl + (size_t)OCT * 32 * 16);   // [8][32]
+    U4* xn = reinterpret_cast<U4*>(hl);                       // [OCT][WH_ROW] 16-byte pieces (32 used)
+    float* ssw = reinterpret_cast<float*>(hl + (size_t)OCT * WH_ROW * 16);   // [8][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     // ---- the fused RMSNorm, once per workgroup: thread t owns row t % 32 of octets t / 32, t / 32 + 16, ..
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(512) void wide_head_kernel(WideP p) {
             const uint32_t* gw = reinterpret_cast<const uint32_t*>(&g);
 #pragma unroll
             for (int e = 0; e < 4; ++e) xw[e] = wk_pack2(wk_unpack2(wk_pack2(wk_unpack2(xw[e]) * inv2)) * wk_unpack2(gw[e]));
-            xn[o * 32 + row] = xr[i];
+            xn[o * WH_ROW + row] = xr[i];
         }
         __syncthreads();
     }
@@ -271,6 +274,11 @@ __global__ __launch_bounds__(512) void wide_head_kernel(WideP p) {
         for (int s = 0; s < HALF; ++s) w[s] = *reinterpret_cast<const U4*>(wrow + s * 32);
     };
     auto mac = [&](const U4 (&w)[HALF], int half, wk_f32x4 (&acc)[2]) {
+        // the activation fragments are re-read from LDS for every tile: an opaque zero in the address keeps the compiler from
+        // hoisting all 64 of them out of the tile loop (256 registers: it spilled them to scratch, 154 us per launch)
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        const U4* xz = xn + z;
 #pragma unroll
         for (int s = 0; s < HALF; ++s) {
             wk_bf16x8 b;
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(512) void wide_head_kernel(WideP p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 wk_bf16x8 a;
-                const U4 av = xn[((half * HALF + s) * 4 + fq) * 32 + j * 16 + fr];
+                const U4 av = xz[((half * HALF + s) * 4 + fq) * WH_ROW + j * 16 + fr];
                 __builtin_memcpy(&a, &av, 16);
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
             }
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(512) void wide_head_kernel(WideP p) {
     }
 }
 template <int K>
-static inline size_t wide_head_lds() { return (size_t)(K / 8) * 32 * 16 + 8 * 32 * sizeof(float); }
+static inline size_t wide_head_lds() { return (size_t)(K / 8) * WH_ROW * 16 + 8 * 32 * sizeof(float); }
 
 // K split: 128..256 contraction elements per wave where the width allows (one memory round trip, registers for every load)
 template <int TS, int NT, bool NORM, int EPI>
