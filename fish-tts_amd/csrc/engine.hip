@@ -739,7 +739,7 @@ static bool wide_pair(const Launch& L) {
 // matrix (W13 always, Wqkv from 17 batch rows), both 16-row batch tiles in one workgroup only where the weights
 // dominate (W13, the vocabulary head); everything else splits the batch rows over workgroups.
 static void wide_gemm(Launch& L, const bf16_t* X, const void* W, const float* bias, int N, int K, const void* gain, int epi,
-                      float* out_f32, long ldo, bf16_t* out_xo, const bf16_t* resid_xo, int rows = 0) {
+                      float* out_f32, long ldo, bf16_t* out_xo, const bf16_t* resid_xo, int rows = 0, bool vocab_head = false) {
     const int M = rows > 0 ? rows : L.M;
     WideP p{};
     p.X = X; p.ldm = L.ctx->xo_ldm; p.W = (const bf16_t*)W; p.ldw = K; p.gain = (const bf16_t*)gain; p.eps = L.ctx->c.norm_eps;
@@ -748,7 +748,7 @@ static void wide_gemm(Launch& L, const bf16_t* X, const void* W, const float* bi
     bool ok;
     if (epi == WEPI_RESID) ok = wide_gemm_launch<1, 1, false, WEPI_RESID>(p, L.s);
     else if (epi == WEPI_SWIGLU) ok = M > 16 ? wide_gemm_launch<2, 2, true, WEPI_SWIGLU>(p, L.s) : wide_gemm_launch<1, 2, true, WEPI_SWIGLU>(p, L.s);
-    else if (N >= 32768 && M <= 32 && K == 1024 && N % 16 == 0 && !L.ctx->no_head_stream) {
+    else if (vocab_head && M <= 32 && K == 1024 && N % 16 == 0 && N >= 4096 && !L.ctx->no_head_stream) {
         // the vocabulary head: activations normalised once per workgroup, weights streamed per wave (wide_head_kernel)
         static DevOnce once;
         once.run([] { hipFuncSetAttribute((const void*)wide_head_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_head_lds<1024>()); });
@@ -1132,7 +1132,7 @@ static void enqueue_head(Launch& L) {
         }
         if constexpr (ROUND == RND_BF16)
             wide_gemm(L, ctx->xo_x + (size_t)L.m0 * 8, ctx->head, nullptr, c.vocab_size, c.dim, ctx->norm, WEPI_STORE,
-                      ctx->logits + (size_t)L.m0 * c.vocab_size, c.vocab_size, nullptr, nullptr);
+                      ctx->logits + (size_t)L.m0 * c.vocab_size, c.vocab_size, nullptr, nullptr, 0, true);
         return;
     }
     GemvP h{};

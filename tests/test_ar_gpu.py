@@ -382,13 +382,18 @@ def test_batch32_mixed_lengths_equals_single(monkeypatch, precision):
     eng.close()
 
 
-@pytest.mark.parametrize("B", [5, 8, 16, 19, 32, 40])
-def test_wide_batch_vs_oracle(monkeypatch, B):
+@pytest.mark.parametrize("B,env", [(5, None), (8, None), (16, None), (19, None), (32, None), (40, None),
+                                   (32, "FT_NO_ATTN_WIDE"), (32, "FT_NO_HEAD_STREAM")])
+def test_wide_batch_vs_oracle(monkeypatch, B, env):
     """Lock-step batches of >= 5 utterances run every Linear as ONE M-row MFMA launch with the RMSNorm / SwiGLU /
     residual add folded in (csrc/wide_kernels.h: octet-major bf16 activations, five launches per layer), which sums in
     a different order than the single-utterance GEMV: each utterance must follow the ORACLE up to a decision whose
     top-1/top-2 margin is inside the bf16 evaluation-order tolerance.  The widths cover one 16-row batch tile (5, 8,
-    16), two (19, 32) and the row split over workgroups beyond 32 (40)."""
+    16), two (19, 32) and the row split over workgroups beyond 32 (40).  The two switches select the kernels the wide path
+    replaced at >= 16 rows (the single rows' online-softmax attention; the general launch for the vocabulary head): both
+    forms must follow the oracle."""
+    if env:
+        monkeypatch.setenv(env, "1")
     shape = medium_shape(n_text=1009)
     eng, orc = make_pair(shape, "bf16", std=0.05, max_batch=B)
     assert "MFMA launches" in eng.frame_path(), eng.frame_path()
