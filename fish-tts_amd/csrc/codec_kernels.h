@@ -497,24 +497,32 @@ struct FlashP {
     float scale;
 };
 template <int HD>
-__global__ __launch_bounds__(256) void flash_prefill_kernel(FlashP p) {
-    constexpr int KT = 32;                  // keys per tile
+__global__ __launch_bounds__(512) void flash_prefill_kernel(FlashP p) {
+    constexpr int KT = 32;                  // keys per tile and key group
+    constexpr int NG = 2;                   // key groups: waves 0-3 take keys [kt, kt + 32) of a step, waves 4-7 [kt + 32, kt + 64)
     constexpr int LDK = HD + 8;             // K tile row stride (bf16)
     constexpr int LDV = KT + 8;             // V^T tile row stride
     constexpr int LDP = KT + 8;
     constexpr int NS = HD / 32;             // k-steps of Q K^T
     constexpr int NT = HD / 16;             // 16-wide output column tiles
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[KT * LDK];
-    __shared__ __attribute__((aligned(16))) bf16_t Vt[HD * LDV];
-    __shared__ __attribute__((aligned(16))) bf16_t Ps[4][2][16 * LDP];
+    // Both key groups walk the SAME 64 query rows with their own online-softmax state and are merged once at the end: the
+    // dependent chain of a block (a 780-position prompt: 26 tiles for the last query tile, the kernel's critical path with
+    // 208 blocks on 256 CUs) halves to 13 steps of two tiles side by side.
+    constexpr int KS_N = KT * LDK, VT_N = HD * LDV, PS_N = 16 * LDP, XW = NT * 4 + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t smem_f[NG * KS_N + NG * VT_N + 4 * NG * 2 * PS_N];
+    static_assert((size_t)(NG * VT_N + 4 * NG * 2 * PS_N) * sizeof(bf16_t) >= (size_t)4 * 64 * XW * sizeof(float), "the merge buffer reuses Vt + Ps");
+    bf16_t (*Ks)[KS_N] = reinterpret_cast<bf16_t (*)[KS_N]>(smem_f);
+    bf16_t (*Vt)[VT_N] = reinterpret_cast<bf16_t (*)[VT_N]>(smem_f + NG * KS_N);
+    bf16_t (*Ps)[2][PS_N] = reinterpret_cast<bf16_t (*)[2][PS_N]>(smem_f + NG * KS_N + NG * VT_N);
     const int h = blockIdx.x, q0 = blockIdx.y * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, qw = wave & 3;             // key group, query sub-tile
     const int fr = lane & 15, fq = lane >> 4;
     const int G = p.H / p.Hkv, kvh = h / G;
     const bf16_t* kc = p.kc + (size_t)kvh * p.n_slots * HD;
     const bf16_t* vc = p.vc + (size_t)kvh * p.n_slots * HD;
     // Q fragments of this wave's 16 rows (A operand: row = lane & 15, 8 consecutive d per lane)
-    const int qrow = min(q0 + wave * 16 + fr, p.S - 1);
+    const int qrow = min(q0 + qw * 16 + fr, p.S - 1);
     bf16x8 qf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -527,39 +535,41 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashP p) {
     for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.f; }
     const int last_row = min(q0 + 63, p.S - 1);
     const int kmax = p.pos0 + last_row;                    // last visible key of the block
-    // K/V rows of a tile travel in registers TWO tiles ahead of their use, in two named register sets; every load is
-    // unconditional (rows past the last visible key re-read that key's row: they are masked below), so no branch sits between
-    // a load and its use and the counted waits never drain the pipeline.  Each thread owns CPT 16-byte pieces of a tile.
-    constexpr int CPT = KT * (HD / 8) / 256;
+    // K/V rows of a step (NG * KT keys) travel in registers TWO steps ahead of their use, in two named register sets; every
+    // load is unconditional (rows past the last visible key re-read that key's row: they are masked below), so no branch sits
+    // between a load and its use and the counted waits never drain the pipeline.  Each thread owns CPT 16-byte pieces.
+    constexpr int CPT = NG * KT * (HD / 8) / 512;
     U4 kregA[CPT], vregA[CPT], kregB[CPT], vregB[CPT];
     auto fetch = [&](U4 (&kreg)[CPT], U4 (&vreg)[CPT], int kt) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = tid + i * 256;
-            const int kr = c / (HD / 8), d8 = (c % (HD / 8)) * 8;
+            const int c = tid + i * 512;
+            const int kr = c / (HD / 8), d8 = (c % (HD / 8)) * 8;      // kr in [0, NG * KT)
             const int j = min(kt + kr, kmax);
             kreg[i] = *reinterpret_cast<const U4*>(kc + (size_t)j * HD + d8);
             vreg[i] = *reinterpret_cast<const U4*>(vc + (size_t)j * HD + d8);
         }
     };
     fetch(kregA, vregA, 0);
-    fetch(kregB, vregB, KT);
+    fetch(kregB, vregB, NG * KT);
     // V^T in LDS: the 8-key group g of row d sits at group g ^ ((d / 8) & 3) - the 16 lanes that write one key of 16 different
     // 8-row bands then spread over four banks instead of one (their rows are 8 x LDV halfs = a multiple of 32 dwords apart)
-    auto tile = [&](U4 (&kreg)[CPT], U4 (&vreg)[CPT], const int kt) {
-        __syncthreads();                                    // previous tile fully consumed
+    auto tile = [&](U4 (&kreg)[CPT], U4 (&vreg)[CPT], const int kt0) {
+        __syncthreads();                                    // previous step fully consumed
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
-            const int c = tid + i * 256;
-            const int kr = c / (HD / 8), d8 = (c % (HD / 8)) * 8;
-            *reinterpret_cast<U4*>(&Ks[kr * LDK + d8]) = kreg[i];
+            const int c = tid + i * 512;
+            const int kr2 = c / (HD / 8), d8 = (c % (HD / 8)) * 8;
+            const int g2 = kr2 / KT, kr = kr2 % KT;
+            *reinterpret_cast<U4*>(&Ks[g2][kr * LDK + d8]) = kreg[i];
             const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vreg[i]);
             const int col = (((kr >> 3) ^ ((d8 >> 3) & 3)) << 3) + (kr & 7);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) Vt[(d8 + e) * LDV + col] = ve[e];
+            for (int e = 0; e < 8; ++e) Vt[g2][(d8 + e) * LDV + col] = ve[e];
         }
         __syncthreads();
-        fetch(kreg, vreg, kt + 2 * KT);
+        fetch(kreg, vreg, kt0 + 2 * NG * KT);
+        const int kt = kt0 + grp * KT;                      // this group's keys
         // S = Q K^T for two 16-key sub-tiles: lane holds S[q = 4 fq + r][key = sub * 16 + fr]
         f32x4 sc[2];
 #pragma unroll
@@ -567,16 +577,16 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashP p) {
             sc[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[(sub * 16 + fr) * LDK + s * 32 + fq * 8]);
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[grp][(sub * 16 + fr) * LDK + s * 32 + fq * 8]);
                 sc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], kf, sc[sub], 0, 0, 0);
             }
         }
         float pr[2][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int qabs = p.pos0 + q0 + wave * 16 + fq * 4 + r;
+            const int qabs = p.pos0 + q0 + qw * 16 + fq * 4 + r;
             float s0 = sc[0][r] * p.scale, s1 = sc[1][r] * p.scale;
-            if (kt + fr > qabs) s0 = -INFINITY;             // causal mask (also hides the zero padding of the last tile)
+            if (kt + fr > qabs) s0 = -INFINITY;             // causal mask (also hides the rows re-read past the last key)
             if (kt + 16 + fr > qabs) s1 = -INFINITY;
             float mx = fmaxf(s0, s1);
             mx = fmaxf(mx, dpp_f<DPP_XOR1>(mx));
@@ -615,24 +625,43 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashP p) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int d = t * 16 + fr;
-            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[d * LDV + ((fq ^ ((d >> 3) & 3)) << 3)]);
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&Vt[grp][d * LDV + ((fq ^ ((d >> 3) & 3)) << 3)]);
             O[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, vf, O[t], 0, 0, 0);
             O[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, vf, O[t], 0, 0, 0);
         }
     };
-    // tiles in pairs (one per register set); a tile wholly past the last visible key adds nothing (every score masked)
-    for (int kt = 0; kt <= kmax; kt += 2 * KT) {
+    // steps in pairs (one per register set); a tile wholly past the last visible key adds nothing (every score masked)
+    for (int kt = 0; kt <= kmax; kt += 2 * NG * KT) {
         tile(kregA, vregA, kt);
-        tile(kregB, vregB, kt + KT);
+        tile(kregB, vregB, kt + NG * KT);
     }
+    // ---- merge of the two key groups: group 1 leaves (m, l, O) of its rows in LDS (the tile buffers are free now), group 0
+    // rescales both to the common maximum and writes y
+    __syncthreads();
+    float* xch = reinterpret_cast<float*>(smem_f + NG * KS_N) + (size_t)(qw * 64 + lane) * XW;     // this lane's slot
+    if (grp == 1) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = q0 + wave * 16 + fq * 4 + r;
-        const float l = row16_sum(lrun[r]);
-        if (row < p.S) {
+        for (int r = 0; r < 4; ++r) { xch[r] = mrun[r]; xch[4 + r] = lrun[r]; }
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                p.y_bf[(size_t)row * p.H * HD + (size_t)h * HD + t * 16 + fr] = f32_to_bf16_bits(O[t][r] / l);
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xch[8 + t * 4 + r] = O[t][r];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m1 = xch[r], l1 = xch[4 + r];
+            const float mn = fmaxf(mrun[r], m1);
+            const float c0 = mrun[r] > -INFINITY ? expf(mrun[r] - mn) : 0.f;
+            const float c1 = m1 > -INFINITY ? expf(m1 - mn) : 0.f;
+            const float l = row16_sum(lrun[r] * c0 + l1 * c1);
+            const int row = q0 + qw * 16 + fq * 4 + r;
+            if (row < p.S) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    p.y_bf[(size_t)row * p.H * HD + (size_t)h * HD + t * 16 + fr] = f32_to_bf16_bits((O[t][r] * c0 + xch[8 + t * 4 + r] * c1) / l);
+            }
         }
     }
 }

@@ -1371,6 +1371,14 @@ static ft_status upload_ctl(ft_ctx* ctx, int m0, int n, const ft_sampling* sp) {
 }
 
 // MFMA prefill (bf16 precision): the whole prompt goes through every slow layer as S = Lp rows on the
+template <int BM, int BN, int NWM, int NWN>
+static void lingemm_launch(const TapGemmP& p, int S, int N, hipStream_t st) {
+    constexpr size_t lds = lingemm_lds_bytes<BM, BN, NWM>();
+    static DevOnce once;     // per device: the dynamic-LDS opt-in belongs to the device's function object
+    once.run([] { hipFuncSetAttribute((const void*)lingemm_kernel<BM, BN, NWM, NWN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    lingemm_kernel<BM, BN, NWM, NWN, 4><<<dim3((S + BM - 1) / BM, N / BN), 64 * NWM * NWN, lds, st>>>(p);
+}
+
 // tap-GEMM kernel (v_mfma_f32_16x16x32_bf16), with the reference's rounding points in the epilogues
 // (Linear output rounded, residual add rounded, SwiGLU steps rounded; llama.py:172-190,229-283,322-331).
 // K/V of all positions are appended first, then every position attends over the cache.
@@ -1396,14 +1404,10 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
         // on 8 waves for the wide products from 512 rows, 64 x 64 on 4 waves otherwise (the N = 1024 products would leave
         // 200 CUs idle on the large tile: 56 workgroups at 780 rows).  Measured at 780 rows (tools/prefill_probe.py): 7.05 ms
         // with the codec's one-step-ahead tile kernel, 5.51 ms with these (3.56 against 5.61 ms at 256 rows).
-        auto lg = [&](auto kern, dim3 grid, int threads, size_t lds) {
-            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            kern<<<grid, threads, lds, L.s>>>(p);
-        };
         constexpr int tile8_s = 512;
         if (K % 256 == 0) {
-            if (S >= tile8_s && N > 1024) lg(lingemm_kernel<128, 128, 2, 4, 4>, dim3((S + 127) / 128, N / 128), 512, lingemm_lds_bytes<128, 128, 2>());
-            else lg(lingemm_kernel<64, 64, 2, 2, 4>, dim3((S + 63) / 64, N / 64), 256, lingemm_lds_bytes<64, 64, 2>());
+            if (S >= tile8_s && N > 1024) lingemm_launch<128, 128, 2, 4>(p, S, N, L.s);
+            else lingemm_launch<64, 64, 2, 2>(p, S, N, L.s);
         } else if (S >= tile8_s) {
             constexpr size_t lds8 = std::max((size_t)((128 + 56) + 2 * 128) * (64 + 8) * 2, (size_t)(128 / 2) * (128 + 4) * 4);
             static DevOnce once8;
@@ -1466,8 +1470,8 @@ static void prefill_gemm(Launch& L, int slot, int Lp, int pos0, bool with_tail =
                 FlashP fp{ctx->pf_qbf, (const bf16_t*)a.kc, (const bf16_t*)a.vc, ctx->pf_ybf, Lp, c.n_head, c.n_local_heads,
                           c.head_dim, ctx->n_slots, pos0, a.scale};
                 const dim3 gridf(c.n_head, (Lp + 63) / 64);
-                if (c.head_dim == 128) flash_prefill_kernel<128><<<gridf, 256, 0, L.s>>>(fp);
-                else flash_prefill_kernel<64><<<gridf, 256, 0, L.s>>>(fp);
+                if (c.head_dim == 128) flash_prefill_kernel<128><<<gridf, 512, 0, L.s>>>(fp);
+                else flash_prefill_kernel<64><<<gridf, 512, 0, L.s>>>(fp);
                 L.chk();
                 continue;
             }
