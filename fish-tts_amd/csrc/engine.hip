@@ -427,8 +427,8 @@ static ft_status ar_finalize(ft_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------------------------------ frame engine (host side)
-// The engine is an instantiation for one shape class (dim = 1024, heads 16/8 x 128, ffn 3072 in bf16: openaudio-s1-mini's
-// widths at any depth); every other configuration keeps the launch path.  It needs every workgroup resident at once:
+// The engine is instantiated for a short list of shape classes (eng_slow_shapes / eng_fast_shapes below: openaudio-s1-mini's
+// widths, ffn 4096, four kv heads; bf16; any depth); every other configuration keeps the launch path.  It needs every workgroup resident at once:
 // one per CU, sized by the device's CU count - so only ONE context per device and process may run it (two would each
 // hold part of the CUs and time each other out), and nothing in here is fatal: whatever fails leaves the launch path.
 constexpr int ENG_MAX_STRIKES = 2;      // hand-off time-outs after which a context stops using the engine
