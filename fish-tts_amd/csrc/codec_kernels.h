@@ -396,8 +396,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) void tapgemm64_kernel(TapGemmP p) {
 // at any time (the pipelined kernel above has its A stripe one step ahead only - enough behind seven taps, not for a
 // linear: at 780 prompt rows every step waited ~2 us for its rows, 38 us per product).  Two LDS buffers, one barrier per
 // step: step k's tiles are written to buffer k % 2 while buffer (k + 1) % 2 may still be read by waves one barrier behind.
-template <int BM, int BN, int NWM, int NWN, int DEPTH>
-__global__ __launch_bounds__(64 * NWM * NWN) void lingemm_kernel(TapGemmP p) {
+template <int BM, int BN, int NWM, int NWN, int DEPTH, int MINW = 1>
+__global__ __launch_bounds__(64 * NWM * NWN, MINW) void lingemm_kernel(TapGemmP p) {
     constexpr int BK = 64, NTHR = 64 * NWM * NWN, LD = BK + 8, QPR = BK / 8;
     constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
     static_assert(WM % 16 == 0 && WN % 16 == 0 && DEPTH % 2 == 0, "whole MFMA tiles per wave; buffer parity follows the unrolled step");

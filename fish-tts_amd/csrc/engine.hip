@@ -1371,12 +1371,12 @@ static ft_status upload_ctl(ft_ctx* ctx, int m0, int n, const ft_sampling* sp) {
 }
 
 // MFMA prefill (bf16 precision): the whole prompt goes through every slow layer as S = Lp rows on the
-template <int BM, int BN, int NWM, int NWN>
+template <int BM, int BN, int NWM, int NWN, int DEPTH = 4, int MINW = 1>
 static void lingemm_launch(const TapGemmP& p, int S, int N, hipStream_t st) {
     constexpr size_t lds = lingemm_lds_bytes<BM, BN, NWM>();
     static DevOnce once;     // per device: the dynamic-LDS opt-in belongs to the device's function object
-    once.run([] { hipFuncSetAttribute((const void*)lingemm_kernel<BM, BN, NWM, NWN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-    lingemm_kernel<BM, BN, NWM, NWN, 4><<<dim3((S + BM - 1) / BM, N / BN), 64 * NWM * NWN, lds, st>>>(p);
+    once.run([] { hipFuncSetAttribute((const void*)lingemm_kernel<BM, BN, NWM, NWN, DEPTH, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+    lingemm_kernel<BM, BN, NWM, NWN, DEPTH, MINW><<<dim3((S + BM - 1) / BM, N / BN), 64 * NWM * NWN, lds, st>>>(p);
 }
 
 // tap-GEMM kernel (v_mfma_f32_16x16x32_bf16), with the reference's rounding points in the epilogues
@@ -1406,7 +1406,12 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
         // with the codec's one-step-ahead tile kernel, 5.51 ms with these (3.56 against 5.61 ms at 256 rows).
         constexpr int tile8_s = 512;
         if (K % 256 == 0) {
-            if (S >= tile8_s && N > 1024) lingemm_launch<128, 128, 2, 4>(p, S, N, L.s);
+            static const int lv = getenv("FT_LIN_VARIANT") ? atoi(getenv("FT_LIN_VARIANT")) : 0;    // experiment
+            // 128 x 128: two K-steps in flight and <= 128 registers, so that TWO workgroups share a CU (4.92 against 5.25 ms per
+            // 780-position prefill with four steps in flight and one workgroup per CU)
+            if (S >= tile8_s && N > 1024) lingemm_launch<128, 128, 2, 4, 2, 4>(p, S, N, L.s);
+            else if (lv == 3) lingemm_launch<64, 64, 2, 2, 2, 4>(p, S, N, L.s);
+            else if (lv == 4) lingemm_launch<64, 64, 2, 2, 4, 4>(p, S, N, L.s);
             else lingemm_launch<64, 64, 2, 2>(p, S, N, L.s);
         } else if (S >= tile8_s) {
             constexpr size_t lds8 = std::max((size_t)((128 + 56) + 2 * 128) * (64 + 8) * 2, (size_t)(128 / 2) * (128 + 4) * 4);

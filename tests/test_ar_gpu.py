@@ -881,10 +881,11 @@ def test_config4_voice_cloning_composite():
     pf.free()
     for i, u in enumerate(utts):
         cols = u.columns()
-        assert cols.shape[1] == n_frames, (i, cols.shape)
+        # the frame budget, or fewer frames ending in <|im_end|> (random weights do emit it now and then: nothing bans it here)
+        assert cols.shape[1] == n_frames or (0 < cols.shape[1] < n_frames and cols[0, -1] == shape.im_end_id), (i, cols.shape)
         streamed = chunks[i] + ([np.concatenate(pending[i], axis=1)] if pending[i] else [])
         assert np.array_equal(np.concatenate(streamed, axis=1), cols)
-        assert chunks[i][0].shape[1] >= 10 and all(c.shape[1] >= 20 for c in chunks[i][1:])
+        assert (not chunks[i] or chunks[i][0].shape[1] >= 10) and all(c.shape[1] >= 20 for c in chunks[i][1:])
     for i in (0, 3, 7):
         taps = []
         orc.reset()
