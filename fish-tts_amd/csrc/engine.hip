@@ -1403,16 +1403,14 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
         // long prompts (reference audio): MFMA tiles with four K-steps of both operands in flight (lingemm_kernel) - 128 x 128
         // on 8 waves for the wide products from 512 rows, 64 x 64 on 4 waves otherwise (the N = 1024 products would leave
         // 200 CUs idle on the large tile: 56 workgroups at 780 rows).  Measured at 780 rows (tools/prefill_probe.py): 7.05 ms
-        // with the codec's one-step-ahead tile kernel, 5.51 ms with these (3.56 against 5.61 ms at 256 rows).
+        // with the codec's one-step-ahead tile kernel, 4.89 ms with these (3.50 against 5.61 ms at 256 rows).
         constexpr int tile8_s = 512;
         if (K % 256 == 0) {
-            static const int lv = getenv("FT_LIN_VARIANT") ? atoi(getenv("FT_LIN_VARIANT")) : 0;    // experiment
-            // 128 x 128: two K-steps in flight and <= 128 registers, so that TWO workgroups share a CU (4.92 against 5.25 ms per
-            // 780-position prefill with four steps in flight and one workgroup per CU)
+            // both tiles are held to <= 128 registers so that workgroups share a CU (128 x 128: two K-steps in flight, two
+            // workgroups per CU - 4.92 against 5.25 ms per 780-position prefill with four steps and one workgroup; 64 x 64: four
+            // steps, four workgroups - another 0.07 ms)
             if (S >= tile8_s && N > 1024) lingemm_launch<128, 128, 2, 4, 2, 4>(p, S, N, L.s);
-            else if (lv == 3) lingemm_launch<64, 64, 2, 2, 2, 4>(p, S, N, L.s);
-            else if (lv == 4) lingemm_launch<64, 64, 2, 2, 4, 4>(p, S, N, L.s);
-            else lingemm_launch<64, 64, 2, 2>(p, S, N, L.s);
+            else lingemm_launch<64, 64, 2, 2, 4, 4>(p, S, N, L.s);
         } else if (S >= tile8_s) {
             constexpr size_t lds8 = std::max((size_t)((128 + 56) + 2 * 128) * (64 + 8) * 2, (size_t)(128 / 2) * (128 + 4) * 4);
             static DevOnce once8;
