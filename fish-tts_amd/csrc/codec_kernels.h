@@ -496,27 +496,29 @@ struct FlashP {
     int S, H, Hkv, hd, n_slots, pos0;
     float scale;
 };
-template <int HD>
+template <int HD, int NG>
 __global__ __launch_bounds__(512) void flash_prefill_kernel(FlashP p) {
     constexpr int KT = 32;                  // keys per tile and key group
-    constexpr int NG = 2;                   // key groups: waves 0-3 take keys [kt, kt + 32) of a step, waves 4-7 [kt + 32, kt + 64)
+    constexpr int QW = 8 / NG;              // NG key groups of QW waves: group g takes keys [kt + 32 g, kt + 32 g + 32) of a step,
+    constexpr int QROWS = 16 * QW;          // its waves 16 query rows each - a block covers QROWS query rows of one head
+    static_assert(NG == 2 || NG == 4, "eight waves: 2 key groups x 64 query rows or 4 x 32");
     constexpr int LDK = HD + 8;             // K tile row stride (bf16)
     constexpr int LDV = KT + 8;             // V^T tile row stride
     constexpr int LDP = KT + 8;
     constexpr int NS = HD / 32;             // k-steps of Q K^T
     constexpr int NT = HD / 16;             // 16-wide output column tiles
-    // Both key groups walk the SAME 64 query rows with their own online-softmax state and are merged once at the end: the
+    // The key groups walk the SAME query rows with their own online-softmax state and are merged once at the end: the
     // dependent chain of a block (a 780-position prompt: 26 tiles for the last query tile, the kernel's critical path with
-    // 208 blocks on 256 CUs) halves to 13 steps of two tiles side by side.
+    // fewer blocks than CUs) shrinks to 26 / NG steps of NG tiles side by side.
     constexpr int KS_N = KT * LDK, VT_N = HD * LDV, PS_N = 16 * LDP, XW = NT * 4 + 8;
-    __shared__ __attribute__((aligned(16))) bf16_t smem_f[NG * KS_N + NG * VT_N + 4 * NG * 2 * PS_N];
-    static_assert((size_t)(NG * VT_N + 4 * NG * 2 * PS_N) * sizeof(bf16_t) >= (size_t)4 * 64 * XW * sizeof(float), "the merge buffer reuses Vt + Ps");
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem_f[];      // flash_prefill_lds<HD, NG>() bytes
+    static_assert((size_t)(NG * VT_N + 8 * 2 * PS_N) * sizeof(bf16_t) >= (size_t)(NG - 1) * QW * 64 * XW * sizeof(float), "the merge buffer reuses Vt + Ps");
     bf16_t (*Ks)[KS_N] = reinterpret_cast<bf16_t (*)[KS_N]>(smem_f);
     bf16_t (*Vt)[VT_N] = reinterpret_cast<bf16_t (*)[VT_N]>(smem_f + NG * KS_N);
-    bf16_t (*Ps)[2][PS_N] = reinterpret_cast<bf16_t (*)[2][PS_N]>(smem_f + NG * KS_N + NG * VT_N);
-    const int h = blockIdx.x, q0 = blockIdx.y * 64;
+    bf16_t (*Ps)[2][PS_N] = reinterpret_cast<bf16_t (*)[2][PS_N]>(smem_f + NG * KS_N + NG * VT_N);   // [8 waves]
+    const int h = blockIdx.x, q0 = blockIdx.y * QROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = wave >> 2, qw = wave & 3;             // key group, query sub-tile
+    const int grp = wave / QW, qw = wave % QW;            // key group, query sub-tile
     const int fr = lane & 15, fq = lane >> 4;
     const int G = p.H / p.Hkv, kvh = h / G;
     const bf16_t* kc = p.kc + (size_t)kvh * p.n_slots * HD;
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(512) void flash_prefill_kernel(FlashP p) {
     float mrun[4], lrun[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.f; }
-    const int last_row = min(q0 + 63, p.S - 1);
+    const int last_row = min(q0 + QROWS - 1, p.S - 1);
     const int kmax = p.pos0 + last_row;                    // last visible key of the block
     // K/V rows of a step (NG * KT keys) travel in registers TWO steps ahead of their use, in two named register sets; every
     // load is unconditional (rows past the last visible key re-read that key's row: they are masked below), so no branch sits
@@ -638,8 +640,9 @@ __global__ __launch_bounds__(512) void flash_prefill_kernel(FlashP p) {
     // ---- merge of the two key groups: group 1 leaves (m, l, O) of its rows in LDS (the tile buffers are free now), group 0
     // rescales both to the common maximum and writes y
     __syncthreads();
-    float* xch = reinterpret_cast<float*>(smem_f + NG * KS_N) + (size_t)(qw * 64 + lane) * XW;     // this lane's slot
-    if (grp == 1) {
+    float* xbase = reinterpret_cast<float*>(smem_f + NG * KS_N);          // [NG - 1][QW][64 lanes][XW]
+    if (grp > 0) {
+        float* xch = xbase + ((size_t)((grp - 1) * QW + qw) * 64 + lane) * XW;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { xch[r] = mrun[r]; xch[4 + r] = lrun[r]; }
 #pragma unroll
@@ -651,20 +654,35 @@ __global__ __launch_bounds__(512) void flash_prefill_kernel(FlashP p) {
     if (grp == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float m1 = xch[r], l1 = xch[4 + r];
-            const float mn = fmaxf(mrun[r], m1);
+            float mn = mrun[r];
+#pragma unroll
+            for (int g = 1; g < NG; ++g) mn = fmaxf(mn, xbase[((size_t)((g - 1) * QW + qw) * 64 + lane) * XW + r]);
             const float c0 = mrun[r] > -INFINITY ? expf(mrun[r] - mn) : 0.f;
-            const float c1 = m1 > -INFINITY ? expf(m1 - mn) : 0.f;
-            const float l = row16_sum(lrun[r] * c0 + l1 * c1);
+            float lsum = lrun[r] * c0;
+            float cg[NG];
+            cg[0] = c0;
+#pragma unroll
+            for (int g = 1; g < NG; ++g) {
+                const float* xg = xbase + ((size_t)((g - 1) * QW + qw) * 64 + lane) * XW;
+                cg[g] = xg[r] > -INFINITY ? expf(xg[r] - mn) : 0.f;
+                lsum += xg[4 + r] * cg[g];
+            }
+            const float l = row16_sum(lsum);
             const int row = q0 + qw * 16 + fq * 4 + r;
             if (row < p.S) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    p.y_bf[(size_t)row * p.H * HD + (size_t)h * HD + t * 16 + fr] = f32_to_bf16_bits((O[t][r] * c0 + xch[8 + t * 4 + r] * c1) / l);
+                for (int t = 0; t < NT; ++t) {
+                    float o = O[t][r] * c0;
+#pragma unroll
+                    for (int g = 1; g < NG; ++g) o += xbase[((size_t)((g - 1) * QW + qw) * 64 + lane) * XW + 8 + t * 4 + r] * cg[g];
+                    p.y_bf[(size_t)row * p.H * HD + (size_t)h * HD + t * 16 + fr] = f32_to_bf16_bits(o / l);
+                }
             }
         }
     }
 }
+template <int HD, int NG>
+constexpr size_t flash_prefill_lds() { return (size_t)(NG * 32 * (HD + 8) + NG * HD * 40 + 8 * 2 * 16 * 40) * sizeof(bf16_t); }
 
 // ---- skinny GEMM: few rows (prompt positions / lock-step utterances), weights streamed once ----------------------
 // out[t][n] = sum_k X[t][k] W[n][k] for M <= 16*TS rows per block column.  The problem is weight-bandwidth bound,
