@@ -1465,10 +1465,10 @@ static void prefill_gemm(Launch& L, int slot, int Lp, int pos0, bool with_tail =
         LA.M = Lp;
         // pass 0 appends K/V of every position (and leaves the finished queries); pass 1 attends: on the matrix cores
         // for 64- and 128-wide heads, otherwise position by position with the decode kernel
-        // (a short tail behind a long restored prefix leaves the tiled kernel with one query tile per head walking the
-        // whole prefix alone: below 64 new positions the per-position kernel is faster - 63 vs 69 ms to the first 10
-        // frames of 8 cloned-voice utterances)
-        const bool flash = !getenv("FT_PREFILL_ATTN_V0") && (c.head_dim == 64 || c.head_dim == 128) && Lp >= 64;
+        // (a short tail behind a long restored prefix: with four key groups per block the tiled kernel wins from 16 new
+        // positions - 47.7 against 49.5 ms to the first 10 frames of 8 cloned-voice utterances with 49-token tails; round 2's
+        // one-group kernel lost below 64)
+        const bool flash = !getenv("FT_PREFILL_ATTN_V0") && (c.head_dim == 64 || c.head_dim == 128) && Lp >= 16;
         a.q_out = flash ? ctx->pf_qbf : nullptr;
         for (int pass = 0; pass < 2; ++pass) {
             a.kv_only = pass == 0; a.no_append = pass == 1;
