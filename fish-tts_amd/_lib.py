@@ -58,6 +58,7 @@ SYMBOLS = {
     "ft_ar_park": (C.c_int32, [_P, C.c_int32]),
     "ft_ar_prefill_slow": (C.c_int32, [_P, C.c_int32, _P, C.c_int32, C.c_int32]),
     "ft_ar_first_frames": (C.c_int32, [_P, C.c_int32, C.c_int32, C.POINTER(ft_sampling), _P, _P]),
+    "ft_ar_prefill_slow_many": (C.c_int32, [_P, C.c_int32, _P, _P, _P, _P]),
     "ft_ar_prefill_at": (C.c_int32, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.POINTER(ft_sampling), _P]),
     "ft_ar_kv_save": (C.c_int32, [_P, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "ft_ar_kv_restore": (C.c_int32, [_P, _P, C.c_int32]),

@@ -170,28 +170,48 @@ class ARHipEngine:
                                               C.byref(sampling), out.ctypes.data_as(C.c_void_p)), "ft_ar_prefill")
         return out
 
-    def prefill_many(self, prompts: Sequence[np.ndarray], samplings: Sequence[L.ft_sampling], slot0: int = 0,
+    def prefill_many(self, prompts: Sequence[np.ndarray], samplings: Sequence[L.ft_sampling], slot0=0,
                      prefixes: Optional[Sequence[Optional["KVPrefix"]]] = None) -> np.ndarray:
-        """Prompts of the contiguous slots [slot0, slot0 + n): each prompt pass on its own, then every first frame in
-        one lock-step pass (a scheduler's initial fill).  Returns (n, R) first frames."""
+        """Prompts of several slots - slot0 = the first of a contiguous range, or the list of (distinct) slots, e.g. the
+        ones a scheduler found finished after a burst: the prompt passes in one call (from 5 prompts in bf16 as the rows
+        of ONE pass through the slow stack, ft_ar_prefill_slow_many), then the first frames in one lock-step pass per
+        contiguous run of slots.  Returns (n, R) first frames in the order of `prompts`."""
         n = len(prompts)
-        next_pos = np.zeros(n, dtype=np.int32)
+        slots = list(range(slot0, slot0 + n)) if isinstance(slot0, (int, np.integer)) else [int(s) for s in slot0]
+        assert len(slots) == n and len(set(slots)) == n, slots
+        tails, lps, pos0s = [], np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
         for i, prompt in enumerate(prompts):
             prompt = np.ascontiguousarray(prompt, dtype=np.int32)
             assert prompt.ndim == 2 and prompt.shape[0] == self.R, prompt.shape
             pf = prefixes[i] if prefixes is not None else None
-            pos0 = 0
             if pf is not None:
                 assert 0 < pf.n_pos < prompt.shape[1], (pf.n_pos, prompt.shape)
-                self.kv_restore(pf, slot0 + i)
-                pos0, prompt = pf.n_pos, np.ascontiguousarray(prompt[:, pf.n_pos:])
-            self._check(self.lib.ft_ar_prefill_slow(self._h, slot0 + i, prompt.ctypes.data_as(C.c_void_p), prompt.shape[1],
-                                                    pos0), "ft_ar_prefill")
-            next_pos[i] = pos0 + prompt.shape[1]
-        arr = (L.ft_sampling * n)(*samplings)
+                self.kv_restore(pf, slots[i])
+                pos0s[i], prompt = pf.n_pos, np.ascontiguousarray(prompt[:, pf.n_pos:])
+            tails.append(prompt.reshape(-1))
+            lps[i] = prompt.shape[1]
+        packed = np.ascontiguousarray(np.concatenate(tails)) if n else np.zeros(0, dtype=np.int32)
+        slot_arr = np.asarray(slots, dtype=np.int32)
+        if n:
+            self._check(self.lib.ft_ar_prefill_slow_many(self._h, n, slot_arr.ctypes.data_as(C.c_void_p),
+                                                         packed.ctypes.data_as(C.c_void_p), lps.ctypes.data_as(C.c_void_p),
+                                                         pos0s.ctypes.data_as(C.c_void_p)), "ft_ar_prefill")
+        next_pos = (pos0s + lps).astype(np.int32)
         out = np.zeros((n, self.R), dtype=np.int32)
-        self._check(self.lib.ft_ar_first_frames(self._h, slot0, n, arr, next_pos.ctypes.data_as(C.c_void_p),
-                                                out.ctypes.data_as(C.c_void_p)), "ft_ar_first_frames")
+        order = sorted(range(n), key=lambda i: slots[i])
+        a = 0
+        while a < n:                                   # one lock-step pass per contiguous run of slots
+            b = a + 1
+            while b < n and slots[order[b]] == slots[order[b - 1]] + 1:
+                b += 1
+            idx = order[a:b]
+            arr = (L.ft_sampling * len(idx))(*[samplings[i] for i in idx])
+            npos = np.ascontiguousarray(next_pos[idx])
+            run = np.zeros((len(idx), self.R), dtype=np.int32)
+            self._check(self.lib.ft_ar_first_frames(self._h, slots[idx[0]], len(idx), arr, npos.ctypes.data_as(C.c_void_p),
+                                                    run.ctypes.data_as(C.c_void_p)), "ft_ar_first_frames")
+            out[idx] = run
+            a = b
         return out
 
     def park(self, slot: int) -> None:

@@ -4,7 +4,7 @@ The reference serves one utterance at a time (synthesizer.py:431-481 under one m
 (batch=32 mixed-length utterances, hipGraph-captured decode loop) asks for the batched form.  Every slot is an
 independent utterance (own prompt, K/V cache, position, penalty window, RNG stream keyed by its seed), all slots
 advance one frame per captured graph replay, a slot that emits <|im_end|> or reaches its frame budget is retired
-between bursts and the next waiting utterance is prefilled into it; idle slots are parked.  Per utterance the result
+between bursts and the next waiting utterances are prefilled into the freed slots together; idle slots are parked.  Per utterance the result
 is what a single-slot run with the same seed produces (tests/test_ar_gpu.py)."""
 from __future__ import annotations
 
@@ -71,45 +71,38 @@ def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int =
         if on_done is not None:
             on_done(i)
 
-    def fill(slot: int) -> None:
-        while waiting:
-            i = waiting.popleft()
-            u = utterances[i]
-            n_new = engine._clamp_new(u.prompt.shape[1], u.max_new_tokens)
-            sp = engine._sampling(u.temperature, u.top_p, u.repetition_penalty, u.seed, u.ban_eos)
-            first = engine._start(np.ascontiguousarray(u.prompt, dtype=np.int32), sp, u.prefix, slot)
-            parked[slot] = False
-            emit(i, first[:, None])
-            if n_new <= 1 or first[0] == engine.im_end_id:
-                done(i)
-                continue                                  # finished at its first frame: the slot takes the next one
-            owner[slot], budget[slot], sps[slot] = i, n_new - 1, sp
-            return
-        owner[slot], budget[slot], sps[slot] = None, 0, idle_sp
-        if not parked[slot]:
-            engine.park(slot)
-            parked[slot] = True
+    def fill_many(slots) -> None:
+        """The free slots take the next waiting utterances: their prompt passes in ONE call (from 5 prompts as the rows of
+        one pass through the slow stack, ar_engine.prefill_many), their first frames in lock step per contiguous run of
+        slots (the reference: one prompt pass per utterance, inference.py:353-362).  A slot whose utterance is over
+        at its first frame takes the next one; slots nothing waits for are parked."""
+        free = list(slots)
+        while free and waiting:
+            take = free[:len(waiting)]
+            free = free[len(take):]
+            ids = [waiting.popleft() for _ in take]
+            us = [utterances[i] for i in ids]
+            sp = [engine._sampling(u.temperature, u.top_p, u.repetition_penalty, u.seed, u.ban_eos) for u in us]
+            firsts = engine.prefill_many([np.ascontiguousarray(u.prompt, dtype=np.int32) for u in us], sp, take,
+                                         [u.prefix for u in us])
+            for s, i, u, spi, first in zip(take, ids, us, sp, firsts):
+                parked[s] = False
+                emit(i, first[:, None])
+                n_new = engine._clamp_new(u.prompt.shape[1], u.max_new_tokens)
+                if n_new <= 1 or first[0] == engine.im_end_id:
+                    done(i)
+                    owner[s], budget[s], sps[s] = None, 0, idle_sp
+                    free.append(s)                            # finished at its first frame: the slot takes the next one
+                else:
+                    owner[s], budget[s], sps[s] = i, n_new - 1, spi
+            free.sort()
+        for s in free:
+            owner[s], budget[s], sps[s] = None, 0, idle_sp
+            if not parked[s]:
+                engine.park(s)
+                parked[s] = True
 
-    # initial fill: the prompt passes one by one, the first frames of all slots in one lock-step pass
-    n0 = min(B, len(waiting))
-    if n0 > 1:
-        first_ids = [waiting.popleft() for _ in range(n0)]
-        us = [utterances[i] for i in first_ids]
-        sp0 = [engine._sampling(u.temperature, u.top_p, u.repetition_penalty, u.seed, u.ban_eos) for u in us]
-        firsts = engine.prefill_many([u.prompt for u in us], sp0, 0, [u.prefix for u in us])
-        for s, (i, u) in enumerate(zip(first_ids, us)):
-            n_new = engine._clamp_new(u.prompt.shape[1], u.max_new_tokens)
-            emit(i, firsts[s][:, None])
-            if n_new <= 1 or firsts[s][0] == engine.im_end_id:
-                done(i)
-                fill(s)                                   # done at its first frame: the slot takes the next one
-            else:
-                owner[s], budget[s], sps[s] = i, n_new - 1, sp0[s]
-        for s in range(n0, B):
-            fill(s)
-    else:
-        for s in range(B):
-            fill(s)
+    fill_many(range(B))                                       # longest budgets first, into the lowest slots
     while True:
         active = [s for s in range(B) if owner[s] is not None]
         if not active:
@@ -119,6 +112,7 @@ def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int =
         frames, n = engine.decode(k, sps[:width], poll=k)
         stats["frame_steps"] += k
         stats["slot_frames"] += k * width
+        freed = []
         for s in active:
             i = owner[s]
             got = int(n[s])
@@ -127,5 +121,6 @@ def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int =
             ended = got < k or (got > 0 and frames[s, got - 1, 0] == engine.im_end_id)
             if ended or budget[s] <= 0:
                 done(i)
-                fill(s)
+                freed.append(s)
+        fill_many(freed)                                      # every slot this burst freed, in one refill
     return stats

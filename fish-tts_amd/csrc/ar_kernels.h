@@ -381,6 +381,8 @@ struct AttnP {
     bf16_t* y_bf;    // optional bf16 copy of y
     int y_xo_ldm;    // > 0: y_bf is octet-major Xo[H * hd / 8][y_xo_ldm][8] (wide_kernels.h), and y may be null
     bf16_t* q_out;   // kv_only pass: the normalised, rotated queries [row][H*hd] for the MFMA prompt attention
+    const int2* row_sp;  // ragged prompt pass of several slots (prefill_rope_append_kernel): row -> (slot, cache position);
+                         // kc / vc then are the layer's base pointers and cache_m_stride the elements between slots
 };
 
 template <typename WT, int G, int ROUND>
@@ -561,12 +563,14 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(AttnP p) {
     constexpr int HP = HD / 2;
     static_assert(HP <= 64, "one lane per rotated pair");
     const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pos = p.pos_off + row;
+    int pos = p.pos_off + row;
+    size_t coff = 0;
+    if (p.row_sp) { const int2 sp = p.row_sp[row]; pos = sp.y; coff = (size_t)sp.x * p.cache_m_stride; }
     const float* qkv = p.qkv + (size_t)row * p.ldq;
     const bf16_t* qn = reinterpret_cast<const bf16_t*>(p.qn);
     const bf16_t* kn = reinterpret_cast<const bf16_t*>(p.kn);
-    bf16_t* kc = reinterpret_cast<bf16_t*>(p.kc);
-    bf16_t* vc = reinterpret_cast<bf16_t*>(p.vc);
+    bf16_t* kc = reinterpret_cast<bf16_t*>(p.kc) + coff;
+    bf16_t* vc = reinterpret_cast<bf16_t*>(p.vc) + coff;
     float c = 1.f, sn = 0.f;
     if (lane < HP) { c = p.rope[((size_t)pos * HP + lane) * 2]; sn = p.rope[((size_t)pos * HP + lane) * 2 + 1]; }
     const int items = p.H + 2 * p.Hkv;

@@ -495,6 +495,11 @@ struct FlashP {
     bf16_t* y_bf;       // [S][H*hd]
     int S, H, Hkv, hd, n_slots, pos0;
     float scale;
+    // ragged pass over the prompts of several slots (grid.z = sequence): seqs[z] = {first row, rows, first cache position,
+    // slot}; q / y_bf rows are the concatenated prompts, kc / vc the layer's base pointers, cache_m_stride the elements
+    // between slots.  Blocks past a sequence's last query tile leave at once.
+    const int4* seqs;
+    size_t cache_m_stride;
 };
 template <int HD, int NG>
 __global__ __launch_bounds__(512) void flash_prefill_kernel(FlashP p) {
@@ -523,20 +528,30 @@ __global__ __launch_bounds__(512) void flash_prefill_kernel(FlashP p) {
     const int G = p.H / p.Hkv, kvh = h / G;
     const bf16_t* kc = p.kc + (size_t)kvh * p.n_slots * HD;
     const bf16_t* vc = p.vc + (size_t)kvh * p.n_slots * HD;
+    const bf16_t* qbase = p.q;
+    bf16_t* ybase = p.y_bf;
+    int S = p.S, pos0 = p.pos0;
+    if (p.seqs) {
+        const int4 sq = p.seqs[blockIdx.z];
+        S = sq.y; pos0 = sq.z;
+        if (q0 >= S) return;                               // the whole block: no barrier has been reached yet
+        qbase += (size_t)sq.x * p.H * HD; ybase += (size_t)sq.x * p.H * HD;
+        kc += (size_t)sq.w * p.cache_m_stride; vc += (size_t)sq.w * p.cache_m_stride;
+    }
     // Q fragments of this wave's 16 rows (A operand: row = lane & 15, 8 consecutive d per lane)
-    const int qrow = min(q0 + qw * 16 + fr, p.S - 1);
+    const int qrow = min(q0 + qw * 16 + fr, S - 1);
     bf16x8 qf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
-        qf[s] = *reinterpret_cast<const bf16x8*>(p.q + (size_t)qrow * p.H * HD + (size_t)h * HD + s * 32 + fq * 8);
+        qf[s] = *reinterpret_cast<const bf16x8*>(qbase + (size_t)qrow * p.H * HD + (size_t)h * HD + s * 32 + fq * 8);
     f32x4 O[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) O[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float mrun[4], lrun[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.f; }
-    const int last_row = min(q0 + QROWS - 1, p.S - 1);
-    const int kmax = p.pos0 + last_row;                    // last visible key of the block
+    const int last_row = min(q0 + QROWS - 1, S - 1);
+    const int kmax = pos0 + last_row;                    // last visible key of the block
     // K/V rows of a step (NG * KT keys) travel in registers TWO steps ahead of their use, in two named register sets; every
     // load is unconditional (rows past the last visible key re-read that key's row: they are masked below), so no branch sits
     // between a load and its use and the counted waits never drain the pipeline.  Each thread owns CPT 16-byte pieces.
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(512) void flash_prefill_kernel(FlashP p) {
         float pr[2][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int qabs = p.pos0 + q0 + qw * 16 + fq * 4 + r;
+            const int qabs = pos0 + q0 + qw * 16 + fq * 4 + r;
             float s0 = sc[0][r] * p.scale, s1 = sc[1][r] * p.scale;
             if (kt + fr > qabs) s0 = -INFINITY;             // causal mask (also hides the rows re-read past the last key)
             if (kt + 16 + fr > qabs) s1 = -INFINITY;
@@ -669,13 +684,13 @@ __global__ __launch_bounds__(512) void flash_prefill_kernel(FlashP p) {
             }
             const float l = row16_sum(lsum);
             const int row = q0 + qw * 16 + fq * 4 + r;
-            if (row < p.S) {
+            if (row < S) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     float o = O[t][r] * c0;
 #pragma unroll
                     for (int g = 1; g < NG; ++g) o += xbase[((size_t)((g - 1) * QW + qw) * 64 + lane) * XW + 8 + t * 4 + r] * cg[g];
-                    p.y_bf[(size_t)row * p.H * HD + (size_t)h * HD + t * 16 + fr] = f32_to_bf16_bits(o / l);
+                    ybase[(size_t)row * p.H * HD + (size_t)h * HD + t * 16 + fr] = f32_to_bf16_bits(o / l);
                 }
             }
         }

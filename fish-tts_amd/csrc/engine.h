@@ -67,6 +67,10 @@ struct ft_ctx {
     // MFMA prefill workspace (bf16 precision): S = max_seq_len rows
     float *pf_x = nullptr, *pf_qkv = nullptr, *pf_y = nullptr;
     ft::bf16_t *pf_xn = nullptr, *pf_ybf = nullptr, *pf_g = nullptr, *pf_qbf = nullptr;
+    // ragged prompt pass of several slots (ft_ar_prefill_slow_many): per sequence {first row, rows, first position, slot},
+    // per row (slot, position)
+    int4* pf_seqs = nullptr;
+    int2* pf_rows = nullptr;
     // lock-step batches of >= wide_min utterances run every Linear as one MFMA launch with the row operations folded in
     // (wide_kernels.h); their activations are octet-major bf16 Xo[width / 8][xo_ldm][8]: residual streams of the slow and
     // the fast stack, the drawn codes' embeddings, the attention output, the SwiGLU vector

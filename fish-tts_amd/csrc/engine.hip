@@ -201,6 +201,8 @@ static ft_status ar_alloc(ft_ctx* ctx) {
         FT_TRY(dmalloc(ctx, &ctx->pf_ybf, S * c.n_head * c.head_dim));
         FT_TRY(dmalloc(ctx, &ctx->pf_g, S * c.intermediate_size));
         FT_TRY(dmalloc(ctx, &ctx->pf_qbf, S * c.n_head * c.head_dim));
+        FT_TRY(dmalloc(ctx, &ctx->pf_seqs, M));
+        FT_TRY(dmalloc(ctx, &ctx->pf_rows, S));
         // wide lock-step batches (wide_kernels.h): no fast-layer f32 bias copies exist; every contraction width must be one
         // the kernel is instantiated for, every output width a whole number of its tiles
         const int HD = c.n_head * c.head_dim, HDf = c.fast_n_head * c.fast_head_dim;
@@ -1372,12 +1374,12 @@ static ft_status upload_ctl(ft_ctx* ctx, int m0, int n, const ft_sampling* sp) {
 
 // MFMA prefill (bf16 precision): the whole prompt goes through every slow layer as S = Lp rows on the
 template <int HD, int NG>
-static void flash_launch(const FlashP& fp, int Lp, hipStream_t st) {
+static void flash_launch(const FlashP& fp, int Lp, hipStream_t st, int nz = 1) {
     constexpr size_t lds = flash_prefill_lds<HD, NG>();
     static DevOnce once;
     once.run([] { hipFuncSetAttribute((const void*)flash_prefill_kernel<HD, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     constexpr int QROWS = 16 * (8 / NG);
-    flash_prefill_kernel<HD, NG><<<dim3(fp.H, (Lp + QROWS - 1) / QROWS), 512, lds, st>>>(fp);
+    flash_prefill_kernel<HD, NG><<<dim3(fp.H, (Lp + QROWS - 1) / QROWS, nz), 512, lds, st>>>(fp);
 }
 
 template <int BM, int BN, int NWM, int NWN, int DEPTH = 4, int MINW = 1>
@@ -1435,7 +1437,14 @@ static void pf_gemm(Launch& L, const bf16_t* X, long ldx, int S, const void* W, 
     L.chk();
 }
 
-static void prefill_gemm(Launch& L, int slot, int Lp, int pos0, bool with_tail = true) {
+// rg: the rows are the prompts of rg->n slots back to back (ctx->pf_seqs / pf_rows describe them; Lp = all rows, slot and
+// pos0 unused): the Linear products and norms do not care, the K/V append and the attention go by sequence.
+struct RaggedPf { int n, max_lp; };
+static __global__ __launch_bounds__(256) void gather_last_rows_kernel(const float* pf_x, int D, const int4* seqs, float* x) {
+    const int4 sq = seqs[blockIdx.x];
+    for (int d = threadIdx.x; d < D; d += 256) x[(size_t)sq.w * D + d] = pf_x[(size_t)(sq.x + sq.y - 1) * D + d];
+}
+static void prefill_gemm(Launch& L, int slot, int Lp, int pos0, bool with_tail = true, const RaggedPf* rg = nullptr) {
     ft_ctx* ctx = L.ctx;
     const ft_ar_config& c = ctx->c;
     const int D = c.dim, HD = c.n_head * c.head_dim, F = c.intermediate_size;
@@ -1459,6 +1468,7 @@ static void prefill_gemm(Launch& L, int slot, int Lp, int pos0, bool with_tail =
         a.kc = (char*)l.kc + (size_t)slot * ctx->cache_m_stride * ctx->esz;
         a.vc = (char*)l.vc + (size_t)slot * ctx->cache_m_stride * ctx->esz;
         a.cache_m_stride = 0; a.pos = nullptr; a.pos_off = pos0; a.row_is_pos = 1;
+        if (rg) { a.kc = l.kc; a.vc = l.vc; a.cache_m_stride = ctx->cache_m_stride; a.row_sp = ctx->pf_rows; }
         a.H = c.n_head; a.Hkv = c.n_local_heads; a.hd = c.head_dim; a.n_slots = ctx->n_slots; a.nsplit = 1;
         a.eps = c.norm_eps; a.scale = 1.0f / sqrtf((float)c.head_dim); a.y = ctx->pf_y; a.ldy = HD; a.y_bf = ctx->pf_ybf;
         Launch LA = L;
@@ -1468,7 +1478,7 @@ static void prefill_gemm(Launch& L, int slot, int Lp, int pos0, bool with_tail =
         // (a short tail behind a long restored prefix: with four key groups per block the tiled kernel wins from 16 new
         // positions - 47.7 against 49.5 ms to the first 10 frames of 8 cloned-voice utterances with 49-token tails; round 2's
         // one-group kernel lost below 64)
-        const bool flash = !getenv("FT_PREFILL_ATTN_V0") && (c.head_dim == 64 || c.head_dim == 128) && Lp >= 16;
+        const bool flash = rg || (!getenv("FT_PREFILL_ATTN_V0") && (c.head_dim == 64 || c.head_dim == 128) && Lp >= 16);
         a.q_out = flash ? ctx->pf_qbf : nullptr;
         for (int pass = 0; pass < 2; ++pass) {
             a.kv_only = pass == 0; a.no_append = pass == 1;
@@ -1481,11 +1491,13 @@ static void prefill_gemm(Launch& L, int slot, int Lp, int pos0, bool with_tail =
             if (pass == 1 && flash) {
                 FlashP fp{ctx->pf_qbf, (const bf16_t*)a.kc, (const bf16_t*)a.vc, ctx->pf_ybf, Lp, c.n_head, c.n_local_heads,
                           c.head_dim, ctx->n_slots, pos0, a.scale};
+                int nz = 1, lp_grid = Lp;
+                if (rg) { fp.seqs = ctx->pf_seqs; fp.cache_m_stride = ctx->cache_m_stride; nz = rg->n; lp_grid = rg->max_lp; }
                 // key groups per block: four (32 query rows per block: more blocks) up to 320 positions, two beyond (measured:
                 // 3.39 against 3.46 ms per 160-position prefill, 5.24 against 4.91 at 780 - the longer walks re-read K/V twice as often)
-                const bool ng4 = Lp <= 320;
-                if (c.head_dim == 128) { if (ng4) flash_launch<128, 4>(fp, Lp, L.s); else flash_launch<128, 2>(fp, Lp, L.s); }
-                else { if (ng4) flash_launch<64, 4>(fp, Lp, L.s); else flash_launch<64, 2>(fp, Lp, L.s); }
+                const bool ng4 = lp_grid <= 320;
+                if (c.head_dim == 128) { if (ng4) flash_launch<128, 4>(fp, lp_grid, L.s, nz); else flash_launch<128, 2>(fp, lp_grid, L.s, nz); }
+                else { if (ng4) flash_launch<64, 4>(fp, lp_grid, L.s, nz); else flash_launch<64, 2>(fp, lp_grid, L.s, nz); }
                 L.chk();
                 continue;
             }
@@ -1506,6 +1518,7 @@ static void prefill_gemm(Launch& L, int slot, int Lp, int pos0, bool with_tail =
         pf_gemm(L, ctx->pf_g, F, Lp, l.w2, nullptr, D, F, ACT_NONE, ctx->pf_x, ctx->pf_x, nullptr, D, 1);
     }
     // the last position feeds the head and the fast stack through the decode kernels
+    if (rg) { gather_last_rows_kernel<<<rg->n, 256, 0, L.s>>>(ctx->pf_x, D, ctx->pf_seqs, ctx->x); L.chk(); return; }
     hipMemcpyAsync(ctx->x + (size_t)slot * D, ctx->pf_x + (size_t)(Lp - 1) * D, D * sizeof(float), hipMemcpyDeviceToDevice, L.s);
     if (!with_tail) return;   // ft_ar_prefill_slow: the first frames of several slots are drawn together later
     enqueue_fproj<bf16_t, true>(L);
@@ -1596,6 +1609,70 @@ extern "C" ft_status ft_ar_prefill_slow(ft_ctx* ctx, int32_t slot, const int32_t
     }
     if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("prefill launch: ") + hipGetErrorString(L.err));
     FT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // d_prompt is reused by the next call
+    return FT_OK;
+}
+
+// Prompt passes of several slots (a batch scheduler's initial fill and its refills; per prompt: inference.py:353-362).
+// Where lock-step batches run on the MFMA launches (ctx->wide_ok) and n reaches their width (wide_min), the prompts go
+// through the slow stack TOGETHER: their positions back to back as the rows of one pass - every Linear product streams its
+// weights once for all of them (a 48-position prompt alone is bound by the weight stream: 32 of them cost 32 streams) -
+// while the K/V append goes by (slot, position) of each row and the attention by sequence (grid.z).  Like the lock-step
+// frames of that width the products then sum in another order than a prompt pass on its own (another tile kernel from
+// 129 rows): judged against the oracle with the bf16 margin.  Fewer prompts, other precisions and shapes: one by one,
+// bit-equal to ft_ar_prefill_slow.  More rows than the workspace holds (max_seq_len): several passes.
+extern "C" ft_status ft_ar_prefill_slow_many(ft_ctx* ctx, int32_t n, const int32_t* slots, const int32_t* prompts,
+                                             const int32_t* Lps, const int32_t* pos0s) {
+    FT_TRY(ar_ready(ctx));
+    const ft_ar_config& c = ctx->c;
+    if (!slots || !prompts || !Lps || !pos0s) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill_slow_many: null argument");
+    if (n < 1 || n > c.max_batch) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill_slow_many: bad count");
+    const int R = c.num_codebooks + 1;
+    std::vector<char> seen(c.max_batch, 0);
+    std::vector<size_t> off(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        if (slots[i] < 0 || slots[i] >= c.max_batch || seen[slots[i]]) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill_slow_many: bad or repeated slot");
+        seen[slots[i]] = 1;
+        if (Lps[i] < 1 || pos0s[i] < 0) return ft_fail(ctx, FT_ERR_ARG, "ft_ar_prefill_slow_many: empty prompt");
+        if (pos0s[i] + Lps[i] >= c.max_seq_len) {
+            char buf[128];
+            snprintf(buf, sizeof buf, "Input sequence length %d exceeds max_seq_len %d", pos0s[i] + Lps[i], c.max_seq_len);
+            return ft_fail(ctx, FT_ERR_TOO_LONG, buf);
+        }
+        off[i + 1] = off[i] + (size_t)R * Lps[i];
+    }
+    const bool ragged = !ctx->prefill_v0 && ctx->wide_ok && n >= ctx->wide_min && (c.head_dim == 64 || c.head_dim == 128) &&
+                        !getenv("FT_PREFILL_ATTN_V0") && !getenv("FT_NO_RAGGED_PREFILL");
+    if (!ragged) {
+        for (int i = 0; i < n; ++i) FT_TRY(ft_ar_prefill_slow(ctx, slots[i], prompts + off[i], Lps[i], pos0s[i]));
+        return FT_OK;
+    }
+    std::vector<int> tok;
+    std::vector<int4> seqs;
+    std::vector<int2> rows;
+    for (int i0 = 0; i0 < n;) {
+        int i1 = i0, S = 0, max_lp = 0, end = 0;
+        while (i1 < n && S + Lps[i1] <= c.max_seq_len) { S += Lps[i1]; max_lp = std::max(max_lp, Lps[i1]); end = std::max(end, pos0s[i1] + Lps[i1]); ++i1; }
+        tok.assign((size_t)R * S, 0); seqs.clear(); rows.clear();
+        int row0 = 0;
+        for (int i = i0; i < i1; ++i) {
+            FT_TRY(ft_ar_reset(ctx, slots[i]));
+            for (int r = 0; r < R; ++r)
+                memcpy(&tok[(size_t)r * S + row0], prompts + off[i] + (size_t)r * Lps[i], (size_t)Lps[i] * sizeof(int));
+            seqs.push_back(int4{row0, Lps[i], pos0s[i], slots[i]});
+            for (int t = 0; t < Lps[i]; ++t) rows.push_back(int2{slots[i], pos0s[i] + t});
+            row0 += Lps[i];
+        }
+        FT_HIP(ctx, hipMemcpyAsync(ctx->d_prompt, tok.data(), tok.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        FT_HIP(ctx, hipMemcpyAsync(ctx->pf_seqs, seqs.data(), seqs.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        FT_HIP(ctx, hipMemcpyAsync(ctx->pf_rows, rows.data(), rows.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+        pick_nsplit(ctx, end);
+        Launch L{ctx, ctx->stream, 0, 1, 0};
+        const RaggedPf rg{i1 - i0, max_lp};
+        prefill_gemm(L, 0, S, 0, false, &rg);
+        if (L.err != hipSuccess) return ft_fail(ctx, FT_ERR_HIP, std::string("prefill launch: ") + hipGetErrorString(L.err));
+        FT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host vectors and d_prompt are reused by the next pass
+        i0 = i1;
+    }
     return FT_OK;
 }
 

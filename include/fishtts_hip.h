@@ -102,6 +102,15 @@ ft_status ft_ar_prefill(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_
 ft_status ft_ar_prefill_slow(ft_ctx* ctx, int32_t slot, const int32_t* prompt, int32_t Lp, int32_t pos0);
 ft_status ft_ar_first_frames(ft_ctx* ctx, int32_t slot0, int32_t n, const ft_sampling* sp, const int32_t* next_pos,
                              int32_t* out_frames);
+/* Prompt passes of n distinct slots in one call (a batch scheduler's initial fill and refills; the reference runs one
+ * prompt pass per utterance, inference.py:353-362).  prompts: the n matrices back to back, matrix i = (num_codebooks+1) x
+ * Lps[i] int32 row-major; slot i's prompt lands at cache positions [pos0s[i], pos0s[i] + Lps[i]).  From the width at
+ * which lock-step batches run on the MFMA launches (5 prompts, bf16) all prompts go through the slow stack as the rows
+ * of ONE pass (weights streamed once; K/V append and attention by sequence) - results follow the oracle within the bf16
+ * evaluation-order margin, like the lock-step frames of that width; below it (and in fp16 / fp32) the call equals n calls
+ * of ft_ar_prefill_slow bit for bit.  Follow with ft_ar_first_frames per contiguous run of slots. */
+ft_status ft_ar_prefill_slow_many(ft_ctx* ctx, int32_t n, const int32_t* slots, const int32_t* prompts,
+                                  const int32_t* Lps, const int32_t* pos0s);
 /* Marks a slot idle for lock-step decoding: it counts as already finished (ft_ar_decode reports 0 frames for
  * it and it limits nothing); a later ft_ar_prefill[_at] on the slot re-activates it.  Slots that emit
  * <|im_end|> freeze the same way on the device, so a host scheduler can refill finished slots between

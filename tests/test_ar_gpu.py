@@ -473,6 +473,84 @@ def test_wide_batch_long_contexts_vs_oracle():
             assert _margin_ok(taps, col - p.shape[1], row, 0.03 * scale), f"utterance {i} ({lens[i]} positions) diverged at {div}"
 
 
+@pytest.mark.parametrize("B,max_seq_len", [(8, 512), (12, 256), (5, 2048)])
+def test_ragged_prompt_pass_vs_oracle(B, max_seq_len):
+    """ft_ar_prefill_slow_many: from 5 prompts (bf16) the prompts of a fill go through the slow stack as the rows of ONE
+    pass - Linear products over all positions at once, K/V append by (slot, position), MFMA attention by sequence - instead
+    of one prompt pass each (inference.py:353-362).  Mixed lengths from 3 positions to more than one query tile; (12, 256):
+    more rows than the workspace holds, so several passes; (5, 2048): long prompts on the 128-row tiles with a one-position
+    prompt beside them.  Judged like every path that sums in another order than the single pass: frame-0 logits of EVERY
+    slot within the bf16 evaluation-order tolerance of the oracle's, and the decoded frames follow the oracle up to a
+    decision inside its margin."""
+    shape = medium_shape(n_text=1009, max_seq_len=max_seq_len)
+    eng, orc = make_pair(shape, "bf16", std=0.05, max_batch=B, max_new_tokens=8)
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    sp = eng._sampling(0.7, 1e-6, 1.1)
+    if max_seq_len == 2048:
+        lens = [700, 1, 130, 520, 64]
+    else:
+        lens = [3 + (41 * i) % (max_seq_len // 2 - 8) for i in range(B)]
+    prompts = [make_prompt(shape, lens[i], seed=900 + i, n_vq=min(max(lens[i] - 2, 0), 4 * i)) for i in range(B)]
+    firsts = eng.prefill_many([p.numpy() for p in prompts], [sp] * B, 0)
+    logits = [eng.debug_state(i)[0].copy() for i in range(B)]
+    frames, n = eng.decode(3, [sp] * B, poll=3)
+    eng.close()
+    for i, p in enumerate(prompts):
+        taps = []
+        orc.reset()
+        want = orc.generate(p.clone(), 4, frame_taps=taps, **kw).numpy()
+        ref = taps[0][0].float().reshape(-1).numpy()
+        scale = max(1.0, float(np.max(np.abs(ref))))
+        assert np.max(np.abs(logits[i] - ref)) <= 0.05 * scale, (i, lens[i])
+        got = np.concatenate([p.numpy(), firsts[i][:, None], frames[i, : n[i]].T], axis=1)
+        div = first_divergence(got, want)
+        if div is not None:
+            col, row = div
+            assert _margin_ok(taps, col - p.shape[1], row, 0.03 * scale), f"slot {i} ({lens[i]} positions) diverged at {div}"
+
+
+def test_continuous_batching_refills_freed_slots_together_vs_oracle():
+    """run_batch at the s1-mini widths on 8 slots: six utterances with the same frame budget sit in slots 2..7 and end in
+    the same burst - their successors' prompts go through ONE ragged pass (ft_ar_prefill_slow_many, 6 >= 5 prompts) and
+    their first frames through one lock-step MFMA pass that starts at slot 2 (a batch offset the initial fill never has);
+    later refills are single slots and pairs between running neighbours.  Every judged utterance (first wave, the refill
+    of six, late refills) follows the ORACLE up to a decision inside its bf16 margin; every utterance has its budget."""
+    from fish_tts_amd.batch import Utterance, run_batch
+    shape = medium_shape(n_text=1009)
+    B = 8
+    eng, orc = make_pair(shape, "bf16", std=0.05, max_batch=B, max_new_tokens=32)
+    assert "MFMA launches" in eng.frame_path(), eng.frame_path()
+    kw = dict(temperature=0.7, top_p=1e-6, repetition_penalty=1.1)
+    budgets = [22, 19] + [9] * 6 + [8] * 6 + [5, 4, 6, 3]
+    utts = []
+    for i, b in enumerate(budgets):
+        L = 7 + (13 * i) % 60
+        utts.append(Utterance(make_prompt(shape, L, seed=1200 + i, n_vq=i % 5).numpy(), b, seed=i, **kw))
+    calls = []
+    real = eng.prefill_many
+
+    def spy(prompts, sps, slots, prefixes=None):
+        calls.append(list(slots) if not isinstance(slots, int) else list(range(slots, slots + len(prompts))))
+        return real(prompts, sps, slots, prefixes)
+    eng.prefill_many = spy
+    run_batch(eng, utts, burst=4)
+    eng.close()
+    assert calls[0] == list(range(8)) and any(len(c) >= 5 and min(c) > 0 for c in calls[1:]), calls
+    for i, u in enumerate(utts):
+        cols = u.columns()
+        assert cols.shape[1] == budgets[i] or (0 < cols.shape[1] < budgets[i] and cols[0, -1] == shape.im_end_id), (i, cols.shape)
+    for i in (0, 4, 8, 11, 13, 15, 17):
+        taps = []
+        orc.reset()
+        want = orc.generate(torch.from_numpy(utts[i].prompt), budgets[i], frame_taps=taps, **kw).numpy()
+        got = np.concatenate([utts[i].prompt, utts[i].columns()], axis=1)
+        scale = max(1.0, float(taps[0][0].float().abs().max()))
+        div = first_divergence(got[:, : want.shape[1]], want[:, : got.shape[1]])
+        if div is not None:
+            col, row = div
+            assert _margin_ok(taps, col - utts[i].prompt.shape[1], row, 0.03 * scale), f"utterance {i} diverged at {div}"
+
+
 def test_continuous_batching_equals_single_runs():
     """fish_tts_amd.batch.run_batch: 11 utterances (mixed prompt lengths, frame budgets, greedy and seeded top-p,
     one with a saved K/V prefix) through 4 slots with refill; each equals its single-slot run."""

@@ -342,8 +342,8 @@ def test_batch_scheduler_on_a_fake_engine():
             self.slot_utt[slot], self.count[slot] = (int(prompt[0, 0]), int(prompt[0, 1])), 0
             return self._frame(slot)
 
-        def prefill_many(self, prompts, sps, slot0, prefixes):
-            return np.stack([self._start(p, s, None, slot0 + i) for i, (p, s) in enumerate(zip(prompts, sps))])
+        def prefill_many(self, prompts, sps, slots, prefixes):
+            return np.stack([self._start(p, s, None, slot) for p, s, slot in zip(prompts, sps, slots)])
 
         def park(self, slot):
             self.parked.append(slot)
