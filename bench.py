@@ -197,6 +197,67 @@ def mixed_batch(eng, tok, n_utt, seed, burst=8, reps=2, codec=None, info=None):
     return made, dt
 
 
+def fill_probe(eng, tok, B):
+    """A scheduler's fill: the prompt passes of B slots as one ragged pass (ft_ar_prefill_slow_many) and, with
+    FT_NO_RAGGED_PREFILL, one pass per prompt as the reference runs them (inference.py:353-362); first frames included."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    lens = rng.integers(16, 97, B)
+    prompts = []
+    for L in lens:
+        p = np.zeros((11, int(L)), dtype=np.int32)
+        p[0] = rng.integers(0, tok.n_ranks, int(L))
+        prompts.append(p)
+    sps = [eng._sampling(0.7, 0.8, 1.1, seed=i, ban_eos=True) for i in range(B)]
+    res = {"prompt_positions": int(lens.sum())}
+    for name, off in (("one_ragged_pass_ms", False), ("one_pass_per_prompt_ms", True)):
+        if off:
+            os.environ["FT_NO_RAGGED_PREFILL"] = "1"
+        best = 1e9
+        try:
+            for rep in range(3):
+                eng.sync()
+                t0 = time.perf_counter()
+                eng.prefill_many(prompts, sps, 0)
+                best = min(best, time.perf_counter() - t0)
+        finally:
+            os.environ.pop("FT_NO_RAGGED_PREFILL", None)
+        res[name] = round(best * 1e3, 3)
+    return res
+
+
+def lockstep_streams_probe(engines, tok, B, n_frames=128, prompt_len=48):
+    """Several engines (one context + stream + weight copy each) decode B equal-length utterances each in lock step at the
+    same time, one host thread per engine: (frames of all, seconds) of the decode loops alone."""
+    import threading
+
+    import numpy as np
+    rng = np.random.default_rng(5)
+    prompts = []
+    for i in range(B):
+        p = np.zeros((11, prompt_len), dtype=np.int32)
+        p[0] = rng.integers(0, tok.n_ranks, prompt_len)
+        prompts.append(p)
+    sps = [[e._sampling(0.7, 0.8, 1.1, seed=1000 * k + i, ban_eos=True) for i in range(B)] for k, e in enumerate(engines)]
+    dt, made = 0.0, [0] * len(engines)
+    for rep in range(2):                      # the first pass captures the graphs
+        for e, sp in zip(engines, sps):
+            e.prefill_many(prompts, sp, 0)
+            e.sync()
+
+        def work(k):
+            _, n = engines[k].decode(n_frames, sps[k], poll=n_frames)
+            made[k] = int(n.sum())
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(len(engines))]
+        t0 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        dt = time.perf_counter() - t0
+    return sum(made), dt
+
+
 def lockstep_probe(eng, tok, B, n_frames=128, prompt_len=48):
     """B utterances of equal length decoded in lock step (no refill): (frames, seconds) of the decode loop alone."""
     import numpy as np
@@ -484,10 +545,28 @@ def main():
             out["configs"]["configs[2] batch=32 mixed lengths, continuous batching"] = {
                 "frames": int(made), "wall_s": round(dtm, 4), "tokens_per_s": round(made / dtm, 1),
                 "ar_rtf": round(dtm / (made * 2048 / 44100.0), 5)}
+            out["configs"]["fill of 32 slots, prompts U[16,96] (prompt passes + first frames)"] = fill_probe(beng, tok, 32)
             made, dtm = lockstep_probe(beng, tok, 32)
             out["configs"]["lock-step B=32, 48-token prompts, 128 frames (decode loop alone)"] = {
                 "frames": int(made), "wall_s": round(dtm, 4), "tokens_per_s": round(made / dtm, 1),
                 "ms_per_lockstep_frame": round(dtm / 128 * 1e3, 4)}
+            # beyond BASELINE's batch sizes: lock-step batches side by side (a frame is a chain of dependent launches that
+            # leaves most of the chip idle, so independent batches overlap): 3 engines x 32 slots = 96 utterances on the GPU
+            more = []
+            try:
+                for _ in range(2):
+                    e2 = ARHipEngine(margs, tok.semantic_begin_id, tok.semantic_end_id, im_end, precision="bf16",
+                                     device=local_rank, max_batch=32, max_new_tokens=512)
+                    more.append(e2)
+                    e2.load_state_dict(sd)
+                for n_eng in (2, 3):
+                    made, dtm = lockstep_streams_probe([beng] + more[: n_eng - 1], tok, 32)
+                    out["configs"][f"{n_eng} lock-step batches of 32 side by side ({32 * n_eng} utterances, one stream each), 128 frames"] = {
+                        "frames": int(made), "wall_s": round(dtm, 4), "tokens_per_s": round(made / dtm, 1),
+                        "ms_per_lockstep_frame_each": round(dtm / 128 * 1e3, 4)}
+            finally:
+                for e2 in more:
+                    e2.close()
             beng.close()
             out["configs"]["configs[4] voice cloning B=8 streamed"] = voice_cloning_probe(sd, tok, im_end, local_rank)
         except Exception as e:  # noqa: BLE001

@@ -124,3 +124,52 @@ def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int =
                 freed.append(s)
         fill_many(freed)                                      # every slot this burst freed, in one refill
     return stats
+
+
+def run_batch_streams(engines: Sequence[ARHipEngine], utterances: Sequence[Utterance], burst: int = 8, on_frames=None,
+                      on_done=None) -> List[dict]:
+    """Several lock-step batches SIDE BY SIDE on one GPU: one engine (context, HIP stream, weight copy, K/V caches) per
+    batch, one host thread each.  A lock-step frame is a chain of ~290 dependent launches that leaves most of the chip
+    idle, so the frames of independent batches overlap: measured at s1-mini shapes, 32 slots each -
+    one batch 14 400 tok/s, two 23 200, three 28 600 (profiles/r04_multistream.txt).  Utterances are dealt longest
+    budget first to the least loaded engine (an utterance with a saved K/V prefix goes to the engine that owns it); each
+    engine then schedules its share with run_batch.  Callbacks receive indices into `utterances` and may be called from
+    any of the threads.  Per utterance the result is what run_batch on one engine gives (its draws depend on its seed,
+    frame and codebook only).  Returns run_batch's counters per engine."""
+    import threading
+    engines = list(engines)
+    if not engines:
+        raise ValueError("run_batch_streams: no engine")
+    shares: List[List[int]] = [[] for _ in engines]
+    loads = [0] * len(engines)
+    cost = [engines[0]._clamp_new(u.prompt.shape[1], u.max_new_tokens) for u in utterances]
+    for i in sorted(range(len(utterances)), key=lambda i: -cost[i]):
+        pf = utterances[i].prefix
+        if pf is not None:
+            owners = [k for k, e in enumerate(engines) if e is pf.engine]
+            if not owners:
+                raise ValueError("run_batch_streams: a K/V prefix belongs to none of the engines")
+            k = owners[0]
+        else:
+            k = min(range(len(engines)), key=lambda k: (loads[k], k))
+        shares[k].append(i)
+        loads[k] += cost[i]
+    stats: List[Optional[dict]] = [None] * len(engines)
+    errors: List[BaseException] = []
+
+    def work(k: int) -> None:
+        share = shares[k]
+        try:
+            stats[k] = run_batch(engines[k], [utterances[i] for i in share], burst=burst,
+                                 on_frames=(lambda j, blk: on_frames(share[j], blk)) if on_frames is not None else None,
+                                 on_done=(lambda j: on_done(share[j])) if on_done is not None else None)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(k,), daemon=True) for k in range(len(engines))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return stats

@@ -584,6 +584,37 @@ def test_continuous_batching_equals_single_runs():
     eng.close()
 
 
+def test_batch_streams_side_by_side_equal_single_runs():
+    """fish_tts_amd.batch.run_batch_streams: two engines (contexts, streams, weight copies) decode their shares of 13
+    utterances AT THE SAME TIME from two host threads, 3 slots each with refill (greedy and seeded top-p, one with a saved
+    K/V prefix that pins it to its engine); every utterance equals its single-slot run bit for bit - the concurrency
+    changes no arithmetic (up to 4 slots a lock-step batch keeps the single rows' sums)."""
+    from fish_tts_amd.batch import Utterance, run_batch_streams
+    shape = tiny_shape()
+    eng_a, _ = make_pair(shape, "bf16", max_batch=3)
+    eng_b, _ = make_pair(shape, "bf16", max_batch=3)
+    utts, singles = [], []
+    for i in range(13):
+        prompt = make_prompt(shape, 6 + (5 * i) % 17, seed=400 + i, n_vq=i % 3).numpy()
+        kw = dict(temperature=0.7, top_p=1e-6 if i % 2 == 0 else 0.8, repetition_penalty=1.1, seed=90 + i)
+        budget = 3 + (4 * i) % 13
+        singles.append(eng_a.generate(prompt, budget, **kw))
+        utts.append(Utterance(prompt, budget, **kw))
+    pf = eng_b.build_prefix(utts[5].prompt[:, :5])
+    utts[5].prefix = pf
+    seen = {}
+    stats = run_batch_streams([eng_a, eng_b], utts, burst=4,
+                              on_frames=lambda i, blk: seen.__setitem__(i, seen.get(i, 0) + blk.shape[1]))
+    assert all(st["frame_steps"] > 0 for st in stats)
+    for i, (u, want) in enumerate(zip(utts, singles)):
+        got = np.concatenate([u.prompt, u.columns()], axis=1)
+        assert np.array_equal(got, want), i
+        assert seen[i] == u.columns().shape[1]
+    pf.free()
+    eng_a.close()
+    eng_b.close()
+
+
 def test_eager_frame_equals_graph_replay(monkeypatch):
     shape = tiny_shape()
     prompt = make_prompt(shape, 9, seed=1, n_vq=3).numpy()

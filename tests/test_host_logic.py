@@ -311,63 +311,68 @@ def test_stream_raises_and_frees_the_lock_when_the_decoder_worker_dies(monkeypat
     assert b"".join(out) == np.arange(4, dtype=np.int16).tobytes()   # the first chunk came through
 
 
+class FakeEngine:
+    """Stands in for ARHipEngine in the scheduler tests: frame (1000 uid + count) for every row, <|im_end|> at eos_at."""
+    max_batch, R, im_end_id, max_new_tokens = 3, 11, 99, 64
+
+    def __init__(self):
+        self.slot_utt, self.count, self.widths, self.parked, self.prefills = {}, {}, [], [], []
+
+    def _sampling(self, *a):
+        return a
+
+    def _clamp_new(self, T, n):
+        return min(n, self.max_new_tokens)
+
+    def _frame(self, slot):
+        self.count[slot] += 1
+        uid, eos_at = self.slot_utt[slot]
+        f = np.full(self.R, 1000 * uid + self.count[slot], dtype=np.int32)
+        if eos_at and self.count[slot] == eos_at:
+            f[0] = self.im_end_id
+        return f
+
+    def _start(self, prompt, sp, prefix, slot):
+        self.prefills.append((int(prompt[0, 0]), slot))
+        self.slot_utt[slot], self.count[slot] = (int(prompt[0, 0]), int(prompt[0, 1])), 0
+        return self._frame(slot)
+
+    def prefill_many(self, prompts, sps, slots, prefixes):
+        return np.stack([self._start(p, s, None, slot) for p, s, slot in zip(prompts, sps, slots)])
+
+    def park(self, slot):
+        self.parked.append(slot)
+        self.slot_utt.pop(slot, None)
+
+    def decode(self, k, sps, poll):
+        self.widths.append(len(sps))
+        frames = np.zeros((len(sps), k, self.R), dtype=np.int32)
+        n = np.zeros(len(sps), dtype=np.int32)
+        for s in range(len(sps)):
+            if s not in self.slot_utt:
+                continue
+            for j in range(k):
+                frames[s, j] = self._frame(s)
+                n[s] = j + 1
+                if frames[s, j, 0] == self.im_end_id:
+                    self.slot_utt.pop(s)
+                    break
+        return frames, n
+
+
+def _fake_utt(uid, budget, eos_at=0):
+    from fish_tts_amd.batch import Utterance
+    p = np.zeros((11, 4), dtype=np.int32)
+    p[0, 0], p[0, 1] = uid, eos_at
+    return Utterance(p, budget)
+
+
 def test_batch_scheduler_on_a_fake_engine():
     """fish_tts_amd.batch.run_batch without a GPU: a fake engine that emits frame counters checks the host policy -
     longest budget first into the lowest slots, one lock-step pass for the initial first frames, refill of finished
     slots, idle slots parked, burst width = 1 + highest active slot, budgets and <|im_end|> respected."""
-    from fish_tts_amd.batch import Utterance, run_batch
-
-    class FakeEngine:
-        max_batch, R, im_end_id, max_new_tokens = 3, 11, 99, 64
-
-        def __init__(self):
-            self.slot_utt, self.count, self.widths, self.parked, self.prefills = {}, {}, [], [], []
-
-        def _sampling(self, *a):
-            return a
-
-        def _clamp_new(self, T, n):
-            return min(n, self.max_new_tokens)
-
-        def _frame(self, slot):
-            self.count[slot] += 1
-            uid, eos_at = self.slot_utt[slot]
-            f = np.full(self.R, 1000 * uid + self.count[slot], dtype=np.int32)
-            if eos_at and self.count[slot] == eos_at:
-                f[0] = self.im_end_id
-            return f
-
-        def _start(self, prompt, sp, prefix, slot):
-            self.prefills.append((int(prompt[0, 0]), slot))
-            self.slot_utt[slot], self.count[slot] = (int(prompt[0, 0]), int(prompt[0, 1])), 0
-            return self._frame(slot)
-
-        def prefill_many(self, prompts, sps, slots, prefixes):
-            return np.stack([self._start(p, s, None, slot) for p, s, slot in zip(prompts, sps, slots)])
-
-        def park(self, slot):
-            self.parked.append(slot)
-            self.slot_utt.pop(slot, None)
-
-        def decode(self, k, sps, poll):
-            self.widths.append(len(sps))
-            frames = np.zeros((len(sps), k, self.R), dtype=np.int32)
-            n = np.zeros(len(sps), dtype=np.int32)
-            for s in range(len(sps)):
-                if s not in self.slot_utt:
-                    continue
-                for j in range(k):
-                    frames[s, j] = self._frame(s)
-                    n[s] = j + 1
-                    if frames[s, j, 0] == self.im_end_id:
-                        self.slot_utt.pop(s)
-                        break
-            return frames, n
-
-    def utt(uid, budget, eos_at=0):
-        p = np.zeros((11, 4), dtype=np.int32)
-        p[0, 0], p[0, 1] = uid, eos_at
-        return Utterance(p, budget)
+    from fish_tts_amd.batch import run_batch
+    utt = _fake_utt
     eng = FakeEngine()
     utts = [utt(1, 5), utt(2, 30), utt(3, 12, eos_at=7), utt(4, 9), utt(5, 20)]
     seen = []
@@ -380,6 +385,39 @@ def test_batch_scheduler_on_a_fake_engine():
     assert eng.widths[0] == 3 and eng.widths[-1] == 1                 # the lock-step width narrows while the queue drains
     assert sorted(set(eng.parked)) == [0, 1, 2] and sum(n for _, n in seen) == sum(got)   # every slot ends parked
     run_batch(eng, [], burst=4)                                       # nothing to do: every slot parked, no decode
+
+
+def test_batch_streams_deal_and_collect_on_fake_engines():
+    """fish_tts_amd.batch.run_batch_streams without a GPU: several lock-step batches side by side (one engine and one host
+    thread each) - utterances dealt longest budget first to the least loaded engine, callbacks carry indices into the
+    caller's list, every utterance gets its budget (or stops at its <|im_end|>), an engine-side error surfaces."""
+    from fish_tts_amd.batch import run_batch_streams
+    engs = [FakeEngine(), FakeEngine()]
+    budgets = [5, 30, 12, 9, 20, 7, 7, 16, 3]
+    utts = [_fake_utt(i + 1, b, eos_at=7 if i == 2 else 0) for i, b in enumerate(budgets)]
+    frames_of, finished = {}, []
+    stats = run_batch_streams(engs, utts, burst=4, on_frames=lambda i, blk: frames_of.__setitem__(i, frames_of.get(i, 0) + blk.shape[1]),
+                              on_done=finished.append)
+    want = [5, 30, 7, 9, 20, 7, 7, 16, 3]
+    assert [u.columns().shape[1] for u in utts] == want
+    assert [frames_of[i] for i in range(len(utts))] == want and sorted(finished) == list(range(len(utts)))
+    for i, u in enumerate(utts):                     # the frames are the utterance's own, in order
+        assert list(u.columns()[1] // 1000) == [i + 1] * want[i] and list(u.columns()[1] % 1000) == list(range(1, want[i] + 1))
+    shares = [sorted({uid for uid, _ in e.prefills}) for e in engs]
+    assert sorted(shares[0] + shares[1]) == list(range(1, 10)) and not set(shares[0]) & set(shares[1])
+    loads = [sum(budgets[uid - 1] for uid in sh) for sh in shares]
+    assert abs(loads[0] - loads[1]) <= max(budgets) // 2, loads     # longest first to the least loaded: 55 / 54 here
+    assert len(stats) == 2 and all(st["frame_steps"] > 0 for st in stats)
+    assert run_batch_streams([FakeEngine()], [], burst=4) == [{"frame_steps": 0, "slot_frames": 0}]
+
+    class Broken(FakeEngine):
+        def decode(self, k, sps, poll):
+            raise RuntimeError("device lost")
+    try:
+        run_batch_streams([FakeEngine(), Broken()], [_fake_utt(1, 5), _fake_utt(2, 6)], burst=4)
+        raise AssertionError("the engine's error must surface")
+    except RuntimeError as e:
+        assert "device lost" in str(e)
 
 
 def test_prefix_cache_is_lru_and_keyed_by_content():
