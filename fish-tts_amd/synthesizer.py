@@ -52,14 +52,21 @@ class FishTTS:
     def __init__(self, model_dir=None, device: Literal["cpu", "cuda"] = "cuda",
                  precision: Literal["bf16", "fp16", "fp32"] = "bf16", warmup: bool = True, *,
                  _synthetic: Optional[dict] = None, gpu_index: int = 0, cache_reference_kv: bool = True,
-                 max_batch: int = 1):
+                 max_batch: int = 1, batch_streams: int = 1):
         """`max_batch` (extension): utterance slots for synthesize_batch (lock-step batch with refill).
+        `batch_streams` (extension): synthesize_batch of more than `max_batch` texts runs that many lock-step batches
+        side by side (one engine - context, stream, weight copy - per batch, created on first use): a lock-step frame
+        leaves most of the chip idle, so independent batches overlap (batch.run_batch_streams; three is the measured
+        optimum at 32 slots each).
         `cache_reference_kv` (extension): keep the K/V of the reference part of the prompt on
         the device per voice, so a cloned-voice call prefills only the new text (the reference re-prefills ~700
         prompt positions per call: synthesizer.py:363-377, inference.py:779-793)."""
         from .generation import PrefixCache
         self._prefix_cache = PrefixCache() if cache_reference_kv else None
         self._max_batch = int(max_batch)
+        self._batch_streams = max(1, int(batch_streams))
+        self._more_engines: list = []
+        self._engine_factory = None
         self.device = device
         self._precision = precision
         self._warmup = warmup
@@ -102,10 +109,15 @@ class FishTTS:
         args = DualARModelArgs.from_pretrained(str(self._model_dir))
         self._tokenizer = load_tokenizer(self._model_dir)
         tok = self._tokenizer
-        self._engine = ARHipEngine(args, tok.semantic_begin_id, tok.semantic_end_id, tok.get_token_id(IM_END_TOKEN),
-                                   precision=self._precision, device=self._gpu_index, max_batch=self._max_batch,
-                                   max_new_tokens=2048 + 8)
-        self._engine.load_state_dict(load_checkpoint(self._model_dir))
+
+        def make_engine():
+            eng = ARHipEngine(args, tok.semantic_begin_id, tok.semantic_end_id, tok.get_token_id(IM_END_TOKEN),
+                              precision=self._precision, device=self._gpu_index, max_batch=self._max_batch,
+                              max_new_tokens=2048 + 8)
+            eng.load_state_dict(load_checkpoint(self._model_dir))
+            return eng
+        self._engine_factory = make_engine
+        self._engine = make_engine()
         logger.info("Transformer loaded in %.1fs", time.perf_counter() - t0)
         codec_path = self._model_dir / "codec.pth"
         if codec_path.exists():
@@ -127,10 +139,15 @@ class FishTTS:
         import torch
         self._tokenizer = tokenizer
         dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(self._precision, torch.float32)
-        self._engine = ARHipEngine(args, tokenizer.semantic_begin_id, tokenizer.semantic_end_id,
-                                   tokenizer.get_token_id(IM_END_TOKEN), precision=self._precision,
-                                   device=self._gpu_index, max_batch=self._max_batch, max_new_tokens=max_new_tokens)
-        self._engine.load_state_dict(random_state_dict(args, seed=seed, dtype=dtype, std=std))
+
+        def make_engine():
+            eng = ARHipEngine(args, tokenizer.semantic_begin_id, tokenizer.semantic_end_id,
+                              tokenizer.get_token_id(IM_END_TOKEN), precision=self._precision,
+                              device=self._gpu_index, max_batch=self._max_batch, max_new_tokens=max_new_tokens)
+            eng.load_state_dict(random_state_dict(args, seed=seed, dtype=dtype, std=std))
+            return eng
+        self._engine_factory = make_engine
+        self._engine = make_engine()
         if with_codec:
             self._vocoder = CodecHipEngine.synthetic(device=self._gpu_index, max_frames=max_new_tokens, seed=seed,
                                                      args=codec_args, with_encoder=with_encoder)
@@ -138,10 +155,10 @@ class FishTTS:
     @classmethod
     def synthetic(cls, args, tokenizer, codec_args=None, precision="bf16", seed: int = 0, warmup: bool = False,
                   with_codec: bool = True, max_new_tokens: int = 2048 + 8, std=None, gpu_index: int = 0,
-                  cache_reference_kv: bool = True, max_batch: int = 1) -> "FishTTS":
+                  cache_reference_kv: bool = True, max_batch: int = 1, batch_streams: int = 1) -> "FishTTS":
         """Random-init model of the given shapes (no checkpoint on disk): benches, smoke tests."""
         return cls(None, "cuda", precision, warmup, gpu_index=gpu_index, cache_reference_kv=cache_reference_kv,
-                   max_batch=max_batch,
+                   max_batch=max_batch, batch_streams=batch_streams,
                    _synthetic=dict(args=args, tokenizer=tokenizer, codec_args=codec_args, seed=seed,
                                    with_codec=with_codec, max_new_tokens=max_new_tokens, std=std))
 
@@ -240,7 +257,7 @@ class FishTTS:
         with refill (fish_tts_amd.batch); utterance i uses seed + i, or seeds[i] when `seeds` is given (a sharded run
         passes the GLOBAL indices so an utterance draws the same noise on any number of GPUs).  Same per-utterance
         semantics as synthesize()."""
-        from .batch import Utterance, run_batch
+        from .batch import Utterance, run_batch, run_batch_streams
         from .prompt import build_prompt_split
         assert 0 < top_p <= 1, "top_p must be in (0, 1]"
         assert 0 < repetition_penalty < 2, "repetition_penalty must be in (0, 2)"
@@ -251,16 +268,25 @@ class FishTTS:
         ncb = self._engine.args.num_codebooks
         with self._gen_lock:
             utts = []
+            engines = [self._engine]
+            if self._batch_streams > 1 and len(texts) > self._max_batch:
+                while len(self._more_engines) < self._batch_streams - 1:      # created on first use, kept
+                    self._more_engines.append(self._engine_factory())
+                engines += self._more_engines
             for i, text in enumerate(texts):
                 enc, n_prefix = build_prompt_split(self._tokenizer, text, prompt_text, prompt_tokens, ncb)
                 if enc.shape[1] > self._engine.args.max_seq_len - 2048:
                     raise ValueError(f"Prompt is too long: {enc.shape[1]} > {self._engine.args.max_seq_len - 2048}")
                 prefix = None
                 if self._prefix_cache is not None and n_prefix >= self._prefix_cache.min_positions:
-                    prefix = self._prefix_cache.get(self._engine, enc[:, :n_prefix])
+                    # a saved prefix lives in one engine's memory and pins its utterance there: spread them evenly
+                    prefix = self._prefix_cache.get(engines[i % len(engines)], enc[:, :n_prefix])
                 utts.append(Utterance(enc, max_tokens, temperature, top_p, repetition_penalty, seeds[i] if seeds is not None else seed + i,
                                       prefix=prefix))
-            run_batch(self._engine, utts)
+            if len(engines) > 1:
+                run_batch_streams(engines, utts)
+            else:
+                run_batch(self._engine, utts)
         out = []
         for u in utts:
             codes = u.codes()

@@ -169,6 +169,32 @@ def test_synthesize_batch_equals_synthesize(tts):
     assert synth.synthesize_batch([], max_tokens=10, **kw) == []
 
 
+def test_synthesize_batch_on_side_by_side_streams_equals_synthesize():
+    """FishTTS(max_batch=2, batch_streams=2): seven texts (more than one batch holds) go through two lock-step batches
+    side by side (batch.run_batch_streams: two engines, two host threads); every WAV equals synthesize() of its text with
+    the same seed - with and without a cloned voice (whose K/V prefix is built per engine and pins its utterances)."""
+    import fish_tts_amd as ft
+    from fish_tts_amd.tokenizer import NAMED_SPECIAL_TOKENS, ByteTokenizer
+    shape = dataclasses.replace(tiny_shape(), max_seq_len=2304)
+    tok = ByteTokenizer(256, NAMED_SPECIAL_TOKENS + [f"<|semantic:{i}|>" for i in range(2048)])
+    synth = ft.FishTTS.synthetic(args_from_shape(shape), tok, codec_args=codec_args_from_shape(api_codec_shape()), precision="bf16",
+                                 max_new_tokens=96, max_batch=2, batch_streams=2)
+    kw = dict(temperature=0.7, top_p=0.8, repetition_penalty=1.1)
+    texts = ["Hi there", "Yo", "A third, longer sentence.", "Four", "Five is here too", "Six.", "And the seventh text"]
+    singles = [synth.synthesize(t, max_tokens=10, **kw) for t in texts]          # synthesize() draws with seed 0
+    assert synth.synthesize_batch(texts, max_tokens=10, seeds=[0] * len(texts), **kw) == singles
+    assert len(synth._more_engines) == 1
+    rng = np.random.default_rng(0)
+    ref = np.concatenate([rng.integers(0, 2048, (1, 40)), rng.integers(0, 1024, (9, 40))]).astype(np.int32)
+    prof = ft.VoiceProfile(codes=ref, text="the reference text", name="v")
+    cloned = [synth.synthesize(t, references=[prof], max_tokens=8, **kw) for t in texts[:5]]
+    assert synth.synthesize_batch(texts[:5], references=[prof], max_tokens=8, seeds=[0] * 5, **kw) == cloned
+    for e in synth._more_engines:
+        e.close()
+    synth._engine.close()
+    synth._vocoder.close()
+
+
 def _write_ar_directory(tmp_path):
     """A directory laid out like the reference's checkpoint (synthesizer.py:158-197, llama.py:466-500): config.json,
     model.pth with a "state_dict" wrapper, "model." prefixes, separate wq / wk / wv, an audio_* tensor;
