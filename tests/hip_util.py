@@ -11,6 +11,20 @@ def args_from_shape(shape: O.ARShape):
     return DualARModelArgs(**{k: v for k, v in shape.__dict__.items() if k in names})
 
 
+_WEIGHTS = {}
+
+
+def cached_random_weights(shape: O.ARShape, **kw):
+    """oracle.ar.random_weights, generated once per (widths, seed, std, dtype, loud rows) and test run: the 700 M seeded
+    parameters of the full-depth fixtures take seconds to draw and nine GPU tests share two sets of them.  (The weights
+    do not depend on max_seq_len; callers must not modify the tensors.)"""
+    dims = tuple(sorted((k, str(v)) for k, v in shape.__dict__.items() if k != "max_seq_len"))
+    key = (dims, tuple(sorted((k, str(v)) for k, v in kw.items())))
+    if key not in _WEIGHTS:
+        _WEIGHTS[key] = O.random_weights(shape, **kw)
+    return _WEIGHTS[key]
+
+
 def make_pair(shape: O.ARShape, precision: str, seed: int = 0, max_batch: int = 1, max_new_tokens: int = 64,
               std=None):
     from fish_tts_amd.ar_engine import ARHipEngine

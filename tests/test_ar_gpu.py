@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import ar as O
-from tests.hip_util import NoiseTape, args_from_shape, first_divergence, make_pair
+from tests.hip_util import NoiseTape, args_from_shape, cached_random_weights, first_divergence, make_pair
 from tests.shapes import make_prompt, tiny_shape, tiny_shape_b
 
 pytestmark = pytest.mark.gpu
@@ -184,7 +184,7 @@ def test_s1mini_shapes_greedy_vs_reference_golden():
     from tests.shapes import s1mini_shape
     g = np.load(os.path.join(G, "ar_s1mini.npz"))
     shape = s1mini_shape()
-    w = O.random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]), dtype=torch.bfloat16)
+    w = cached_random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]), dtype=torch.bfloat16)
     eng = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,
                       precision="bf16", device=0, max_batch=3, max_new_tokens=16)
     eng.load_state_dict(w)
@@ -391,6 +391,9 @@ def test_batch32_mixed_lengths_equals_single(monkeypatch, precision):
     eng.close()
 
 
+_WIDE_ORACLE = {}    # utterance index -> (oracle sequence, taps) of test_wide_batch_vs_oracle's prompts
+
+
 @pytest.mark.parametrize("B,env", [(5, None), (8, None), (16, None), (19, None), (32, None), (40, None),
                                    (32, "FT_NO_ATTN_WIDE"), (32, "FT_NO_HEAD_STREAM")])
 def test_wide_batch_vs_oracle(monkeypatch, B, env):
@@ -415,9 +418,12 @@ def test_wide_batch_vs_oracle(monkeypatch, B, env):
     for i, p in enumerate(prompts):
         if i % 3 and B > 8 and i != B - 1:
             continue                                   # the oracle is slow: every third utterance of the big batch, and the last row
-        taps = []
-        orc.reset()
-        want = orc.generate(p.clone(), 6, frame_taps=taps, **kw).numpy()
+        # utterance i has the same prompt, weights and sampling in every parametrisation: the oracle follows it once per run
+        if i not in _WIDE_ORACLE:
+            taps = []
+            orc.reset()
+            _WIDE_ORACLE[i] = (orc.generate(p.clone(), 6, frame_taps=taps, **kw).numpy(), taps)
+        want, taps = _WIDE_ORACLE[i]
         got = np.concatenate([p.numpy(), firsts[i][:, None], frames[i, : n[i]].T], axis=1)
         scale = max(1.0, float(taps[0][0].float().abs().max()))
         div = first_divergence(got, want)
@@ -482,7 +488,7 @@ def test_wide_batch_long_contexts_vs_oracle():
             assert _margin_ok(taps, col - p.shape[1], row, 0.03 * scale), f"utterance {i} ({lens[i]} positions) diverged at {div}"
 
 
-@pytest.mark.parametrize("B,max_seq_len", [(8, 512), (12, 256), (5, 2048)])
+@pytest.mark.parametrize("B,max_seq_len", [(8, 512), (9, 256), (5, 2048)])
 def test_ragged_prompt_pass_vs_oracle(B, max_seq_len):
     """ft_ar_prefill_slow_many: from 5 prompts (bf16) the prompts of a fill go through the slow stack as the rows of ONE
     pass - Linear products over all positions at once, K/V append by (slot, position), MFMA attention by sequence - instead
@@ -548,7 +554,7 @@ def test_continuous_batching_refills_freed_slots_together_vs_oracle():
     for i, u in enumerate(utts):
         cols = u.columns()
         assert cols.shape[1] == budgets[i] or (0 < cols.shape[1] < budgets[i] and cols[0, -1] == shape.im_end_id), (i, cols.shape)
-    for i in (0, 4, 8, 11, 13, 15, 17):
+    for i in (0, 4, 8, 13, 17):
         taps = []
         orc.reset()
         want = orc.generate(torch.from_numpy(utts[i].prompt), budgets[i], frame_taps=taps, **kw).numpy()
@@ -788,8 +794,8 @@ def _teacher_forced(g, pre, tag, precision, max_seq_len, min_judged=0.8, launch_
     from tests.shapes import s1mini_shape
     shape = s1mini_shape(max_seq_len=max_seq_len)
     dtype = torch.float32 if precision == "fp32" else torch.bfloat16
-    w = O.random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]), dtype=dtype,
-                         loud=(int(g["loud_n"]), float(g["loud_factor"])))
+    w = cached_random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]), dtype=dtype,
+                              loud=(int(g["loud_n"]), float(g["loud_factor"])))
     eng = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,
                       precision=precision, device=0, max_batch=1, max_new_tokens=8)
     eng.load_state_dict(w)
@@ -892,8 +898,8 @@ def test_s1mini_ragged_prompt_pass_vs_reference_fixture():
     from tests.shapes import s1mini_shape
     g = np.load(os.path.join(G, "ar_s1mini_tf_long.npz"))
     shape = s1mini_shape(max_seq_len=int(g["max_seq_len"]))
-    w = O.random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]), dtype=torch.bfloat16,
-                         loud=(int(g["loud_n"]), float(g["loud_factor"])))
+    w = cached_random_weights(shape, seed=int(g["seed_w"]), std=float(g["std"]), dtype=torch.bfloat16,
+                              loud=(int(g["loud_n"]), float(g["loud_factor"])))
     eng = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,
                       precision="bf16", device=0, max_batch=8, max_new_tokens=8)
     eng.load_state_dict(w)
@@ -964,7 +970,7 @@ def test_batch32_wide_path_at_full_depth_vs_oracle_and_single_runs():
     from fish_tts_amd.ar_engine import ARHipEngine
     from tests.shapes import s1mini_shape
     shape = s1mini_shape(max_seq_len=1024)
-    w = O.random_weights(shape, seed=0, std=0.05, dtype=torch.bfloat16)
+    w = cached_random_weights(shape, seed=0, std=0.05, dtype=torch.bfloat16)
     B, n_dec = 32, 3
     eng = ARHipEngine(args_from_shape(shape), shape.semantic_begin_id, shape.semantic_end_id, shape.im_end_id,
                       precision="bf16", device=0, max_batch=B, max_new_tokens=16)
