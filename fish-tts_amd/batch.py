@@ -59,6 +59,12 @@ def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int =
     parked = [False] * B
 
     stats = {"frame_steps": 0, "slot_frames": 0}
+    # A draining batch of 2..4 rows would fall back to the multi-row GEMV frame (~325 launches, 3.07 ms at s1-mini shapes)
+    # while 5 rows run the MFMA launches (2.22 ms): where the engine has that path and the batch was wide to begin with,
+    # the last rows keep it by taking parked slots along.  (Batches of <= 4 slots never leave the GEMV path: their rows
+    # stay bit-equal to single runs.)
+    path = engine.frame_path() if hasattr(engine, "frame_path") else ""
+    wide_from = 5 if "MFMA launches" in path else B + 1
 
     def emit(i: int, block: np.ndarray):
         if block.shape[1] == 0:
@@ -108,6 +114,8 @@ def run_batch(engine: ARHipEngine, utterances: Sequence[Utterance], burst: int =
         if not active:
             break
         width = active[-1] + 1                            # slots above the highest active one are left out
+        if 2 <= width < wide_from <= B:
+            width = wide_from                             # (idle slots ride along: the wider launch form is the cheaper one)
         k = min([burst] + [budget[s] for s in active])
         frames, n = engine.decode(k, sps[:width], poll=k)
         stats["frame_steps"] += k
