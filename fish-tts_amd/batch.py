@@ -5,7 +5,9 @@ The reference serves one utterance at a time (synthesizer.py:431-481 under one m
 independent utterance (own prompt, K/V cache, position, penalty window, RNG stream keyed by its seed), all slots
 advance one frame per captured graph replay, a slot that emits <|im_end|> or reaches its frame budget is retired
 between bursts and the next waiting utterances are prefilled into the freed slots together; idle slots are parked.  Per utterance the result
-is what a single-slot run with the same seed produces (tests/test_ar_gpu.py)."""
+is what a single-slot run with the same seed produces: bit for bit on an engine of up to 4 slots (and in fp16 / fp32); an
+engine of >= 5 bf16 slots runs its prompt passes and frames in the MFMA batch form, whose sums take another order - those
+follow the oracle within the bf16 evaluation-order margin (tests/test_ar_gpu.py)."""
 from __future__ import annotations
 
 from collections import deque
