@@ -166,6 +166,46 @@ def test_bpe_tokenizer_algorithm():
     assert tok.encode("") == []
 
 
+def test_bpe_tokenizer_against_an_independent_bpe_engine():
+    """F3 beyond self-made cases: `tiktoken` and the model's rank file are absent, so parity with them stays unpinned -
+    but the algorithm can be held against an INDEPENDENT engine.  A byte-level BPE is trained with the `tokenizers`
+    package (Rust merge loop, Oniguruma regex) behind the reference's FISH_TIKTOKEN_PATTERN pre-split
+    (tokenizer.py:16-27); its vocabulary, turned into a tiktoken-style rank table (token bytes -> id, merges ranked in
+    training order), is given to BPETokenizer: both must encode 2 500 texts (corpus lines and random strings with
+    contractions, digits, CJK, umlauts, tabs and newlines) to the same ids."""
+    import random
+    tk = pytest.importorskip("tokenizers")
+    from tokenizers import Regex, Tokenizer, models, pre_tokenizers, trainers
+    from fish_tts_amd.tokenizer import FISH_TIKTOKEN_PATTERN, BPETokenizer
+    rnd = random.Random(0)
+    words = ["hello", "world", "the", "quick", "brown", "fox", "jumps", "over", "lazy", "dog", "Grüße", "世界", "naïve", "don't",
+             "it's", "we'll", "123", "4567", "foo_bar", "x=y+z;", "\n\n", "  tabs\t", "über", "señor", "日本語", "テキスト", "emoji😀",
+             "they've", "I'm", "you'd"]
+    corpus = [" ".join(rnd.choice(words) for _ in range(rnd.randint(3, 12))) + rnd.choice(["", ".", "!", "?\n", " \n\n", "  "])
+              for _ in range(3000)]
+    hf = Tokenizer(models.BPE())
+    hf.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.Split(Regex(FISH_TIKTOKEN_PATTERN), behavior="isolated"),
+                                                pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)])
+    hf.train_from_iterator(corpus, trainers.BpeTrainer(vocab_size=256 + 400, initial_alphabet=pre_tokenizers.ByteLevel.alphabet(),
+                                                       special_tokens=[], show_progress=False))
+    # the byte <-> printable-character table of byte-level BPE vocabularies (GPT-2's bytes_to_unicode)
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("¡"), ord("¬") + 1)) + list(range(ord("®"), ord("ÿ") + 1))
+    cs, extra = bs[:], 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + extra)
+            extra += 1
+    to_byte = {chr(c): b for b, c in zip(bs, cs)}
+    vocab = hf.get_vocab()
+    ranks = {bytes(to_byte[ch] for ch in t): i for t, i in vocab.items()}
+    assert len(ranks) == len(vocab) > 300
+    mine = BPETokenizer(ranks, ["<|semantic:0|>"])
+    texts = corpus[:500] + ["".join(rnd.choice("abc xyz\n\t'.,!?123üß世") for _ in range(rnd.randint(0, 40))) for _ in range(2000)]
+    for t in texts:
+        assert mine.encode(t, allowed_special=False) == hf.encode(t).ids, repr(t)
+
+
 def test_tiktoken_file_loader_and_from_pretrained(tmp_path):
     import base64
     import json
