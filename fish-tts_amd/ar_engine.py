@@ -46,6 +46,20 @@ def normalise_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]
     return out
 
 
+def contiguous_runs(slots: Sequence[int]) -> list:
+    """Indices into `slots`, grouped into runs of consecutive slot numbers in ascending slot order: [5, 2, 3, 9] ->
+    [[1, 2], [0], [3]] (ft_ar_first_frames draws the first frames of a contiguous slot range in one lock-step pass)."""
+    order = sorted(range(len(slots)), key=lambda i: slots[i])
+    runs, a = [], 0
+    while a < len(order):
+        b = a + 1
+        while b < len(order) and slots[order[b]] == slots[order[b - 1]] + 1:
+            b += 1
+        runs.append(order[a:b])
+        a = b
+    return runs
+
+
 class ARHipEngine:
     """One GPU context holding the dual-AR weights, KV caches and the captured frame graph."""
 
@@ -198,20 +212,13 @@ class ARHipEngine:
                                                          pos0s.ctypes.data_as(C.c_void_p)), "ft_ar_prefill")
         next_pos = (pos0s + lps).astype(np.int32)
         out = np.zeros((n, self.R), dtype=np.int32)
-        order = sorted(range(n), key=lambda i: slots[i])
-        a = 0
-        while a < n:                                   # one lock-step pass per contiguous run of slots
-            b = a + 1
-            while b < n and slots[order[b]] == slots[order[b - 1]] + 1:
-                b += 1
-            idx = order[a:b]
+        for idx in contiguous_runs(slots):             # one lock-step pass per contiguous run of slots
             arr = (L.ft_sampling * len(idx))(*[samplings[i] for i in idx])
             npos = np.ascontiguousarray(next_pos[idx])
             run = np.zeros((len(idx), self.R), dtype=np.int32)
             self._check(self.lib.ft_ar_first_frames(self._h, slots[idx[0]], len(idx), arr, npos.ctypes.data_as(C.c_void_p),
                                                     run.ctypes.data_as(C.c_void_p)), "ft_ar_first_frames")
             out[idx] = run
-            a = b
         return out
 
     def park(self, slot: int) -> None:

@@ -427,6 +427,17 @@ def test_batch_scheduler_on_a_fake_engine():
     run_batch(eng, [], burst=4)                                       # nothing to do: every slot parked, no decode
 
 
+def test_refill_slots_are_grouped_into_contiguous_runs():
+    """ARHipEngine.prefill_many draws the first frames of a refill per contiguous run of slots (ft_ar_first_frames takes a
+    slot range): the grouping, as indices into the caller's order."""
+    from fish_tts_amd.ar_engine import contiguous_runs
+    assert contiguous_runs([]) == []
+    assert contiguous_runs([4]) == [[0]]
+    assert contiguous_runs([0, 1, 2, 3]) == [[0, 1, 2, 3]]
+    assert contiguous_runs([5, 2, 3, 9]) == [[1, 2], [0], [3]]
+    assert contiguous_runs([7, 6, 5, 1, 0, 3]) == [[4, 3], [5], [2, 1, 0]]
+
+
 def test_batch_streams_deal_and_collect_on_fake_engines():
     """fish_tts_amd.batch.run_batch_streams without a GPU: several lock-step batches side by side (one engine and one host
     thread each) - utterances dealt longest budget first to the least loaded engine, callbacks carry indices into the
